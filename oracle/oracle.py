@@ -1,0 +1,181 @@
+"""ctypes wrapper around oracle/libseer_oracle.so (the CPU restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under pyseer_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_up = C.POINTER(C.c_uint)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libseer_oracle.so")
+    src = os.path.join(_HERE, "seer_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libseer_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libseer_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_chi2_sf1.restype = C.c_double; L.orc_chi2_sf1.argtypes = [C.c_double]
+        L.orc_f_sf_1.restype = C.c_double; L.orc_f_sf_1.argtypes = [C.c_double, C.c_double]
+        L.orc_t_sf2.restype = C.c_double; L.orc_t_sf2.argtypes = [C.c_double, C.c_double]
+        L.orc_firth_likelihood.restype = C.c_double
+        L.orc_lmm_create.restype = C.c_void_p
+        L.orc_lmm_nll.restype = C.c_double
+        L.orc_lmm_nll.argtypes = [C.c_void_p, C.c_double]
+        L.orc_lmm_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def chi2_sf1(x):
+    return lib().orc_chi2_sf1(float(x))
+
+
+def f_sf_1(x, d):
+    return lib().orc_f_sf_1(float(x), float(d))
+
+
+def t_sf2(t, df):
+    return lib().orc_t_sf2(float(t), float(df))
+
+
+def pre_filtering(p, k, continuous):
+    p = _d(p); k = _d(k)
+    prep = C.c_double(); bad = C.c_int()
+    lib().orc_pre_filtering(_p(p), _p(k), C.c_int(p.shape[0]), C.c_int(int(continuous)), C.byref(prep), C.byref(bad))
+    return prep.value, bool(bad.value)
+
+
+def design(k, Z):
+    k = _d(k).reshape(-1, 1)
+    n = k.shape[0]
+    cols = [np.ones((n, 1)), k]
+    if Z is not None and np.size(Z):
+        cols.append(_d(Z).reshape(n, -1))
+    return np.ascontiguousarray(np.concatenate(cols, axis=1))
+
+
+def logit_newton(X, y, start, check_separation=True):
+    X = _d(X); y = _d(y); start = _d(start)
+    n, pc = X.shape
+    beta = np.zeros(pc); bse = np.zeros(pc); llf = C.c_double(); it = C.c_int()
+    st = lib().orc_logit_newton(_p(X), _p(y), n, pc, _p(start), int(check_separation), _p(beta), _p(bse),
+                                C.byref(llf), C.byref(it))
+    return st, beta, bse, llf.value, it.value
+
+
+def firth_likelihood(X, y, beta):
+    X = _d(X); y = _d(y); beta = _d(beta)
+    return lib().orc_firth_likelihood(_p(X), _p(y), X.shape[0], X.shape[1], _p(beta))
+
+
+def fit_firth(X, y, start, step_limit=1000, convergence_limit=1e-4):
+    X = _d(X); y = _d(y); start = _d(start)
+    n, pc = X.shape
+    beta = np.zeros(pc); b1 = C.c_double(); fl = C.c_double()
+    st = lib().orc_fit_firth(_p(X), _p(y), n, pc, _p(start), int(step_limit), C.c_double(convergence_limit),
+                             _p(beta), C.byref(b1), C.byref(fl))
+    if st:
+        return None
+    return beta, b1.value, fl.value
+
+
+def ols(X, y):
+    X = _d(X); y = _d(y)
+    n, pc = X.shape
+    beta = np.zeros(pc); bse = np.zeros(pc); pv = np.zeros(pc)
+    lib().orc_ols(_p(X), _p(y), n, pc, _p(beta), _p(bse), _p(pv))
+    return beta, bse, pv
+
+
+def fixed_effects_batch(y, Kv, Z, continuous, pret, lrtt, null_llf, null_firth):
+    """Kv: (V, n) 0/1; Z: (n, q) or None. Returns dict of arrays mirroring Seer fields."""
+    y = _d(y); Kv = _d(Kv)
+    V, n = Kv.shape
+    q = 0 if Z is None or np.size(Z) == 0 else np.asarray(Z).reshape(n, -1).shape[1]
+    Zc = _d(np.asarray(Z).reshape(n, -1)) if q else np.zeros(1)
+    out5 = np.zeros((V, 5)); betas = np.zeros((V, max(q, 1)))
+    notes = np.zeros(V, dtype=np.uint32); pf = np.zeros(V, dtype=np.int32); fl = np.zeros(V, dtype=np.int32)
+    nf = float("nan") if null_firth is None else float(null_firth)
+    lib().orc_fixed_effects_batch(_p(y), _p(Kv), _p(Zc), n, q, V, int(continuous), C.c_double(pret), C.c_double(lrtt),
+                                  C.c_double(float(null_llf)), C.c_double(nf), _p(out5), _p(betas),
+                                  notes.ctypes.data_as(c_up), pf.ctypes.data_as(c_ip), fl.ctypes.data_as(c_ip))
+    return dict(prep=out5[:, 0], pvalue=out5[:, 1], kbeta=out5[:, 2], bse=out5[:, 3], intercept=out5[:, 4],
+                betas=betas[:, :q], notes=notes, prefilter=pf, filter=fl)
+
+
+def firth_batch(y, Kv, Z):
+    y = _d(y); Kv = _d(Kv)
+    V, n = Kv.shape
+    q = 0 if Z is None or np.size(Z) == 0 else np.asarray(Z).reshape(n, -1).shape[1]
+    Zc = _d(np.asarray(Z).reshape(n, -1)) if q else np.zeros(1)
+    out4 = np.zeros((V, 4)); betas = np.zeros((V, max(q, 1))); st = np.zeros(V, dtype=np.int32)
+    lib().orc_firth_batch(_p(y), _p(Kv), _p(Zc), n, q, V, _p(out4), _p(betas), st.ctypes.data_as(c_ip))
+    return dict(intercept=out4[:, 0], kbeta=out4[:, 1], bse=out4[:, 2], fitll=out4[:, 3], betas=betas[:, :q], status=st)
+
+
+class LmmOracle(object):
+    """U (n,k), S (k,), y (n,), covar (n,D) with the intercept LAST (lmm.py:95-99)."""
+
+    def __init__(self, U, S, y, covar):
+        U = _d(U); S = _d(S); y = _d(y).reshape(-1); covar = _d(covar).reshape(y.shape[0], -1)
+        self.n, self.k = U.shape
+        self.D = covar.shape[1]
+        self._h = C.c_void_p(lib().orc_lmm_create(_p(U), _p(S), self.n, self.k, _p(y), _p(covar), self.D))
+
+    def __del__(self):
+        try:
+            lib().orc_lmm_destroy(self._h)
+        except Exception:
+            pass
+
+    def nll(self, h2):
+        return lib().orc_lmm_nll(self._h, float(h2))
+
+    def block(self, h2, Xv):
+        """Xv: (B, n) variant-major. Returns (beta, bse, frac_h2, p) or raises KeyError like the reference."""
+        Xv = _d(Xv); B = Xv.shape[0]
+        o = np.zeros((4, B))
+        rc = lib().orc_lmm_block(self._h, C.c_double(h2), _p(Xv), B, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]))
+        if rc:
+            raise KeyError("beta")
+        return o[0], o[1], o[2], o[3]
+
+    def fit_lmm(self, h2, Xv, afmask, continuous, filter_pvalue, lrt_pvalue):
+        Xv = _d(Xv); V = Xv.shape[0]
+        rows = np.zeros((V, 5)); notes = np.zeros(V, dtype=np.uint32)
+        pf = np.zeros(V, dtype=np.int32); fl = np.zeros(V, dtype=np.int32)
+        am = np.ascontiguousarray(afmask, dtype=np.uint8)
+        rc = lib().orc_fit_lmm(self._h, C.c_double(h2), _p(Xv), am.ctypes.data_as(C.POINTER(C.c_ubyte)), V,
+                               int(continuous), C.c_double(filter_pvalue), C.c_double(lrt_pvalue), _p(rows),
+                               notes.ctypes.data_as(c_up), pf.ctypes.data_as(c_ip), fl.ctypes.data_as(c_ip))
+        if rc == -1:
+            raise KeyError("beta")
+        if rc:
+            raise AssertionError("length of LMM result does not match number of variants")
+        return dict(prep=rows[:, 0], pvalue=rows[:, 1], kbeta=rows[:, 2], bse=rows[:, 3], frac_h2=rows[:, 4],
+                    notes=notes, prefilter=pf, filter=fl)
