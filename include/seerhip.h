@@ -1,0 +1,112 @@
+/*
+ * seerhip.h -- flat C ABI of libseerhip.so, the MI355X (gfx950) per-variant association engine.
+ *
+ * The reference (pyseer) is pure Python and has NO FFI for this path; the boundary it exposes is the
+ * Python call signature between its variant stream and its per-variant test:
+ *     pyseer/model.py:202  fixed_effects_regression(variant,p,k,m,c,af,pattern,lineage_effects,lin,pret,lrtt,
+ *                                                   null_res,null_firth,kstrains,nkstrains,continuous) -> Seer
+ *     pyseer/lmm.py:125    fit_lmm(lmm,h2,variants,variant_mat,lineage_effects,lineage_clusters,covariates,
+ *                                  continuous,filter_pvalue,lrt_pvalue) -> [LMM]
+ *     pyseer/lmm.py:228    fit_lmm_block(lmm,h2,variant_block) -> {beta,bse,frac_h2,p_values}
+ * Each entry point below names the reference call it replaces.  INTEGRATION.md shows the ctypes stub a
+ * pyseer maintainer would add (pyseer_amd/_abi.py is that stub, in full).
+ *
+ * Conventions
+ *  - return 0 on success, a negative SH_E* code otherwise; sh_last_error() gives a thread-local message.
+ *  - no CPU fallback: every compute entry point needs a gfx950 device (sh_create fails without one).
+ *  - host-pointer calls (sh_*_batch) copy in/out and synchronise; *_dev calls take DEVICE pointers, are
+ *    asynchronous on the context's stream (sh_set_stream) and touch no host memory.
+ *  - a context is bound to one device and is NOT thread-safe; use one context per device per host thread.
+ *  - presence bits: V rows x row_bytes bytes, variant-major; bit (i & 7) of byte (i >> 3) of row v is the
+ *    presence of sample i in variant v (LSB first).  Bits at i >= n_samples are ignored.
+ *  - flags[v]: bits 0..8 = notes in the order of docs/usage.rst:553-566 (SH_NOTE_*), bit 16 = Seer/LMM.prefilter,
+ *    bit 17 = Seer/LMM.filter.
+ */
+#ifndef SEERHIP_H
+#define SEERHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SH_ABI_VERSION 1
+
+#define SH_OK          0
+#define SH_EINVAL     -1   /* bad argument / call order */
+#define SH_ENODEV     -2   /* no gfx950 device / device error */
+#define SH_ENOMEM     -3
+#define SH_EH2        -4   /* h2 outside [0,1): reference raises KeyError('beta') (lmm_cov.py:667-670) */
+#define SH_ESHAPE     -5   /* shape mismatch: reference AssertionError (lmm_cov.py:674) */
+#define SH_EHIP       -6   /* HIP runtime failure */
+
+/* notes (pyseer/model.py:253-386, pyseer/lmm.py:160-204) */
+#define SH_NOTE_AF_FILTER        (1u << 0)
+#define SH_NOTE_PRE_FILTER       (1u << 1)
+#define SH_NOTE_BAD_CHISQ        (1u << 2)
+#define SH_NOTE_HIGH_BSE         (1u << 3)
+#define SH_NOTE_PERFECT_SEP      (1u << 4)
+#define SH_NOTE_MATRIX_INV       (1u << 5)
+#define SH_NOTE_FIRTH_FAIL       (1u << 6)
+#define SH_NOTE_MISSING_DATA     (1u << 7)
+#define SH_NOTE_LRT_FILTER       (1u << 8)
+#define SH_FLAG_PREFILTER        (1u << 16)
+#define SH_FLAG_FILTER           (1u << 17)
+
+typedef struct sh_ctx sh_ctx;
+
+int         sh_abi_version(void);
+const char *sh_last_error(void);
+int         sh_device_count(void);
+
+/* one context per device; n_samples = len(p) of the reference */
+sh_ctx *sh_create(int device, int n_samples);
+void    sh_destroy(sh_ctx *ctx);
+/* enqueue all later work on this hipStream_t (NULL = the device's default stream) */
+int     sh_set_stream(sh_ctx *ctx, void *hip_stream);
+int     sh_synchronize(sh_ctx *ctx);
+/* HIP-event timing of the dominant kernel of each later *_batch_dev call (k_lmm_quadform_i8 / the GLM Newton kernel),
+ * recorded on the context's stream.  sh_get_timing synchronises on the recorded events and returns their sum. */
+int     sh_set_timing(sh_ctx *ctx, int on);
+int     sh_get_timing(sh_ctx *ctx, double *total_ms, int64_t *launches);
+/* AF filter of the variant stream (pyseer/input.py:608,693): keep min_af <= count/n <= max_af (inclusive);
+ * others get SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER and NaN statistics.  Default: disabled (0, 1). */
+int     sh_set_af_filter(sh_ctx *ctx, double min_af, double max_af);
+
+/* ---------------------------------------------------------------------------------------------
+ * LMM  (replaces pyseer/lmm.py:125 fit_lmm + :228 fit_lmm_block over pyseer/fastlmm/lmm_cov.py:165,597,686)
+ * U: n x k row-major (lmm.U; arr_0 of the --save-lmm cache), S: k (lmm.S), y: n (lmm.Y),
+ * C: n x D row-major covariates with the intercept LAST (lmm.X, pyseer/lmm.py:95-99), h2 (lmm.py:115).
+ * continuous selects the prefilter test (model.py:52-55 vs :57-68); pret/lrtt = filter_pvalue/lrt_pvalue
+ * (compared with >=, lmm.py:174,201).  n_limbs = 4..7 int8 limbs of the fixed-point kernel matrix (0 = default 5).
+ * ------------------------------------------------------------------------------------------- */
+int sh_lmm_setup(sh_ctx *ctx, const double *U, const double *S, int k, const double *y,
+                 const double *C, int D, double h2, int continuous, double pret, double lrtt, int n_limbs);
+/* per variant: prep, pvalue, beta, bse, frac_h2 (each V doubles) + flags.  Statistics are written for every
+ * variant that passes the AF filter (the caller applies the NaN masking implied by flags, lmm.py:176-217). */
+int sh_lmm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
+                 double *prep, double *pvalue, double *beta, double *bse, double *frac_h2, uint32_t *flags);
+/* device-resident variant: d_bits (V*row_bytes bytes), d_out (5*V doubles, SoA in the order above), d_flags (V). */
+int sh_lmm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
+/* introspection for tests/benchmarks: dominant-kernel work of the last batch */
+int sh_lmm_info(sh_ctx *ctx, int *n_limbs, int64_t *int8_macs_per_variant, double *quant_scale);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fixed effects (replaces pyseer/model.py:202 fixed_effects_regression = a1 prefilter + statsmodels Logit newton /
+ * OLS + model.py:414 fit_firth).  y: n; W: n x q row-major = [m | c] (MDS components then covariates, no
+ * intercept, no variant column; model.py:274-297); null_llf / null_firth from fit_null (model.py:73-148).
+ * force_firth != 0 sends every variant through fit_firth (benchmark config C4).
+ * ------------------------------------------------------------------------------------------- */
+int sh_glm_setup(sh_ctx *ctx, const double *y, const double *W, int q, int continuous,
+                 double null_llf, double null_firth, double pret, double lrtt, int force_firth);
+/* outputs: prep, pvalue, kbeta, bse, intercept (V each), betas (V*q row-major), flags (V) */
+int sh_glm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
+                 double *prep, double *pvalue, double *kbeta, double *bse, double *intercept,
+                 double *betas, uint32_t *flags);
+/* d_out: (5+q)*V doubles SoA: prep,pvalue,kbeta,bse,intercept,betas[0..q) ; d_flags: V */
+int sh_glm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

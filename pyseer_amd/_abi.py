@@ -1,0 +1,70 @@
+"""ctypes binding of libseerhip.so (include/seerhip.h).  This is the stub a pyseer maintainer would add.
+
+Fails loudly when the library or a gfx950 device is missing: there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseerhip.so")
+
+SH_OK, SH_EINVAL, SH_ENODEV, SH_ENOMEM, SH_EH2, SH_ESHAPE, SH_EHIP = 0, -1, -2, -3, -4, -5, -6
+
+c_dp = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+c_u32p = C.POINTER(C.c_uint32)
+
+# every symbol include/seerhip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "sh_abi_version": (C.c_int, []),
+    "sh_last_error": (C.c_char_p, []),
+    "sh_device_count": (C.c_int, []),
+    "sh_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "sh_destroy": (None, [C.c_void_p]),
+    "sh_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sh_synchronize": (C.c_int, [C.c_void_p]),
+    "sh_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "sh_get_timing": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int64)]),
+    "sh_set_af_filter": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "sh_lmm_setup": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_int,
+                               C.c_double, C.c_double, C.c_int]),
+    "sh_lmm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
+    "sh_lmm_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sh_lmm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), c_dp]),
+    "sh_glm_setup": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                               C.c_double, C.c_int]),
+    "sh_glm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
+    "sh_glm_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class SeerHipError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libseerhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libseerhip.so and bind every declared symbol (no device needed for this)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libseerhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                              "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sh_abi_version() != 1:
+            raise ImportError("libseerhip ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != SH_OK:
+        raise SeerHipError(rc, load().sh_last_error().decode())
+    return rc

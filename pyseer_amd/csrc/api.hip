@@ -1,0 +1,355 @@
+// api.hip -- host side of libseerhip.so: the flat C ABI declared in include/seerhip.h.
+// One-off per-run setup is done here in plain C++ (it is O(N^2 D) at most); everything per-variant is a HIP kernel.
+#include "common.h"
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+
+// ---- kernel launchers (lmm_kernels.hip / glm_kernels.hip) -----------------------------------------------------
+struct LmmLinOut { int *t11, *t01, *m; double *xky, *dg, *rss, *s1, *q1; };
+struct LmmFinParams {
+    int N, D, continuous; int n1, n0; double yc_sum, yc_sq; double yKy, inv_scale; double pret, lrtt;
+    double min_af, max_af; int af_on;
+};
+extern "C" {
+hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
+hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
+                          const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+hipError_t shk_lmm_quadform(hipStream_t, const int8_t *, const uint64_t *, int64_t, int, int, double *);
+hipError_t shk_lmm_finalize(hipStream_t, int64_t, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
+hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
+                           unsigned long long *, int8_t *);
+}
+#include "glm_api.inc"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SH_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T> static hipError_t dmalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)); }
+
+struct sh_ctx {
+    int device = 0, N = 0;
+    hipStream_t stream = nullptr;
+    double min_af = 0.0, max_af = 1.0; int af_on = 0;
+    // common per-run constants
+    int NT = 0, Np = 0, NB64 = 0, NB64p = 0;
+    // ---- LMM state
+    bool lmm_ready = false;
+    int k = 0, D = 0, L = 5, DP = 0;
+    LmmFinParams fin{};
+    double *d_vv = nullptr, *d_mdiag = nullptr, *d_yc = nullptr, *d_Qb = nullptr;
+    uint64_t *d_y1 = nullptr, *d_y0 = nullptr;
+    int8_t *d_G = nullptr;
+    double quant_scale = 0.0;
+    // ---- GLM state
+    GlmState glm;
+    // ---- per-batch workspace (grown on demand)
+    int64_t capV = 0;
+    uint64_t *d_T = nullptr;
+    int *d_t11 = nullptr, *d_t01 = nullptr, *d_m = nullptr;
+    double *d_xky = nullptr, *d_dg = nullptr, *d_rss = nullptr, *d_s1 = nullptr, *d_q1 = nullptr, *d_q = nullptr;
+    // ---- optional timing of the dominant kernel (sh_set_timing / sh_get_timing)
+    int timing = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
+    // ---- staging for the host-pointer entry points
+    int64_t cap_bits = 0, cap_out = 0;
+    uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
+};
+
+static void free_ws(sh_ctx *c)
+{
+    hipFree(c->d_T); hipFree(c->d_t11); hipFree(c->d_t01); hipFree(c->d_m); hipFree(c->d_xky); hipFree(c->d_dg);
+    hipFree(c->d_rss); hipFree(c->d_s1); hipFree(c->d_q1); hipFree(c->d_q);
+    c->d_T = nullptr; c->d_t11 = c->d_t01 = c->d_m = nullptr;
+    c->d_xky = c->d_dg = c->d_rss = c->d_s1 = c->d_q1 = c->d_q = nullptr; c->capV = 0;
+}
+
+static int ensure_ws(sh_ctx *c, int64_t Vpad)
+{
+    if (Vpad <= c->capV) return SH_OK;
+    free_ws(c);
+    HIPCHK(dmalloc(&c->d_T, (size_t)Vpad * c->NB64p));
+    HIPCHK(dmalloc(&c->d_t11, Vpad)); HIPCHK(dmalloc(&c->d_t01, Vpad)); HIPCHK(dmalloc(&c->d_m, Vpad));
+    HIPCHK(dmalloc(&c->d_xky, Vpad)); HIPCHK(dmalloc(&c->d_dg, Vpad)); HIPCHK(dmalloc(&c->d_rss, Vpad));
+    HIPCHK(dmalloc(&c->d_s1, Vpad)); HIPCHK(dmalloc(&c->d_q1, Vpad)); HIPCHK(dmalloc(&c->d_q, Vpad));
+    c->capV = Vpad;
+    return SH_OK;
+}
+
+extern "C" {
+
+int sh_abi_version(void) { return SH_ABI_VERSION; }
+const char *sh_last_error(void) { return g_err.c_str(); }
+
+int sh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+sh_ctx *sh_create(int device, int n_samples)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device: libseerhip has no CPU fallback"; return nullptr; }
+    if (device < 0 || device >= n) { g_err = "bad device index"; return nullptr; }
+    if (n_samples < 2) { g_err = "n_samples must be >= 2"; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_err = "hipGetDeviceProperties failed"; return nullptr; }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_err = std::string("device is ") + prop.gcnArchName + ", libseerhip is built for gfx950 only"; return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    sh_ctx *c = new sh_ctx();
+    c->device = device; c->N = n_samples;
+    c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
+    c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
+    return c;
+}
+
+void sh_destroy(sh_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    free_ws(c);
+    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0);
+    hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);
+    glm_free(&c->glm);
+    delete c;
+}
+
+int sh_set_stream(sh_ctx *c, void *s) { if (!c) return fail(SH_EINVAL, "null ctx"); c->stream = (hipStream_t)s; return SH_OK; }
+
+int sh_synchronize(sh_ctx *c)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
+}
+
+int sh_set_timing(sh_ctx *c, int on)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    for (auto &p : c->tev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    c->tev.clear(); c->timing = on;
+    return SH_OK;
+}
+
+int sh_get_timing(sh_ctx *c, double *total_ms, int64_t *launches)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    double tot = 0;
+    for (auto &p : c->tev) { HIPCHK(hipEventSynchronize(p.second)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, p.first, p.second)); tot += ms; }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)c->tev.size();
+    return SH_OK;
+}
+
+int sh_set_af_filter(sh_ctx *c, double min_af, double max_af)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    c->min_af = min_af; c->max_af = max_af; c->af_on = !(min_af <= 0.0 && max_af >= 1.0);
+    return SH_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// LMM setup: pyseer/lmm.py:26-122 hands over (U, S, y, covariates, h2); everything derived from them that the per-
+// variant kernels need is built here (rotate / getUY: lmm_cov.py:165-218; Sd, yKy: lmm_cov.py:665, 734).
+// -------------------------------------------------------------------------------------------------------------
+int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const double *y, const double *C, int D,
+                 double h2, int continuous, double pret, double lrtt, int n_limbs)
+{
+    if (!c || !U || !S || !y || !C) return fail(SH_EINVAL, "null argument");
+    if (k < 1 || D < 1) return fail(SH_ESHAPE, "k and D must be >= 1");
+    if (h2 < 0.0 || h2 >= 1.0 || std::isnan(h2)) return fail(SH_EH2, "h2 outside [0,1): reference returns no 'beta' (KeyError)");
+    if (n_limbs == 0) n_limbs = 5;
+    if (n_limbs < 3 || n_limbs > 7) return fail(SH_EINVAL, "n_limbs must be 3..7");
+    HIPCHK(hipSetDevice(c->device));
+    const int N = c->N, Np = c->Np;
+    const int kp = (k + 3) & ~3;
+    c->lmm_ready = false;
+
+    // 1. orthonormal basis of the covariate space (modified Gram-Schmidt, twice): P = I - Qb Qb^T = I - X pinv(X)
+    std::vector<double> Qb((size_t)N * D, 0.0);
+    int r = 0;
+    for (int d = 0; d < D; ++d) {
+        // intercept (last column of C) first, so that rank 1 == "intercept only"
+        const int src = (d == 0) ? D - 1 : d - 1;
+        std::vector<double> col(N);
+        double n0 = 0;
+        for (int i = 0; i < N; ++i) { col[i] = C[(size_t)i * D + src]; n0 += col[i] * col[i]; }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int e = 0; e < r; ++e) {
+                double dot = 0; for (int i = 0; i < N; ++i) dot += Qb[(size_t)i * D + e] * col[i];
+                for (int i = 0; i < N; ++i) col[i] -= dot * Qb[(size_t)i * D + e];
+            }
+        double n1 = 0; for (int i = 0; i < N; ++i) n1 += col[i] * col[i];
+        if (!(n1 > 1e-24 * n0) || n0 == 0) continue;        // numerically dependent column (pinv drops it as well)
+        const double inv = 1.0 / std::sqrt(n1);
+        for (int i = 0; i < N; ++i) Qb[(size_t)i * D + r] = col[i] * inv;
+        ++r;
+    }
+    if (r < 1) return fail(SH_EINVAL, "covariate matrix has rank 0");
+    bool intercept_only = (r == 1);
+    if (intercept_only) { const double q0 = Qb[0]; for (int i = 0; i < N; ++i) if (std::fabs(Qb[(size_t)i * D] - q0) > 1e-12 * std::fabs(q0)) intercept_only = false; }
+    int DP = 0;
+    if (!intercept_only) { DP = 4; while (DP < r) DP *= 2; if (DP > 32) return fail(SH_EINVAL, "more than 32 independent covariates are not supported"); }
+
+    // 2. residualised phenotype (getUY -> rotate(Y)), with rotate's zeroing rule
+    std::vector<double> yt(N);
+    {
+        std::vector<double> cy(r, 0.0);
+        for (int e = 0; e < r; ++e) { double s = 0; for (int i = 0; i < N; ++i) s += Qb[(size_t)i * D + e] * y[i]; cy[e] = s; }
+        double mean = 0;
+        for (int i = 0; i < N; ++i) { double s = y[i]; for (int e = 0; e < r; ++e) s -= Qb[(size_t)i * D + e] * cy[e]; yt[i] = s; mean += s; }
+        mean /= N; double q = 0; for (int i = 0; i < N; ++i) q += (yt[i] - mean) * (yt[i] - mean);
+        if (std::sqrt(q / N) <= 1e-10) std::fill(yt.begin(), yt.end(), 0.0);
+    }
+    // 3. U~ = P U  (a no-op for a fresh fit where U is already orthogonal to the covariates; required for --load-lmm with
+    //    different covariates, run_test.sh:47), Sd, uy, yKy, v, W
+    std::vector<double> Sd(k), uy(k, 0.0), sgn(kp, 0.0);
+    for (int rr = 0; rr < k; ++rr) Sd[rr] = h2 * S[rr] + (1.0 - h2);                    // lmm_cov.py:665
+    std::vector<double> W((size_t)Np * kp, 0.0);
+    {
+        std::vector<double> QtU((size_t)r * k, 0.0);
+        for (int i = 0; i < N; ++i) {
+            const double *u = U + (size_t)i * k;
+            for (int e = 0; e < r; ++e) { const double q = Qb[(size_t)i * D + e]; double *o = &QtU[(size_t)e * k]; for (int rr = 0; rr < k; ++rr) o[rr] += q * u[rr]; }
+        }
+        for (int i = 0; i < N; ++i) {
+            const double *u = U + (size_t)i * k; double *w = &W[(size_t)i * kp];
+            for (int rr = 0; rr < k; ++rr) w[rr] = u[rr];
+            for (int e = 0; e < r; ++e) { const double q = Qb[(size_t)i * D + e]; const double *o = &QtU[(size_t)e * k]; for (int rr = 0; rr < k; ++rr) w[rr] -= q * o[rr]; }
+            const double yi = yt[i];
+            if (yi != 0.0) for (int rr = 0; rr < k; ++rr) uy[rr] += w[rr] * yi;         // uy = U~^T y
+        }
+    }
+    double yKy = 0;
+    std::vector<double> uys(k);
+    for (int rr = 0; rr < k; ++rr) { yKy += uy[rr] * uy[rr] / Sd[rr]; uys[rr] = uy[rr] / Sd[rr]; sgn[rr] = Sd[rr] < 0 ? -1.0 : 1.0; }
+    std::vector<double> vv(N);
+    for (int i = 0; i < N; ++i) {
+        double *w = &W[(size_t)i * kp]; double s = 0;
+        for (int rr = 0; rr < k; ++rr) s += w[rr] * uys[rr];
+        vv[i] = s;                                                                       // v = U~ diag(1/Sd) uy
+        for (int rr = 0; rr < k; ++rr) w[rr] *= 1.0 / std::sqrt(std::fabs(Sd[rr]));
+    }
+    // 4. prefilter constants
+    std::vector<uint64_t> y1(c->NB64p, 0), y0(c->NB64p, 0);
+    int n1 = 0, n0 = 0; double ymean = 0;
+    for (int i = 0; i < N; ++i) { if (y[i] == 1.0) { y1[i >> 6] |= 1ull << (i & 63); ++n1; } else if (y[i] == 0.0) { y0[i >> 6] |= 1ull << (i & 63); ++n0; } ymean += y[i]; }
+    ymean /= N;
+    std::vector<double> yc(N); double ycs = 0, ycq = 0;
+    for (int i = 0; i < N; ++i) { yc[i] = y[i] - ymean; ycs += yc[i]; ycq += yc[i] * yc[i]; }
+    std::vector<double> Qbp;
+    if (DP) { Qbp.assign((size_t)N * DP, 0.0); for (int i = 0; i < N; ++i) for (int e = 0; e < r; ++e) Qbp[(size_t)i * DP + e] = Qb[(size_t)i * D + e]; }
+
+    // 5. device side: M = W sgn W^T (fp64 MFMA), diagonal, limbs
+    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_G);
+    c->d_vv = c->d_mdiag = c->d_yc = c->d_Qb = nullptr; c->d_y1 = c->d_y0 = nullptr; c->d_G = nullptr;
+    const int NT = c->NT, L = n_limbs;
+    const size_t gbytes = (size_t)L * 2 * NT * (NT + 1) * 16384;
+    double *d_W = nullptr, *d_sgn = nullptr, *d_M = nullptr; unsigned long long *d_amax = nullptr;
+    HIPCHK(dmalloc(&c->d_vv, N)); HIPCHK(dmalloc(&c->d_mdiag, N)); HIPCHK(dmalloc(&c->d_yc, N));
+    HIPCHK(dmalloc(&c->d_y1, c->NB64p)); HIPCHK(dmalloc(&c->d_y0, c->NB64p));
+    if (DP) HIPCHK(dmalloc(&c->d_Qb, (size_t)N * DP));
+    HIPCHK(hipMalloc((void **)&c->d_G, gbytes));
+    HIPCHK(dmalloc(&d_W, (size_t)Np * kp)); HIPCHK(dmalloc(&d_sgn, kp)); HIPCHK(dmalloc(&d_M, (size_t)Np * Np)); HIPCHK(dmalloc(&d_amax, 1));
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemcpyAsync(d_W, W.data(), sizeof(double) * (size_t)Np * kp, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sgn, sgn.data(), sizeof(double) * kp, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_vv, vv.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_yc, yc.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_y1, y1.data(), sizeof(uint64_t) * c->NB64p, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_y0, y0.data(), sizeof(uint64_t) * c->NB64p, hipMemcpyHostToDevice, st));
+    if (DP) HIPCHK(hipMemcpyAsync(c->d_Qb, Qbp.data(), sizeof(double) * (size_t)N * DP, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_M, 0, sizeof(double) * (size_t)Np * Np, st));
+    HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NT, L, d_M, c->d_mdiag, d_amax, c->d_G));
+    unsigned long long amax_bits = 0;
+    HIPCHK(hipMemcpyAsync(&amax_bits, d_amax, sizeof(amax_bits), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_W); hipFree(d_sgn); hipFree(d_M); hipFree(d_amax);
+    double amax; std::memcpy(&amax, &amax_bits, sizeof(double));
+    const double p256 = std::pow(256.0, L);
+    c->quant_scale = amax > 0 ? 0.49 * p256 / amax : 0.0;
+
+    c->k = k; c->D = D; c->L = L; c->DP = DP;
+    LmmFinParams &P = c->fin;
+    P.N = N; P.D = D; P.continuous = continuous; P.n1 = n1; P.n0 = n0; P.yc_sum = ycs; P.yc_sq = ycq;
+    P.yKy = yKy; P.inv_scale = amax > 0 ? 1.0 / c->quant_scale : 0.0; P.pret = pret; P.lrtt = lrtt;
+    c->lmm_ready = true;
+    return SH_OK;
+}
+
+int sh_lmm_info(sh_ctx *c, int *n_limbs, int64_t *macs, double *qscale)
+{
+    if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
+    if (n_limbs) *n_limbs = c->L;
+    // executed int8 MACs per variant in k_lmm_quadform_i8: sum_I L * 4(I+1) K-steps * (256 rows * 64)
+    if (macs) *macs = (int64_t)c->L * 2 * c->NT * (c->NT + 1) * 256 * 64;
+    if (qscale) *qscale = c->quant_scale;
+    return SH_OK;
+}
+
+int sh_lmm_batch_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags)
+{
+    if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
+    if (V <= 0) return SH_OK;
+    if (row_bytes * 8 < c->N) return fail(SH_ESHAPE, "row_bytes*8 < n_samples: shape mismatch between snps and Y");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t Vpad = (V + 255) / 256 * 256;
+    int rc = ensure_ws(c, Vpad); if (rc) return rc;
+    hipStream_t st = c->stream;
+    LmmLinOut lo{c->d_t11, c->d_t01, c->d_m, c->d_xky, c->d_dg, c->d_rss, c->d_s1, c->d_q1};
+    HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
+    HIPCHK(shk_lmm_linear(st, c->DP, c->d_T, Vpad, c->N, c->NB64, c->d_vv, c->d_mdiag, c->d_yc, c->d_Qb, c->d_y1, c->d_y0,
+                          c->fin.continuous, lo));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+    HIPCHK(shk_lmm_quadform(st, c->d_G, c->d_T, Vpad, c->NT, c->L, c->d_q));
+    if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->tev.emplace_back(e0, e1); }
+    LmmFinParams P = c->fin; P.min_af = c->min_af; P.max_af = c->max_af; P.af_on = c->af_on;
+    HIPCHK(shk_lmm_finalize(st, V, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags));
+    return SH_OK;
+}
+
+static int ensure_staging(sh_ctx *c, int64_t bits_bytes, int64_t out_doubles, int64_t V)
+{
+    if (bits_bytes > c->cap_bits) { hipFree(c->d_bits); c->d_bits = nullptr; HIPCHK(hipMalloc((void **)&c->d_bits, bits_bytes)); c->cap_bits = bits_bytes; }
+    if (out_doubles > c->cap_out) {
+        hipFree(c->d_out); hipFree(c->d_flags); c->d_out = nullptr; c->d_flags = nullptr;
+        HIPCHK(dmalloc(&c->d_out, out_doubles)); HIPCHK(dmalloc(&c->d_flags, V)); c->cap_out = out_doubles;
+    }
+    return SH_OK;
+}
+
+int sh_lmm_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, double *prep, double *pvalue,
+                 double *beta, double *bse, double *frac_h2, uint32_t *flags)
+{
+    if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
+    if (!bits || !prep || !pvalue || !beta || !bse || !frac_h2 || !flags) return fail(SH_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t CH = 1 << 20;
+    double *outs[5] = {prep, pvalue, beta, bse, frac_h2};
+    for (int64_t s = 0; s < V; s += CH) {
+        const int64_t n = std::min(CH, V - s);
+        int rc = ensure_staging(c, n * row_bytes, std::min(CH, V) * 5, std::min(CH, V)); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_bits, bits + s * row_bytes, n * row_bytes, hipMemcpyHostToDevice, c->stream));
+        rc = sh_lmm_batch_dev(c, c->d_bits, row_bytes, n, c->d_out, c->d_flags); if (rc) return rc;
+        for (int a = 0; a < 5; ++a)
+            HIPCHK(hipMemcpyAsync(outs[a] + s, c->d_out + (size_t)a * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(flags + s, c->d_flags, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SH_OK;
+}
+
+#include "glm_api_impl.inc"
+
+}  // extern "C"

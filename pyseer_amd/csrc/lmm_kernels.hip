@@ -1,0 +1,466 @@
+// lmm_kernels.hip -- FaST-LMM per-variant test on MI355X (gfx950).
+//
+// Reference path restated here (see DESIGN.md §LMM for the algebra):
+//   pyseer/lmm.py:228-260            fit_lmm_block
+//   pyseer/fastlmm/lmm_cov.py:165-194 rotate  (+ Linreg.regress :874-880)
+//   pyseer/fastlmm/lmm_cov.py:597-838 nLLeval / nLLcore, computeAKA/AKB :885-916
+//
+// For a 0/1 variant x the reference needs  xKx = sum_r (U~^T x)_r^2 / Sd_r  and  xKy = sum_r (U~^T x)_r (U~^T y)_r / Sd_r
+// with U~ = P U (P = covariate residual maker).  With M = U~ diag(1/Sd) U~^T (N x N, per-run constant):
+//     xKy = x . v          v = U~ diag(1/Sd) U~^T y                      -> O(N) masked sum   (k_lmm_linear)
+//     xKx = sum_i x_i M_ii + x^T G x,   G = 2*strict_lower(M)             -> the dense contraction (k_lmm_quadform_i8)
+// x is exactly representable in int8, and G is held as L balanced base-256 int8 limbs of a fixed-point number, so the
+// contraction runs on v_mfma_i32_32x32x32_i8 with EXACT int32 accumulation; limbs are recombined in fp64.
+#include "common.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// bits (variant-major rows) -> T[sb][v] : one uint64 per (64-sample block, variant); coalesced for every consumer.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_repack_bits(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V,
+                                                     int64_t Vpad, int N, uint64_t *__restrict__ T)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int sb = blockIdx.y;
+    uint64_t w = 0;
+    if (v < V) {
+        const int64_t off = (int64_t)sb * 8;
+        const uint8_t *p = bits + v * row_bytes + off;
+        int64_t nbytes = row_bytes - off; if (nbytes > 8) nbytes = 8;
+        if (nbytes == 8 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) {
+            w = *reinterpret_cast<const uint64_t *>(p);
+        } else {
+            for (int b = 0; b < nbytes; b++) w |= (uint64_t)p[b] << (8 * b);
+        }
+        const int valid = N - sb * 64;
+        if (valid <= 0) w = 0; else if (valid < 64) w &= ((1ull << valid) - 1ull);
+    }
+    T[(int64_t)sb * Vpad + v] = w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// O(N) per-variant terms: table counts (a1), x.v, x.diag(M), Welch sums, covariate-residual variance (rotate's
+// "explained by the covariates" test, lmm_cov.py:179-181).  One variant per lane; sample loop is wave-uniform so the
+// per-sample constants arrive through the scalar cache.
+//   Qb: N x DP row-major orthonormal basis of the covariate space (only when D > 1; DP = D padded), else DP = 0.
+// ---------------------------------------------------------------------------------------------
+struct LmmLinOut {
+    int *t11, *t01, *m;          // Vpad each
+    double *xky, *dg, *rss, *s1, *q1;
+};
+
+template <int DP>
+__global__ __launch_bounds__(256) void k_lmm_linear(const uint64_t *__restrict__ T, int64_t Vpad, int N, int NB64,
+                                                    const double *__restrict__ vv, const double *__restrict__ mdiag,
+                                                    const double *__restrict__ yc, const double *__restrict__ Qb,
+                                                    const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                    int continuous, LmmLinOut o)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double xky = 0, dg = 0, s1 = 0, q1 = 0;
+    double c[DP > 0 ? DP : 1];
+#pragma unroll
+    for (int d = 0; d < DP; d++) c[d] = 0;
+    int t11 = 0, t01 = 0, m = 0;
+    for (int sb = 0; sb < NB64; sb++) {
+        const uint64_t w = T[(int64_t)sb * Vpad + v];
+        m += __popcll(w); t11 += __popcll(w & y1[sb]); t01 += __popcll(w & y0[sb]);
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; b++) {
+            const int i = sb * 64 + b;
+            const double xd = (double)(unsigned)((w >> b) & 1ull);
+            xky = fma(xd, vv[i], xky);
+            dg = fma(xd, mdiag[i], dg);
+            if (continuous) { const double t = yc[i]; s1 = fma(xd, t, s1); q1 = fma(xd, t * t, q1); }
+#pragma unroll
+            for (int d = 0; d < DP; d++) c[d] = fma(xd, Qb[(int64_t)i * DP + d], c[d]);
+        }
+    }
+    double rss;
+    if (DP > 0) {
+        rss = 0;
+        for (int sb = 0; sb < NB64; sb++) {
+            const uint64_t w = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; b++) {
+                const int i = sb * 64 + b;
+                double r = (double)(unsigned)((w >> b) & 1ull);
+#pragma unroll
+                for (int d = 0; d < DP; d++) r = fma(-Qb[(int64_t)i * DP + d], c[d], r);
+                rss = fma(r, r, rss);
+            }
+        }
+    } else {
+        rss = (double)m * (double)(N - m) / (double)N;           // ||x - mean(x)||^2, exact
+    }
+    o.t11[v] = t11; o.t01[v] = t01; o.m[v] = m;
+    o.xky[v] = xky; o.dg[v] = dg; o.rss[v] = rss; o.s1[v] = s1; o.q1[v] = q1;
+}
+
+template __global__ void k_lmm_linear<0>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+template __global__ void k_lmm_linear<4>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+template __global__ void k_lmm_linear<8>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+template __global__ void k_lmm_linear<16>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+template __global__ void k_lmm_linear<32>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+
+// ---------------------------------------------------------------------------------------------
+// THE hot kernel:  q[v] = sum_{i>j} x_i x_j Gq_ij   (exact integers; Gq = fixed-point 2*M_ij in L int8 limbs)
+//
+// Block = one tile of 256 variants, 512 threads = 8 waves as 2 (sample rows) x 4 (variants); each wave owns a
+// 128 x 64 int32 accumulator (4 x 2 MFMA 32x32 tiles = 128 VGPRs).  For every (row tile I, limb l) the block runs the
+// K loop over sample columns j < (I+1)*256 (G is strictly lower triangular, upper tiles are skipped), then folds the
+// accumulator against the variants' own bits for rows of tile I (x_i * (G x)_i) into an fp64 running sum.
+//
+// LDS image of a 256 x 64 int8 tile (rows = samples i or variants, 64 B of K per row): byte (r, c) lives at
+//   r*64 + 16*((c>>4) ^ ((r>>2)&3)) + (c&15)
+// so the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots (no bank conflicts).  G is stored in HBM already in
+// this image order (k_lmm_quantize), the variant tile is expanded bits->bytes on the fly.
+// ---------------------------------------------------------------------------------------------
+#define QF_TILE_BYTES 16384
+
+__device__ __forceinline__ int qf_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ uint4 qf_expand16(uint32_t bits16)
+{
+    uint4 r;
+    r.x = (((bits16) & 0xFu) * 0x00204081u) & 0x01010101u;
+    r.y = (((bits16 >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+    r.z = (((bits16 >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+    r.w = (((bits16 >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
+    return r;
+}
+
+__global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
+                                                            int64_t Vpad, int NT, int L, double *__restrict__ qout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const sA0 = smem, *const sB0 = smem + 2 * QF_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t v0 = (int64_t)blockIdx.x * 256;
+    const int bv = tid >> 1, bh = tid & 1;                       // B staging role: variant, 32-sample half
+    const int64_t TL = 2ll * NT * (NT + 1);                      // tiles per limb
+    double tot[2] = {0.0, 0.0};
+
+    for (int I = 0; I < NT; ++I) {
+        const int nks = 4 * (I + 1);
+        // the variants' own bits for the rows this wave accumulates (epilogue mask): x_i, i in tile I
+        uint32_t xw[4][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int64_t vcol = v0 + wc * 64 + jt * 32 + l31;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int srow = I * 256 + wr * 128 + it * 32;
+                const uint64_t w = T[(int64_t)(srow >> 6) * Vpad + vcol];
+                xw[it][jt] = (uint32_t)(w >> (srow & 63));
+            }
+        }
+        double scale_l = 1.0;
+        for (int l = 0; l < L; ++l) {
+            const int8_t *Gt = G + ((int64_t)l * TL + 2ll * I * (I + 1)) * QF_TILE_BYTES;
+            v16i acc[4][2];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0;
+
+            uint4 ra0, ra1; uint32_t rb;
+            // ---- prologue: stage K-step 0 into buffer 0
+            ra0 = *reinterpret_cast<const uint4 *>(Gt + tid * 16);
+            ra1 = *reinterpret_cast<const uint4 *>(Gt + 8192 + tid * 16);
+            rb = (uint32_t)(T[v0 + bv] >> (32 * bh));
+            *reinterpret_cast<uint4 *>(sA0 + tid * 16) = ra0;
+            *reinterpret_cast<uint4 *>(sA0 + 8192 + tid * 16) = ra1;
+            *reinterpret_cast<uint4 *>(sB0 + qf_off(bv, 2 * bh)) = qf_expand16(rb & 0xFFFFu);
+            *reinterpret_cast<uint4 *>(sB0 + qf_off(bv, 2 * bh + 1)) = qf_expand16(rb >> 16);
+            __syncthreads();
+
+            for (int ks = 0; ks < nks; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                const bool more = (ks + 1 < nks);
+                if (more) {
+                    const int8_t *g = Gt + (int64_t)(ks + 1) * QF_TILE_BYTES;
+                    ra0 = *reinterpret_cast<const uint4 *>(g + tid * 16);
+                    ra1 = *reinterpret_cast<const uint4 *>(g + 8192 + tid * 16);
+                    rb = (uint32_t)(T[(int64_t)(ks + 1) * Vpad + v0 + bv] >> (32 * bh));
+                }
+                const char *a_base = sA0 + cur * QF_TILE_BYTES;
+                const char *b_base = sB0 + cur * QF_TILE_BYTES;
+#pragma unroll
+                for (int ksub = 0; ksub < 2; ++ksub) {
+                    v4i a[4], b[2];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        a[it] = *reinterpret_cast<const v4i *>(a_base + qf_off(wr * 128 + it * 32 + l31, ksub * 2 + lh));
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt)
+                        b[jt] = *reinterpret_cast<const v4i *>(b_base + qf_off(wc * 64 + jt * 32 + l31, ksub * 2 + lh));
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt)
+                            acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[it], b[jt], acc[it][jt], 0, 0, 0);
+                }
+                if (more) {
+                    char *an = sA0 + nxt * QF_TILE_BYTES, *bn = sB0 + nxt * QF_TILE_BYTES;
+                    *reinterpret_cast<uint4 *>(an + tid * 16) = ra0;
+                    *reinterpret_cast<uint4 *>(an + 8192 + tid * 16) = ra1;
+                    *reinterpret_cast<uint4 *>(bn + qf_off(bv, 2 * bh)) = qf_expand16(rb & 0xFFFFu);
+                    *reinterpret_cast<uint4 *>(bn + qf_off(bv, 2 * bh + 1)) = qf_expand16(rb >> 16);
+                }
+                __syncthreads();
+            }
+            // ---- epilogue: s = sum_i x_i * acc_i for this wave's 128 rows, per variant column
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                int s = 0;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const uint32_t w = xw[it][jt];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;       // C/D layout of the 32x32 MFMA
+                        const int msk = -(int)((w >> row) & 1u);
+                        s += acc[it][jt][r] & msk;
+                    }
+                }
+                tot[jt] = fma((double)s, scale_l, tot[jt]);
+            }
+            scale_l *= 256.0;
+        }
+    }
+    // lanes l and l^32 hold different rows of the same variant; waves wr=0/1 hold different rows too
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) tot[jt] += __shfl_xor(tot[jt], 32, 64);
+    double *red = reinterpret_cast<double *>(smem);
+    __syncthreads();
+    if (wr == 1 && lh == 0) { red[wc * 64 + l31] = tot[0]; red[wc * 64 + 32 + l31] = tot[1]; }
+    __syncthreads();
+    if (wr == 0 && lh == 0) {
+        qout[v0 + wc * 64 + l31] = tot[0] + red[wc * 64 + l31];
+        qout[v0 + wc * 64 + 32 + l31] = tot[1] + red[wc * 64 + 32 + l31];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-variant finalisation: a1 prefilter + A5 statistics + a7 filters (pyseer/lmm.py:160-217, 244-258).
+// ---------------------------------------------------------------------------------------------
+struct LmmFinParams {
+    int N, D, continuous;
+    int n1, n0;                 // #(y == 1), #(y == 0)   (binary prefilter margins)
+    double yc_sum, yc_sq;       // sum / sum of squares of the centred phenotype (Welch, group 0 by subtraction)
+    double yKy, inv_scale;
+    double pret, lrtt;
+    double min_af, max_af; int af_on;
+};
+
+__global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, LmmLinOut li, const double *__restrict__ q,
+                                                      LmmFinParams P, double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const double nanv = NAN;
+    double prep = nanv, pval = nanv, beta = nanv, bse = nanv, frac = nanv;
+    uint32_t fl = 0;
+    const int m = li.m[v];
+    bool go = true;
+    if (P.af_on) {
+        const double af = (double)m / (double)P.N;
+        if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; go = false; }
+    }
+    if (go) {
+        bool bad = false;
+        if (P.continuous) {
+            const double n1 = (double)m, n0 = (double)(P.N - m);
+            prep = sh_prefilter_welch(n1, li.s1[v], li.q1[v], n0, P.yc_sum - li.s1[v], P.yc_sq - li.q1[v]);
+        } else {
+            const int t11 = li.t11[v], t01 = li.t01[v];
+            prep = sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, &bad);
+        }
+        if (bad) fl |= SH_NOTE_BAD_CHISQ;
+        if (prep >= P.pret || !isfinite(prep)) fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER;      // lmm.py:174 (>=)
+        // statistics (computed for every AF-passing variant; masking by flags is the caller's, lmm.py:176-217)
+        const bool zeroed = sqrt(li.rss[v] / (double)P.N) <= 1e-10;                              // lmm_cov.py:179-181
+        const double xKx = zeroed ? 0.0 : (li.dg[v] + q[v] * P.inv_scale);
+        const double xKy = zeroed ? 0.0 : li.xky[v];
+        double b = xKy / xKx;
+        if (isnan(b) && xKy == 0.0) b = 0.0;                                                      // lmm_cov.py:802-805
+        const double veb = xKy * b, r2 = P.yKy - veb;
+        const double var = r2 / ((double)(P.N - P.D) - 1.0) / xKx;                                // lmm_cov.py:813
+        const double chi2 = b * b / var;                                                          // lmm.py:248
+        pval = sh_f_sf_1(chi2, (double)(P.N - (P.D + 1)));                                        // lmm.py:251-253
+        beta = b; bse = sqrt(var); frac = sqrt(veb / P.yKy);
+        if (!(fl & SH_FLAG_PREFILTER)) {
+            if (pval >= P.lrtt || !isfinite(pval)) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;      // lmm.py:201 (>=)
+        }
+    }
+    out[v] = prep; out[V + v] = pval; out[2 * V + v] = beta; out[3 * V + v] = bse; out[4 * V + v] = frac;
+    flags[v] = fl;
+}
+
+// =============================================================================================
+// Setup kernels (once per run)
+// =============================================================================================
+
+// M = W diag(sgn) W^T on fp64 MFMA (v_mfma_f64_16x16x4_f64), lower 128x128 tiles only.  W: Np x kp row-major
+// (rows >= N and columns >= k are zero).  Block = 4 waves, each a 64x64 sub-tile (16 MFMA tiles, 64 f64 acc / lane).
+__global__ __launch_bounds__(256) void k_syrk_f64(const double *__restrict__ W, const double *__restrict__ sgn,
+                                                  int Np, int kp, double *__restrict__ M)
+{
+    // blockIdx.x enumerates (bi >= bj)
+    int t = blockIdx.x, bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = bi * 128 + (wave >> 1) * 64, j0 = bj * 128 + (wave & 1) * 64;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
+    const double *Ai = W + (int64_t)(i0 + lr) * kp + lk;
+    const double *Bj = W + (int64_t)(j0 + lr) * kp + lk;
+    for (int kk = 0; kk < kp; kk += 4) {
+        const double sg = sgn[kk + lk];
+        double a[4], b[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { a[x] = Ai[(int64_t)x * 16 * kp + kk] * sg; b[x] = Bj[(int64_t)x * 16 * kp + kk]; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    // C/D layout of the f64 16x16 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                M[(int64_t)(i0 + x * 16 + lk + 4 * r) * Np + (j0 + y * 16 + lr)] = acc[x][y][r];
+}
+
+// max |2 M_ij| over i > j (i, j < N)  ->  *amax (bit pattern of a non-negative double orders like uint64)
+__global__ __launch_bounds__(256) void k_lower_absmax(const double *__restrict__ M, int N, int Np,
+                                                      unsigned long long *__restrict__ amax)
+{
+    const int i = blockIdx.x;
+    double mx = 0;
+    for (int j = threadIdx.x; j < i; j += 256) mx = fmax(mx, fabs(2.0 * M[(int64_t)i * Np + j]));
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(amax, (unsigned long long)__double_as_longlong(mx));
+}
+
+__global__ void k_extract_diag(const double *__restrict__ M, int N, int Np, double *__restrict__ mdiag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) mdiag[i] = M[(int64_t)i * Np + i];
+}
+
+// fixed-point limbs in LDS-image order.  grid = (tile index within a limb), block = 256 threads (one tile row each).
+__global__ __launch_bounds__(256) void k_lmm_quantize(const double *__restrict__ M, int N, int Np, int NT, int L,
+                                                      const unsigned long long *__restrict__ amax_bits,
+                                                      int8_t *__restrict__ G)
+{
+    // decode (I, ks) from the linear tile id: tiles of row tile I start at 2*I*(I+1)
+    int t = blockIdx.x, I = 0;
+    while (2 * (I + 1) * (I + 2) <= t) ++I;
+    const int ks = t - 2 * I * (I + 1);
+    const int r = threadIdx.x;
+    const int i = I * 256 + r;
+    const double amax = __longlong_as_double((long long)*amax_bits);
+    double p256 = 1.0;
+    for (int l = 0; l < L; ++l) p256 *= 256.0;
+    const double scale = amax > 0 ? 0.49 * p256 / amax : 0.0;
+    const int64_t TL = 2ll * NT * (NT + 1);
+    for (int ch = 0; ch < 4; ++ch) {
+        long long qv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int j = ks * 64 + ch * 16 + c;
+            double g = 0.0;
+            if (i < N && j < i) g = 2.0 * M[(int64_t)i * Np + j];
+            qv[c] = llrint(g * scale);
+        }
+        for (int l = 0; l < L; ++l) {
+            uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                long long d = ((qv[c] + 128) & 255) - 128;          // balanced digit in [-128, 127]
+                qv[c] = (qv[c] - d) >> 8;
+                pk[c >> 2] |= ((uint32_t)(d & 255)) << (8 * (c & 3));
+            }
+            uint4 o; o.x = pk[0]; o.y = pk[1]; o.z = pk[2]; o.w = pk[3];
+            *reinterpret_cast<uint4 *>(G + ((int64_t)l * TL + t) * QF_TILE_BYTES + qf_off(r, ch)) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-callable launch wrappers (called from api.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+hipError_t shk_repack_bits(hipStream_t st, const uint8_t *bits, int64_t row_bytes, int64_t V, int64_t Vpad, int N,
+                           int NB64, uint64_t *T)
+{
+    dim3 grid((unsigned)(Vpad / 256), (unsigned)NB64);
+    hipLaunchKernelGGL(k_repack_bits, grid, dim3(256), 0, st, bits, row_bytes, V, Vpad, N, T);
+    return hipGetLastError();
+}
+
+hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpad, int N, int NB64, const double *vv,
+                          const double *mdiag, const double *yc, const double *Qb, const uint64_t *y1,
+                          const uint64_t *y0, int continuous, LmmLinOut o)
+{
+    dim3 grid((unsigned)(Vpad / 256)), blk(256);
+    switch (DP) {
+    case 0: hipLaunchKernelGGL(k_lmm_linear<0>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
+    case 4: hipLaunchKernelGGL(k_lmm_linear<4>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
+    case 8: hipLaunchKernelGGL(k_lmm_linear<8>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
+    case 16: hipLaunchKernelGGL(k_lmm_linear<16>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
+    case 32: hipLaunchKernelGGL(k_lmm_linear<32>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t shk_lmm_quadform(hipStream_t st, const int8_t *G, const uint64_t *T, int64_t Vpad, int NT, int L, double *q)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * QF_TILE_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_lmm_quadform_i8, dim3((unsigned)(Vpad / 256)), dim3(512), 4 * QF_TILE_BYTES, st, G, T, Vpad, NT, L, q);
+    return hipGetLastError();
+}
+
+hipError_t shk_lmm_finalize(hipStream_t st, int64_t V, LmmLinOut li, const double *q, LmmFinParams P, double *out,
+                            uint32_t *flags)
+{
+    hipLaunchKernelGGL(k_lmm_finalize, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, li, q, P, out, flags);
+    return hipGetLastError();
+}
+
+hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, int N, int Np, int kp, int NT, int L,
+                           double *M, double *mdiag, unsigned long long *amax, int8_t *G)
+{
+    const int nb = Np / 128;
+    hipMemsetAsync(amax, 0, sizeof(unsigned long long), st);
+    hipLaunchKernelGGL(k_syrk_f64, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, st, W, sgn, Np, kp, M);
+    hipLaunchKernelGGL(k_lower_absmax, dim3((unsigned)N), dim3(256), 0, st, M, N, Np, amax);
+    hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, M, N, Np, mdiag);
+    hipLaunchKernelGGL(k_lmm_quantize, dim3((unsigned)(2 * NT * (NT + 1))), dim3(256), 0, st, M, N, Np, NT, L, amax, G);
+    return hipGetLastError();
+}
+
+}  // extern "C"

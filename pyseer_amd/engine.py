@@ -1,0 +1,146 @@
+"""Thin object layer over the C ABI: one Engine per (device, n_samples).
+
+Host arrays go through sh_*_batch (copy in / copy out); torch tensors that already live in HBM go
+through sh_*_batch_dev on torch's current stream (torch is used only for device memory and streams).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .packing import pack_variants, row_bytes_for
+
+
+def _dp(a):
+    return a.ctypes.data_as(_abi.c_dp)
+
+
+class Engine(object):
+    def __init__(self, n_samples, device=0):
+        self._lib = _abi.load()
+        if self._lib.sh_device_count() <= 0:
+            raise _abi.SeerHipError(_abi.SH_ENODEV, "no HIP device visible; libseerhip has no CPU fallback")
+        h = self._lib.sh_create(int(device), int(n_samples))
+        if not h:
+            raise _abi.SeerHipError(_abi.SH_ENODEV, self._lib.sh_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n = int(n_samples)
+        self.device = int(device)
+        self.q = None
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- common ------------------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        _abi.check(self._lib.sh_set_stream(self._h, C.c_void_p(int(stream_handle or 0))))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        _abi.check(self._lib.sh_synchronize(self._h))
+
+    def set_timing(self, on=True):
+        _abi.check(self._lib.sh_set_timing(self._h, int(bool(on))))
+
+    def get_timing(self):
+        """(total ms of the dominant kernel, number of launches) since set_timing(True)."""
+        ms = C.c_double(); n = C.c_int64()
+        _abi.check(self._lib.sh_get_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def set_af_filter(self, min_af, max_af):
+        _abi.check(self._lib.sh_set_af_filter(self._h, float(min_af), float(max_af)))
+
+    def _bits(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        if bits.ndim != 2 or bits.shape[1] * 8 < self.n:
+            raise AssertionError("shape missmatch between snps and Y")       # lmm_cov.py:674
+        return bits
+
+    # ---- LMM ---------------------------------------------------------------------------------
+    def lmm_setup(self, U, S, y, covar, h2, continuous=False, filter_pvalue=1.0, lrt_pvalue=1.0, n_limbs=0):
+        """U (n,k), S (k,), y (n,), covar (n,D) with the intercept LAST (pyseer/lmm.py:95-99)."""
+        U = np.ascontiguousarray(U, dtype=np.float64); S = np.ascontiguousarray(S, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        covar = np.ascontiguousarray(np.asarray(covar, dtype=np.float64).reshape(y.shape[0], -1))
+        if U.shape[0] != self.n or y.shape[0] != self.n or S.shape[0] != U.shape[1]:
+            raise AssertionError("shape missmatch")
+        rc = self._lib.sh_lmm_setup(self._h, _dp(U), _dp(S), U.shape[1], _dp(y), _dp(covar), covar.shape[1], float(h2),
+                                    int(bool(continuous)), float(filter_pvalue), float(lrt_pvalue), int(n_limbs))
+        if rc == _abi.SH_EH2:
+            raise KeyError("beta")                                           # lmm_test.py:416-417
+        _abi.check(rc)
+
+    def lmm_info(self):
+        nl = C.c_int(); macs = C.c_int64(); qs = C.c_double()
+        _abi.check(self._lib.sh_lmm_info(self._h, C.byref(nl), C.byref(macs), C.byref(qs)))
+        return dict(n_limbs=nl.value, int8_macs_per_variant=macs.value, quant_scale=qs.value)
+
+    def lmm_batch(self, bits):
+        """bits: (V, row_bytes) uint8 host array -> dict of host arrays (raw statistics + flags)."""
+        bits = self._bits(bits)
+        V = bits.shape[0]
+        o = np.full((5, V), np.nan); fl = np.zeros(V, dtype=np.uint32)
+        if V:
+            _abi.check(self._lib.sh_lmm_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
+                                              _dp(o[2]), _dp(o[3]), _dp(o[4]), fl.ctypes.data_as(_abi.c_u32p)))
+        return dict(prep=o[0], pvalue=o[1], beta=o[2], bse=o[3], frac_h2=o[4], flags=fl)
+
+    def lmm_batch_dev(self, bits_t, out_t=None, flags_t=None):
+        """bits_t: torch uint8 CUDA tensor (V, row_bytes); returns (out (5,V) float64, flags (V,) int32) CUDA tensors."""
+        import torch
+        V, rb = bits_t.shape
+        if out_t is None:
+            out_t = torch.empty((5, V), dtype=torch.float64, device=bits_t.device)
+        if flags_t is None:
+            flags_t = torch.empty((V,), dtype=torch.int32, device=bits_t.device)
+        _abi.check(self._lib.sh_lmm_batch_dev(self._h, C.c_void_p(bits_t.data_ptr()), rb, V, C.c_void_p(out_t.data_ptr()),
+                                              C.c_void_p(flags_t.data_ptr())))
+        return out_t, flags_t
+
+    # ---- fixed effects -----------------------------------------------------------------------
+    def glm_setup(self, y, W, continuous, null_llf, null_firth, pret=1.0, lrtt=1.0, force_firth=False):
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        if W is None or np.size(W) == 0:
+            W = np.zeros((self.n, 0))
+        W = np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(self.n, -1))
+        self.q = W.shape[1]
+        nf = float("nan") if null_firth is None else float(null_firth)
+        Wp = W if self.q else np.zeros(1)
+        _abi.check(self._lib.sh_glm_setup(self._h, _dp(y), _dp(Wp), self.q, int(bool(continuous)), float(null_llf), nf,
+                                          float(pret), float(lrtt), int(bool(force_firth))))
+
+    def glm_batch(self, bits):
+        bits = self._bits(bits)
+        V = bits.shape[0]; q = self.q
+        o = np.full((5, V), np.nan); betas = np.full((V, max(q, 1)), np.nan); fl = np.zeros(V, dtype=np.uint32)
+        if V:
+            _abi.check(self._lib.sh_glm_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
+                                              _dp(o[2]), _dp(o[3]), _dp(o[4]), _dp(betas), fl.ctypes.data_as(_abi.c_u32p)))
+        return dict(prep=o[0], pvalue=o[1], kbeta=o[2], bse=o[3], intercept=o[4], betas=betas[:, :q], flags=fl)
+
+    def glm_batch_dev(self, bits_t, out_t=None, flags_t=None):
+        import torch
+        V, rb = bits_t.shape
+        if out_t is None:
+            out_t = torch.empty((5 + self.q, V), dtype=torch.float64, device=bits_t.device)
+        if flags_t is None:
+            flags_t = torch.empty((V,), dtype=torch.int32, device=bits_t.device)
+        _abi.check(self._lib.sh_glm_batch_dev(self._h, C.c_void_p(bits_t.data_ptr()), rb, V, C.c_void_p(out_t.data_ptr()),
+                                              C.c_void_p(flags_t.data_ptr())))
+        return out_t, flags_t
+
+
+__all__ = ["Engine", "pack_variants", "row_bytes_for"]

@@ -1,0 +1,179 @@
+"""GPU parity of the LMM path (HIP kernels through the C ABI) against the reference's golden vectors and the CPU oracle.
+Tolerance: 1e-6 relative on beta / bse / frac_h2 / p-values (BASELINE.json north_star); flags bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=0.0, what=""):
+    a = np.atleast_1d(np.asarray(a, dtype=float)); b = np.atleast_1d(np.asarray(b, dtype=float))
+    assert a.shape == b.shape
+    with np.errstate(invalid="ignore"):
+        ok = (np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))) | \
+             (np.abs(a - b) <= atol + rtol * np.abs(b))
+    assert ok.all(), "%s mismatch at %s: got %s want %s" % (what, np.where(~ok)[0][:5], a[~ok][:5], b[~ok][:5])
+
+
+@pytest.fixture(scope="module")
+def engine_mod():
+    from pyseer_amd.engine import Engine, pack_variants
+    return Engine, pack_variants
+
+
+def _perfect_fit(Kv, y):
+    return (Kv == y).all(axis=1) | (Kv == 1 - y).all(axis=1)
+
+
+def test_lmm_reference_unit_pins(engine_mod):
+    Engine, pack = engine_mod
+    d = np.load(os.path.join(G, "lmm_unit.npz"))
+    for tag in ("nocov", "cov"):
+        e = Engine(50)
+        e.lmm_setup(d[tag + "_U"], d[tag + "_S"], d[tag + "_y"], d[tag + "_covar"], float(d[tag + "_h2"]))
+        for kk, bb in ((tag + "_k", tag + "_blk"), (tag + "_badk", tag + "_blk_bad")):
+            r = e.lmm_batch(pack(d[kk].reshape(1, -1)))
+            close([r["beta"][0], r["bse"][0], r["frac_h2"][0], r["pvalue"][0]], d[bb][0], what=tag + kk)
+        r = e.lmm_batch(pack(d[tag + "_k"].reshape(1, -1)))
+        close(r["prep"], [d[tag + "_prep_binary"]])
+        with pytest.raises(KeyError):
+            e.lmm_setup(d[tag + "_U"], d[tag + "_S"], d[tag + "_y"], d[tag + "_covar"], 1.0)
+        with pytest.raises(AssertionError):
+            e.lmm_batch(np.zeros((1, 1), dtype=np.uint8))
+        e.close()
+    # the literals of the reference's tests/lmm_test.py:407-414, through the HIP path
+    e = Engine(50)
+    e.lmm_setup(d["nocov_U"], d["nocov_S"], d["nocov_y"], d["nocov_covar"], float(d["nocov_h2"]))
+    r = e.lmm_batch(pack(d["nocov_k"].reshape(1, -1)))
+    assert abs(r["beta"][0] - 0.15136876) < 1e-7 and abs(r["bse"][0] - 0.14208536) < 1e-7
+    assert abs(r["frac_h2"][0] - 0.15198184) < 1e-7 and abs(r["pvalue"][0] - 0.29205322) < 1e-7
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "lmm_N*.npz"))))
+@pytest.mark.parametrize("limbs", [5, 6])
+def test_lmm_golden_blocks(engine_mod, path, limbs):
+    Engine, pack = engine_mod
+    d = np.load(path)
+    Kv = d["Kv"]; N = int(d["N"]); y = d["y"]
+    bits = pack(Kv)
+    noise = _perfect_fit(Kv.astype(float), y) if not int(d["continuous"]) else np.zeros(Kv.shape[0], bool)
+    e = Engine(N)
+    for key in d["h2_keys"]:
+        h2 = float(str(key).split("_")[1])
+        if abs(h2 - float(d["h2"])) < 1e-6:
+            h2 = float(d["h2"])
+        e.lmm_setup(d["U"], d["S"], y, d["covar"], h2, continuous=bool(d["continuous"]), n_limbs=limbs)
+        r = e.lmm_batch(bits)
+        want = d["blk_" + str(key)]
+        close(r["beta"], want[:, 0], atol=1e-12, what="beta")
+        close(r["frac_h2"], want[:, 2], atol=1e-9, what="frac_h2")
+        ok = ~noise & ~np.isnan(want[:, 1])
+        close(r["bse"][ok], want[ok, 1], what="bse"); close(r["pvalue"][ok], want[ok, 3], atol=1e-300, what="p")
+    if "mis_U" in d.files:          # --load-lmm cache built with other covariates (run_test.sh:47)
+        e.lmm_setup(d["mis_U"], d["mis_S"], y, d["covar"], float(d["mis_h2"]), n_limbs=limbs)
+        r = e.lmm_batch(bits)
+        want = d["mis_blk"]; ok = ~noise & ~np.isnan(want[:, 1])
+        close(r["beta"], want[:, 0], atol=1e-12); close(r["frac_h2"], want[:, 2], atol=1e-9)
+        close(r["bse"][ok], want[ok, 1]); close(r["pvalue"][ok], want[ok, 3], atol=1e-300)
+    e.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "lmm_N*.npz"))))
+def test_lmm_golden_orchestration(engine_mod, path):
+    """fit_lmm (lmm.py:125-226): AF filter, prefilter (>=), LRT filter (>=), notes, prefilter/filter booleans."""
+    Engine, pack = engine_mod
+    from pyseer_amd.lmm import mask_like_fit_lmm
+    d = np.load(path)
+    Kv = d["Kv"]; N = int(d["N"]); y = d["y"]
+    noise = _perfect_fit(Kv.astype(float), y) if not int(d["continuous"]) else np.zeros(Kv.shape[0], bool)
+    e = Engine(N)
+    e.set_af_filter(0.01, 0.99)
+    for o, (fp, lp) in (("o1", (1.0, 1.0)), ("o2", (0.05, 0.01))):
+        e.lmm_setup(d["U"], d["S"], y, d["covar"], float(d["h2"]), continuous=bool(d["continuous"]), filter_pvalue=fp,
+                    lrt_pvalue=lp)
+        r = mask_like_fit_lmm(e.lmm_batch(pack(Kv)))
+        order = np.array([int(s[1:]) for s in d[o + "_order"]])
+        rows = d[o + "_rows"]; nz = ~noise[order]
+        got = np.stack([r["prep"], r["pvalue"], r["beta"], r["bse"], r["frac_h2"]], axis=1)[order]
+        close(got[nz], rows[nz], atol=1e-300, what=o)
+        fl = r["flags"][order]
+        assert ((fl & 0x1FF)[nz] == d[o + "_notes"][nz]).all()
+        assert (((fl >> 16) & 1) == d[o + "_prefilter"]).all()
+        assert (((fl >> 17) & 1)[nz] == d[o + "_filter"][nz]).all()
+    e.close()
+
+
+def _random_lmm(N, D, seed, V):
+    rng = np.random.default_rng(seed)
+    k = N - D
+    U = rng.standard_normal((N, k)) / np.sqrt(N)          # the algebra does not need orthonormal U
+    S = np.sort(rng.gamma(0.5, 2.0, k))[::-1].copy()
+    covar = np.ones((N, 1)) if D == 1 else np.c_[rng.standard_normal((N, D - 1)), np.ones((N, 1))]
+    y = (rng.random(N) < 0.4).astype(float)
+    af = rng.uniform(0.02, 0.98, V)
+    Kv = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    return U, S, covar, y, Kv
+
+
+@pytest.mark.parametrize("N,D,V", [(257, 1, 300), (1000, 3, 520), (777, 2, 64)])
+def test_lmm_vs_oracle_random(engine_mod, N, D, V):
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    U, S, covar, y, Kv = _random_lmm(N, D, 1234 + N, V)
+    L = orc.LmmOracle(U, S, y, covar)
+    wb, ws, wf, wp = L.block(0.37, Kv.astype(float))
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.37)
+    r = e.lmm_batch(pack(Kv))
+    close(r["beta"], wb, atol=1e-12, what="beta"); close(r["bse"], ws, what="bse")
+    close(r["frac_h2"], wf, atol=1e-9, what="frac"); close(r["pvalue"], wp, atol=1e-300, what="p")
+    for v in range(0, V, 37):
+        pr, bad = orc.pre_filtering(y, Kv[v].astype(float), False)
+        close(r["prep"][v], pr, what="prep"); assert bool(r["flags"][v] & 4) == bad
+    e.close()
+
+
+def test_lmm_full_size_properties(engine_mod):
+    """BASELINE config size (N=5000): oracle on a sample + size-independent properties on the whole batch."""
+    Engine, pack = engine_mod
+    import torch
+    from oracle import oracle as orc
+    N, D, V = 5000, 1, 2048
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    U = (torch.randn((N, N - 1), generator=g, device="cuda", dtype=torch.float64) / np.sqrt(N)).cpu().numpy()
+    rng = np.random.default_rng(9)
+    S = np.sort(rng.gamma(0.5, 2.0, N - 1))[::-1].copy()
+    y = (rng.random(N) < 0.4).astype(float); covar = np.ones((N, 1))
+    af = rng.uniform(0.02, 0.98, V)
+    Kv = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    Kv[1] = 1 - Kv[0]                       # complement: beta flips sign, bse / p identical (U~^T 1 = 0)
+    Kv[2] = Kv[0]                           # duplicate: identical outputs
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.3)
+    r5 = e.lmm_batch(pack(Kv))
+    close(r5["beta"][1], -r5["beta"][0], rtol=1e-9); close(r5["bse"][1], r5["bse"][0], rtol=1e-9)
+    close(r5["pvalue"][1], r5["pvalue"][0], rtol=1e-8)
+    for f in ("beta", "bse", "pvalue", "frac_h2", "prep"):
+        assert r5[f][2] == r5[f][0]
+    e.lmm_setup(U, S, y, covar, 0.3, n_limbs=6)
+    r6 = e.lmm_batch(pack(Kv))
+    close(r5["beta"], r6["beta"], rtol=1e-9); close(r5["bse"], r6["bse"], rtol=1e-9)
+    close(r5["pvalue"], r6["pvalue"], rtol=1e-7)
+    L = orc.LmmOracle(U, S, y, covar)
+    idx = np.arange(0, V, 64)
+    wb, ws, wf, wp = L.block(0.3, Kv[idx].astype(float))
+    close(r5["beta"][idx], wb, atol=1e-12); close(r5["bse"][idx], ws); close(r5["frac_h2"][idx], wf, atol=1e-9)
+    close(r5["pvalue"][idx], wp, atol=1e-300)
+    # device-resident entry point gives the same numbers
+    e.use_torch_stream()
+    bt = torch.from_numpy(pack(Kv)).cuda()
+    out, fl = e.lmm_batch_dev(bt)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy()[2], r6["beta"]) and np.array_equal(fl.cpu().numpy().astype(np.uint32), r6["flags"])
+    e.close()
