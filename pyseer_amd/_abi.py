@@ -50,6 +50,10 @@ def load():
     """Load libseerhip.so and bind every declared symbol (no device needed for this)."""
     global _lib
     if _lib is None:
+        # torch first: libseerhip shares torch's HIP runtime (one libamdhip64 per process), which is what lets the engine
+        # run on torch's streams and on torch-allocated HBM.  Loading our library before torch makes torch's later
+        # runtime initialisation fail ("no ROCm-capable device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError("libseerhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
                               "There is no CPU fallback." % LIB_PATH)

@@ -24,3 +24,93 @@ def mask_like_fit_lmm(r):
     p[af] = np.nan
     out["prep"] = p
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One-off LMM setup on the host (pyseer/lmm.py:26-122 initialise_lmm; pyseer/fastlmm/lmm_cov.py:88-104 setSU_fromK,
+# :427-478 findH2; pyseer/fastlmm/mingrid.py:13-103 minimize1D).  O(N^3) once per run, never per variant.
+# ---------------------------------------------------------------------------------------------------------------
+def spectral_decomposition(K, covar, use_gpu=False):
+    """setSU_fromK: K += I; K_ = P K P; eigh; U = U[:, D:], S = S[D:] - 1   (lmm_cov.py:88-104).
+
+    covar: (N, D) covariates incl. the intercept (last column).  use_gpu=True runs the symmetric eigensolver through
+    torch (rocSOLVER); the result feeds only per-run constants."""
+    K = np.array(K, dtype=np.float64, copy=True)
+    N = K.shape[0]
+    D = covar.shape[1]
+    K.flat[::N + 1] += 1.0
+    Xd = np.linalg.pinv(covar)                              # Linreg.Xdagger, lmm_cov.py:869
+    K_ = K - covar.dot(Xd.dot(K))
+    K_ = K_.T
+    K_ = K_ - covar.dot(Xd.dot(K_))
+    if use_gpu:
+        import torch
+        S, U = torch.linalg.eigh(torch.from_numpy(K_).cuda())
+        S = S.cpu().numpy(); U = U.cpu().numpy()
+    else:
+        S, U = np.linalg.eigh(K_)
+    return np.ascontiguousarray(U[:, D:N]), S[D:N] - 1.0
+
+
+def lmm_nll(h2, S, UY, n_dof):
+    """nLLeval(h2) without SNPs (lmm_cov.py:597-684, 686-838): the objective findH2 minimises."""
+    if h2 < 0.0 or h2 >= 1.0:
+        return 3e20
+    Sd = h2 * S + (1.0 - h2)
+    yKy = float(np.sum(UY * UY / Sd))
+    logdet = float(np.sum(np.log(Sd)))
+    sigma2 = yKy / n_dof
+    return 0.5 * (logdet + n_dof * (np.log(2.0 * np.pi * sigma2) + 1.0))
+
+
+def _rotate_y(U, y, covar):
+    """getUY -> rotate(Y): regress out the covariates, zero a constant residual, rotate (lmm_cov.py:165-218)."""
+    a = y - covar.dot(np.linalg.pinv(covar).dot(y))
+    if a.std() <= 1e-10:
+        a = np.zeros_like(a)
+    return U.T.dot(a)
+
+
+def find_h2(U, S, y, covar, n_grid=10, min_h2=0.0, max_h2=0.99999):
+    """findH2 + minimize1D (lmm_cov.py:427-478, mingrid.py:13-73): grid, fminbound at the edges, Brent on interior
+    triplets.  Returns (h2, nLL) of the best evaluated point, as the reference's resmin[0] does."""
+    from scipy import optimize as opt
+    UY = _rotate_y(U, np.asarray(y, dtype=np.float64).reshape(-1), covar)
+    n_dof = y.shape[0] - covar.shape[1]
+    best = [None, np.inf]
+
+    def f(x):
+        v = lmm_nll(float(x), S, UY, n_dof)
+        if best[0] is None or v < best[1]:
+            best[0], best[1] = float(x), v
+        return v
+
+    step = (max_h2 - min_h2) / n_grid
+    grid = np.arange(min_h2, max_h2 + step, step)           # mingrid.py:91-92
+    res = np.array([f(x) for x in grid])
+    if res[0] < res[1]:
+        opt.fminbound(f, grid[0], grid[1], full_output=True)
+    if res[-1] < res[-2]:
+        opt.fminbound(f, grid[-2], grid[-1], full_output=True)
+    for i in range(res.shape[0] - 2):
+        if res[i + 1] < res[i + 2] and res[i + 1] < res[i]:
+            opt.brent(f, brack=(grid[i], grid[i + 1], grid[i + 2]), full_output=True)
+    return best[0], best[1]
+
+
+def initialise_lmm_arrays(K, y, covar=None, use_gpu=False):
+    """Array-level initialise_lmm (lmm.py:77-122): normalise K by N/trace, append the intercept LAST, decompose, fit h2.
+    Returns (U, S, h2, nLL, covar_with_intercept)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    N = y.shape[0]
+    K = np.array(K, dtype=np.float64, copy=True)
+    if covar is None or np.size(covar) == 0:
+        C = np.ones((N, 1))
+    else:
+        C = np.c_[np.asarray(covar, dtype=np.float64).reshape(N, -1), np.ones((N, 1))]
+    factor = float(N) / np.diag(K).sum()
+    if abs(factor - 1.0) > 1e-15:
+        K *= factor
+    U, S = spectral_decomposition(K, C, use_gpu=use_gpu)
+    h2, nll = find_h2(U, S, y, C)
+    return U, S, h2, nll, C
