@@ -1,0 +1,487 @@
+// glm_kernels.hip -- fixed-effects per-variant regression on MI355X (gfx950).
+//
+// Reference path restated here:
+//   pyseer/model.py:202-394  fixed_effects_regression   (orchestration, notes, filters)
+//   statsmodels Logit.fit(method='newton')               (SM:base/optimizer.py:407-446, SM:base/model.py:497-534)
+//   pyseer/model.py:397-504  firth_likelihood / fit_firth
+//   statsmodels OLS.fit()                                (model.py:299-312)
+//
+// Mapping: ONE VARIANT PER LANE.  The design matrix is [1, k, W] where only the k column differs between variants,
+// so a wavefront walks the samples in lock-step: the sample's phenotype and covariate row are wave-uniform (they
+// arrive through the scalar cache as SGPR operands), the variant bit, eta, mu, the score vector and the p x p
+// information matrix are per-lane registers.  No cross-lane reduction, no LDS, no atomics on the hot path; the p x p
+// solves (LDL^T) run per lane, fully unrolled in registers.  Variants that need Firth (bad-chisq, high-bse, separation,
+// singular) are appended to a list and handled by the Firth kernel with the same mapping.
+#include "common.h"
+
+#define GLM_MAXQ 14
+
+__host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, i >= j
+
+struct GlmParams {
+    int N, NB64, continuous, force_firth;
+    int n1, n0;                   // #(y==1), #(y==0)
+    double ymean_logit;           // log(mean(y)/(1-mean(y)))   model.py:323-324
+    double yc_sum, yc_sq;         // centred-phenotype sums (Welch prefilter)
+    double null_llf, null_firth, pret, lrtt;
+    double min_af, max_af; int af_on;
+};
+
+// ---- LDL^T of a packed symmetric P x P matrix, in place (no pivoting; tolerates indefinite matrices) ----------------
+// returns false when a pivot is exactly zero (or NaN-free tiny relative to its diagonal when rel_tol > 0).
+template <int P>
+__device__ __forceinline__ bool ldl_factor(double (&A)[P * (P + 1) / 2], double rel_tol, double *det)
+{
+    bool ok = true;
+    double dt = 1.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double v[P];
+        const double ajj = A[sidx(j, j)];
+        double d = ajj;
+#pragma unroll
+        for (int k = 0; k < j; ++k) { v[k] = A[sidx(j, k)] * A[sidx(k, k)]; d = fma(-A[sidx(j, k)], v[k], d); }
+        if (d == 0.0 || fabs(d) <= rel_tol * fabs(ajj)) ok = false;
+        A[sidx(j, j)] = d;
+        dt *= d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+            double s = A[sidx(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = fma(-A[sidx(i, k)], v[k], s);
+            A[sidx(i, j)] = s * inv;
+        }
+    }
+    *det = dt;
+    return ok;
+}
+
+template <int P>
+__device__ __forceinline__ void ldl_solve(const double (&A)[P * (P + 1) / 2], double (&b)[P])
+{
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) b[i] = fma(-A[sidx(i, k)], b[k], b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) b[i] = b[i] / A[sidx(i, i)];
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) {
+#pragma unroll
+        for (int k = i + 1; k < P; ++k) b[i] = fma(-A[sidx(k, i)], b[k], b[i]);
+    }
+}
+
+__device__ __forceinline__ double logit_cdf(double x) { return 1.0 / (1.0 + exp(-x)); }    // SM Logit.cdf
+
+// ---- one pass over the samples at beta: X^T W X (packed), optional score, log-likelihood, max |mu - y| --------------
+// column order of the design: 0 = intercept, 1 = variant, 2.. = W columns (model.py:286-297)
+template <int Q, bool SCORE, bool LOGLIK>
+__device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
+                                          const double *__restrict__ y, const double *__restrict__ W,
+                                          const double (&beta)[Q + 2], double (&H)[(Q + 2) * (Q + 3) / 2],
+                                          double (&g)[Q + 2], double &ll, double &maxdev)
+{
+    constexpr int P = Q + 2;
+#pragma unroll
+    for (int a = 0; a < P * (P + 1) / 2; ++a) H[a] = 0.0;
+    if (SCORE) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) g[a] = 0.0;
+    }
+    ll = 0.0; maxdev = 0.0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            const double xd = (double)(unsigned)((w64 >> b) & 1ull);
+            const double yi = y[i];
+            double z[Q > 0 ? Q : 1];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) z[j] = W[(int64_t)i * Q + j];
+            double eta = fma(beta[1], xd, beta[0]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], z[j], eta);
+            const double mu = logit_cdf(eta);
+            const double wgt = mu * (1.0 - mu);
+            const double r = yi - mu;
+            maxdev = fmax(maxdev, fabs(r));
+            if (LOGLIK) ll += log(logit_cdf((2.0 * yi - 1.0) * eta));          // SM Logit.loglike
+            if (SCORE) {
+                g[0] += r; g[1] = fma(r, xd, g[1]);
+#pragma unroll
+                for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, z[j], g[2 + j]);
+            }
+            const double wx = wgt * xd;
+            H[sidx(0, 0)] += wgt;
+            H[sidx(1, 0)] += wx;                       // H11 == H10 (xd^2 == xd), filled in after the loop
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const double wz = wgt * z[j];
+                H[sidx(2 + j, 0)] += wz;
+                H[sidx(2 + j, 1)] = fma(wx, z[j], H[sidx(2 + j, 1)]);
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = fma(wz, z[k], H[sidx(2 + j, 2 + k)]);
+            }
+        }
+    }
+    H[sidx(1, 1)] = H[sidx(1, 0)];
+}
+
+// ---- a1 prefilter from the packed bits ------------------------------------------------------------------------------
+__device__ __forceinline__ double glm_prefilter(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int NB64, int N,
+                                                const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                const double *__restrict__ yc, const GlmParams &P, bool *bad, int *mcount)
+{
+    int t11 = 0, t01 = 0, m = 0;
+    double s1 = 0, q1 = 0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w = T[(int64_t)sb * Vpad + v];
+        m += __popcll(w); t11 += __popcll(w & y1[sb]); t01 += __popcll(w & y0[sb]);
+        if (P.continuous) {
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; ++b) {
+                const double xd = (double)(unsigned)((w >> b) & 1ull), t = yc[sb * 64 + b];
+                s1 = fma(xd, t, s1); q1 = fma(xd, t * t, q1);
+            }
+        }
+    }
+    *mcount = m;
+    *bad = false;
+    if (P.continuous) return sh_prefilter_welch((double)m, s1, q1, (double)(N - m), P.yc_sum - s1, P.yc_sq - q1);
+    return sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, bad);
+}
+
+// =====================================================================================================================
+// Logistic Newton (binary phenotype) -- one variant per lane
+// =====================================================================================================================
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_logit(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                  const double *__restrict__ y, const double *__restrict__ W,
+                                                  const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                  const double *__restrict__ yc, GlmParams P,
+                                                  double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                  int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    constexpr int PC = Q + 2;
+    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = v < V;
+    const int64_t vr = live ? v : 0;           // dead lanes shadow variant 0 and never write
+    const int N = P.N, NB64 = P.NB64;
+    uint32_t fl = 0;
+    double prep = NAN, pval = NAN, kbeta = NAN, kbse = NAN, icpt = NAN;
+    double beta[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
+    bool want_fit = live, to_firth = false;
+    bool bad = false; int m = 0;
+    prep = glm_prefilter(T, Vpad, vr, NB64, N, y1, y0, yc, P, &bad, &m);
+    if (P.af_on) {
+        const double af = (double)m / (double)N;
+        if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; want_fit = false; prep = NAN; }
+    }
+    if (want_fit) {
+        if (bad) fl |= SH_NOTE_BAD_CHISQ;
+        if (prep > P.pret || !isfinite(prep)) { fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER; want_fit = false; }   // model.py:266 (>)
+    }
+    if (want_fit && (bad || P.force_firth)) { to_firth = true; want_fit = false; }
+
+    // ---- statsmodels Newton: all lanes of the wave iterate together; finished lanes idle
+    beta[0] = P.ymean_logit;
+    int it = 0; bool fin = false, active = want_fit;
+    int status = 0;                     // 0 ok, 1 separation, 2 linalg
+    double llf = NAN, bse1 = NAN;
+    const double nobs = (double)N;
+    while (__any(active)) {
+        if (active) {
+            double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
+            info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev);
+            if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }                  // _check_perfect_pred
+            else if (fin) {
+                llf = ll;
+                // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534); only bse[1] is used (model.py:332)
+#pragma unroll
+                for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
+                double det;
+                if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
+                else {
+                    double e[PC];
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) e[a] = (a == 1) ? 1.0 : 0.0;
+                    ldl_solve<PC>(H, e);
+                    bse1 = sqrt(e[1] / nobs);
+                }
+                active = false;
+            } else {
+                // newparams = oldparams - inv(H/n + 1e-10 I) . score/n   with H = -X^T W X   (optimizer.py:415-423)
+#pragma unroll
+                for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) { H[sidx(a, a)] -= 1e-10; g[a] = g[a] / nobs; }
+                double det;
+                if (!ldl_factor<PC>(H, 0.0, &det)) { status = 2; active = false; }
+                else {
+                    ldl_solve<PC>(H, g);
+                    bool moving = false;
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
+                    ++it;
+                    if (!moving || it >= 35) fin = true;
+                }
+            }
+        }
+    }
+    if (want_fit) {
+        if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }
+        else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
+        else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }                 // model.py:332-334
+        else {
+            const double lrstat = -2.0 * (P.null_llf - llf);
+            pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);                        // model.py:336-339
+            icpt = beta[0]; kbeta = beta[1]; kbse = bse1;
+            if (pval > P.lrtt || !isfinite(pval) || !isfinite(kbeta)) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
+        }
+    }
+    if (live) {
+        out[v] = prep; out[V + v] = pval; out[2 * V + v] = kbeta; out[3 * V + v] = kbse; out[4 * V + v] = icpt;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = (to_firth || !want_fit) ? NAN : beta[2 + j];
+        flags[v] = fl;
+        if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
+    }
+}
+
+// =====================================================================================================================
+// Firth-penalised logistic regression (model.py:414-504) -- one listed variant per lane
+// =====================================================================================================================
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                  const double *__restrict__ y, const double *__restrict__ W,
+                                                  GlmParams P, const int *__restrict__ firth_list,
+                                                  const int *__restrict__ firth_count,
+                                                  double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    constexpr int PC = Q + 2;
+    const int cnt = *firth_count;
+    if ((int64_t)blockIdx.x * 64 >= cnt) return;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const bool live = slot < cnt;
+    const int64_t v = firth_list[live ? slot : 0];
+    const int N = P.N, NB64 = P.NB64;
+
+    double beta[PC], cand[PC], A[PC * (PC + 1) / 2], dummy[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
+    beta[0] = P.ymean_logit;
+    double ll, maxdev, det;
+    // F(beta_0)
+    info_pass<Q, false, true>(T, Vpad, v, N, NB64, y, W, beta, A, dummy, ll, maxdev);
+    double i11 = A[sidx(1, 1)];
+    ldl_factor<PC>(A, 0.0, &det);
+    double Fcur = -(ll + 0.5 * log(det));                       // firth_likelihood, model.py:410-411
+    double Fcand = Fcur, i11c = i11;
+    int state = live ? 0 : 3;          // 0: needs a score pass (new outer iteration), 1: needs F(cand), 2: converged, 3: done/failed
+    int iter = 0, halvings = 0;
+    double sn_prev = INFINITY;
+    bool failed = false;
+    while (__any(state < 2)) {
+        if (state == 0) {
+            // ---- penalised score at beta with the factored information A = L D L^T:  h_i = w_i x_i^T I^-1 x_i
+            double U[PC];
+#pragma unroll
+            for (int a = 0; a < PC; ++a) U[a] = 0.0;
+            for (int sb = 0; sb < NB64; ++sb) {
+                const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+                const int nb = min(64, N - sb * 64);
+                for (int b = 0; b < nb; ++b) {
+                    const int i = sb * 64 + b;
+                    double x[PC];
+                    x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll
+                    for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+                    double eta = 0.0;
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+                    const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+                    double zt[PC]; double qf = 0.0;
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) {
+                        double s = x[a];
+#pragma unroll
+                        for (int k = 0; k < a; ++k) s = fma(-A[sidx(a, k)], zt[k], s);
+                        zt[a] = s;
+                        qf = fma(s * s, 1.0 / A[sidx(a, a)], qf);
+                    }
+                    const double h = wgt * qf;                               // diagonal of the hat matrix, model.py:455-462
+                    const double res = y[i] - mu + h * (0.5 - mu);
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
+                }
+            }
+            ldl_solve<PC>(A, U);                                             // var_covar_mat . U, model.py:463
+#pragma unroll
+            for (int a = 0; a < PC; ++a) cand[a] = beta[a] + U[a];
+            halvings = 0;
+            state = 1;
+        }
+        if (state == 1) {
+            info_pass<Q, false, true>(T, Vpad, v, N, NB64, y, W, cand, A, dummy, ll, maxdev);
+            i11c = A[sidx(1, 1)];
+            ldl_factor<PC>(A, 0.0, &det);
+            Fcand = -(ll + 0.5 * log(det));
+            if (Fcand > Fcur) {                                              // step halving, model.py:467-474
+#pragma unroll
+                for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
+                if (++halvings > 1000) { failed = true; state = 3; }
+            } else {
+                double sn = 0.0;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) { const double d = cand[a] - beta[a]; sn = fma(d, d, sn); beta[a] = cand[a]; }
+                sn = sqrt(sn);
+                Fcur = Fcand; i11 = i11c;
+                const bool conv = (iter > 0) && (sn_prev < 1e-4);            // tests the PREVIOUS step, model.py:477-479
+                sn_prev = sn;
+                ++iter;
+                if (conv) state = 2;
+                else if (iter >= 1000) { failed = true; state = 3; }         // step_limit exhausted, model.py:482-484
+                else state = 0;
+            }
+        }
+    }
+    if (!live) return;
+    uint32_t fl = flags[v];
+    if (failed) {
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                           // model.py:357-362
+        out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
+    } else {
+        const double fitll = -Fcur;
+        const double lrstat = -2.0 * (P.null_firth - fitll);
+        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
+        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0];   // bse = sqrt(I11), model.py:491
+#pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    }
+    flags[v] = fl;
+}
+
+// =====================================================================================================================
+// OLS (continuous phenotype; model.py:299-312) -- closed form through the normal equations, one variant per lane.
+// XtX_shared: packed lower (Q+1)x(Q+1) of [1, W] ; Xty_shared: Q+1
+// =====================================================================================================================
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_ols(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                const double *__restrict__ y, const double *__restrict__ W,
+                                                const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                const double *__restrict__ yc, const double *__restrict__ ZtZ,
+                                                const double *__restrict__ Zty, GlmParams P,
+                                                double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    constexpr int PC = Q + 2;
+    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const int N = P.N, NB64 = P.NB64;
+    uint32_t fl = 0;
+    bool bad = false; int m = 0;
+    double prep = glm_prefilter(T, Vpad, v, NB64, N, y1, y0, yc, P, &bad, &m);
+    double pval = NAN, kbeta = NAN, kbse = NAN, icpt = NAN;
+    double beta[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = NAN;
+    bool go = true;
+    if (P.af_on) {
+        const double af = (double)m / (double)N;
+        if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; go = false; prep = NAN; }
+    }
+    if (go && (prep > P.pret || !isfinite(prep))) { fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER; go = false; }
+    if (go) {
+        // X^T X and X^T y: shared blocks from the host, variant column accumulated here
+        double sxz[Q > 0 ? Q : 1], sxy = 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) sxz[j] = 0.0;
+        for (int sb = 0; sb < NB64; ++sb) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; ++b) {
+                const int i = sb * 64 + b;
+                const double xd = (double)(unsigned)((w64 >> b) & 1ull);
+                sxy = fma(xd, y[i], sxy);
+#pragma unroll
+                for (int j = 0; j < Q; ++j) sxz[j] = fma(xd, W[(int64_t)i * Q + j], sxz[j]);
+            }
+        }
+        double A[PC * (PC + 1) / 2], rhs[PC], e1[PC];
+        A[sidx(0, 0)] = ZtZ[0]; A[sidx(1, 0)] = (double)m; A[sidx(1, 1)] = (double)m;
+        rhs[0] = Zty[0]; rhs[1] = sxy;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            A[sidx(2 + j, 0)] = ZtZ[sidx(1 + j, 0)]; A[sidx(2 + j, 1)] = sxz[j]; rhs[2 + j] = Zty[1 + j];
+#pragma unroll
+            for (int k = 0; k <= j; ++k) A[sidx(2 + j, 2 + k)] = ZtZ[sidx(1 + j, 1 + k)];
+        }
+        double det;
+        const bool ok = ldl_factor<PC>(A, 4.0e-16, &det);
+        ldl_solve<PC>(A, rhs);
+#pragma unroll
+        for (int a = 0; a < PC; ++a) { beta[a] = rhs[a]; e1[a] = (a == 1) ? 1.0 : 0.0; }
+        ldl_solve<PC>(A, e1);
+        double ssr = 0.0;
+        for (int sb = 0; sb < NB64; ++sb) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; ++b) {
+                const int i = sb * 64 + b;
+                double f = fma(beta[1], (double)(unsigned)((w64 >> b) & 1ull), beta[0]);
+#pragma unroll
+                for (int j = 0; j < Q; ++j) f = fma(beta[2 + j], W[(int64_t)i * Q + j], f);
+                const double r = y[i] - f;
+                ssr = fma(r, r, ssr);
+            }
+        }
+        const double dfr = (double)(N - PC);
+        const double scale = ssr / dfr;
+        kbse = sqrt(scale * e1[1]);
+        kbeta = beta[1]; icpt = beta[0];
+        pval = sh_t_sf2(kbeta / kbse, dfr);                                   // res.pvalues[1]
+        if (!ok) { pval = NAN; fl |= SH_NOTE_MATRIX_INV; }
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(kbeta)) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    }
+    out[v] = prep; out[V + v] = pval; out[2 * V + v] = kbeta; out[3 * V + v] = kbse; out[4 * V + v] = icpt;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = go ? beta[2 + j] : NAN;
+    flags[v] = fl;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------------
+template <int Q>
+static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
+                             const double *W, const uint64_t *y1, const uint64_t *y0, const double *yc, const double *ZtZ,
+                             const double *Zty, GlmParams P, double *out, uint32_t *flags, int *flist, int *fcount)
+{
+    const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
+    if (which == 0) hipLaunchKernelGGL(k_glm_logit<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, P, out, flags, flist, fcount);
+    else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags);
+    else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uint64_t *T, int64_t Vpad, int64_t V,
+                                     const double *y, const double *W, const uint64_t *y1, const uint64_t *y0,
+                                     const double *yc, const double *ZtZ, const double *Zty, GlmParams P, double *out,
+                                     uint32_t *flags, int *flist, int *fcount)
+{
+#define GLM_CASE(q) case q: return launch_glm<q>(st, which, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, flist, fcount);
+    switch (Q) {
+        GLM_CASE(0) GLM_CASE(1) GLM_CASE(2) GLM_CASE(3) GLM_CASE(4) GLM_CASE(5) GLM_CASE(6) GLM_CASE(7)
+        GLM_CASE(8) GLM_CASE(9) GLM_CASE(10) GLM_CASE(11) GLM_CASE(12) GLM_CASE(13) GLM_CASE(14)
+    default: return hipErrorInvalidValue;
+    }
+#undef GLM_CASE
+}

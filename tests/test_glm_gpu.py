@@ -1,0 +1,109 @@
+"""GPU parity of the fixed-effects path (logistic Newton, Firth, OLS kernels through the C ABI) against the reference's
+golden vectors and the CPU oracle.  Tolerances: 1e-6 relative (north_star); Firth-fitted values additionally get the
+3e-7 absolute slack explained in tests/test_oracle_golden.py (the reference's step-halving test is decided by rounding
+noise once steps are < ~1e-6)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FA = 3e-7
+
+
+def close(a, b, rtol=1e-6, atol=0.0, what=""):
+    a = np.atleast_1d(np.asarray(a, dtype=float)); b = np.atleast_1d(np.asarray(b, dtype=float))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    with np.errstate(invalid="ignore"):
+        ok = (np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))) | \
+             (np.abs(a - b) <= atol + rtol * np.abs(b))
+    assert ok.all(), "%s mismatch at %s: got %s want %s" % (what, np.argwhere(~ok)[:5].tolist(), a[~ok][:5], b[~ok][:5])
+
+
+def _run(d, force_firth=False):
+    from pyseer_amd.engine import Engine, pack_variants
+    y, m, K = d["y"], d["m"], d["K"]
+    e = Engine(int(d["N"]))
+    e.set_af_filter(0.01, 0.99)
+    e.glm_setup(y, m, bool(d["continuous"]), float(d["null_llf"]), float(d["null_firth"]), float(d["pret"]), float(d["lrtt"]),
+                force_firth=force_firth)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    return r
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "glm_*.npz")) + glob.glob(os.path.join(G, "ols_*.npz"))))
+def test_fixed_effects_golden(path):
+    d = np.load(path)
+    r = _run(d)
+    main = d["main"]
+    # exactly singular designs (variant column duplicates a covariate): the reference's Firth log det is LAPACK rounding
+    # noise -> its p-value is not a parity target (see tests/test_oracle_golden.py)
+    dup = np.zeros(main.shape[0], bool)
+    if "bincov" in path:
+        dup[[8, 9]] = True
+    close(r["prep"], main[:, 0], what="prep")
+    close(r["pvalue"][~dup], main[~dup, 1], atol=1e-300, what="pvalue")
+    close(r["kbeta"], main[:, 2], atol=FA, what="kbeta"); close(r["bse"], main[:, 3], atol=FA, what="bse")
+    close(r["intercept"], main[:, 4], atol=FA, what="intercept")
+    if int(d["q"]):
+        tested = np.isfinite(main[:, 2])
+        close(r["betas"][tested], d["betas"][tested], atol=FA, what="betas")
+        assert np.isnan(r["betas"][~tested]).all()
+    fl = r["flags"]
+    assert ((fl & 0x1FF) == d["notes"]).all(), np.argwhere((fl & 0x1FF) != d["notes"]).ravel()
+    assert (((fl >> 16) & 1) == d["prefilter"]).all() and (((fl >> 17) & 1) == d["filter"]).all()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "glm_*.npz"))))
+def test_forced_firth_golden(path):
+    """BASELINE config C4: every variant through fit_firth (model.py:414)."""
+    d = np.load(path)
+    if float(d["pret"]) < 1:
+        pytest.skip("prefilter active in this fixture")
+    r = _run(d, force_firth=True)
+    ok = d["firth_ok"] == 1
+    if "bincov" in path:
+        ok[[8, 9]] = False
+    fm = d["firth_main"]
+    close(r["intercept"][ok], fm[ok, 0], atol=FA); close(r["kbeta"][ok], fm[ok, 1], atol=FA)
+    close(r["bse"][ok], fm[ok, 2], atol=FA)
+    if int(d["q"]):
+        close(r["betas"][ok], d["firth_betas"][ok], atol=FA)
+    # p-value from fitll: lrstat = -2 (null_firth - fitll)
+    from oracle import oracle as orc
+    lr = -2 * (float(d["null_firth"]) - fm[ok, 3])
+    want_p = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
+    close(r["pvalue"][ok], want_p, rtol=2e-6, atol=1e-300)
+
+
+@pytest.mark.parametrize("N,q,V,cont", [(1000, 10, 640, False), (517, 5, 300, False), (800, 7, 256, True), (5000, 10, 192, False)])
+def test_fixed_effects_vs_oracle_random(N, q, V, cont):
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(100 + N + q)
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.3 + 1.5 * W[:, 0] - W[:, 1]
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    af = np.concatenate([rng.uniform(0.02, 0.98, V - V // 8), rng.uniform(0.002, 0.02, V // 8)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    keep = (K.mean(axis=1) >= 0.01) & (K.mean(axis=1) <= 0.99)
+    K = K[keep]
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, cont).llf
+    nf = np.nan if cont else fit_null(y, W, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W, cont, 1.0, 1.0, nl, nf)
+    e = Engine(N)
+    e.glm_setup(y, W, cont, nl, nf)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    firth = (want["notes"] & 0x7C) != 0          # any of bad-chisq/high-bse/sep/inv/firth-fail
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(r[f][~firth], want[f][~firth], what=f)
+        close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
+    close(r["betas"][~firth], want["betas"][~firth], atol=1e-12, what="betas")
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()

@@ -1,0 +1,37 @@
+"""Host-side null fits (pyseer_amd/model.py fit_null) against the reference's numbers (model_test.py:120-172 family)."""
+import os
+
+import numpy as np
+
+from pyseer_amd.model import fit_null, fit_firth_host, firth_likelihood
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_fit_null_matches_reference():
+    d = np.load(os.path.join(G, "model_unit.npz"))
+    pb, pc, m, cov = d["p_binary"], d["p_continuous"], d["m"], d["cov"]
+    e = np.zeros((0, 0))
+    assert abs(fit_null(pb, m, e, False).llf - float(d["null_llf_binary"])) < 1e-9
+    assert abs(fit_null(pb, m, e, False, firth=True) - float(d["null_firth_binary"])) < 1e-8
+    assert abs(fit_null(pc, m, e, True).llf - float(d["null_llf_cont"])) < 1e-8
+    assert abs(fit_null(pb, m, cov, False).llf - float(d["null_llf_binary_cov"])) < 1e-9
+    assert abs(fit_null(pb, m, cov, False, firth=True) - float(d["null_firth_binary_cov"])) < 1e-8
+
+
+def test_fit_firth_host_matches_reference():
+    d = np.load(os.path.join(G, "model_unit.npz"))
+    pb, k = d["p_binary"], d["k"]
+    X = np.concatenate((np.ones((100, 1)), k.reshape(-1, 1)), axis=1)
+    sv = np.array([np.log(pb.mean() / (1 - pb.mean())), 0.0])
+    beta, bse, fitll = fit_firth_host(X, pb, sv)
+    want = d["fit_firth_k"]
+    assert np.allclose([beta[0], beta[1], bse, fitll], [want[0], want[1], want[3], want[4]], rtol=1e-8, atol=1e-9)
+
+
+def test_synthetic_nulls():
+    for name in ("glm_N300_q10", "glm_N100_q0", "glm_N1000_q10"):
+        d = np.load(os.path.join(G, name + ".npz"))
+        m = d["m"] if int(d["q"]) else np.zeros((0, 0))
+        assert abs(fit_null(d["y"], m, np.zeros((0, 0)), False).llf - float(d["null_llf"])) < 1e-8
+        assert abs(fit_null(d["y"], m, np.zeros((0, 0)), False, firth=True) - float(d["null_firth"])) < 1e-7
