@@ -102,7 +102,8 @@ __device__ __forceinline__ double sh_prefilter_binary(int t11, int t10, int t01,
 __device__ __forceinline__ double sh_prefilter_welch(double n1, double s1, double q1, double n0, double s0, double q0)
 {
     double m1 = s1 / n1, m0 = s0 / n0;
-    double v1 = (q1 - s1 * m1) / (n1 - 1.0), v0 = (q0 - s0 * m0) / (n0 - 1.0);
+    // np.var(ddof=1) of a single observation is 0/0 = NaN (two-pass: deviations are exactly 0)
+    double v1 = n1 > 1.0 ? (q1 - s1 * m1) / (n1 - 1.0) : NAN, v0 = n0 > 1.0 ? (q0 - s0 * m0) / (n0 - 1.0) : NAN;
     double vn1 = v1 / n1, vn0 = v0 / n0;
     double df = (vn1 + vn0) * (vn1 + vn0) / (vn1 * vn1 / (n1 - 1.0) + vn0 * vn0 / (n0 - 1.0));
     if (isnan(df)) df = 1.0;

@@ -262,9 +262,11 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
                                                   const double *__restrict__ y, const double *__restrict__ W,
                                                   GlmParams P, const int *__restrict__ firth_list,
                                                   const int *__restrict__ firth_count,
-                                                  double *__restrict__ out, uint32_t *__restrict__ flags)
+                                                  double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                  int *__restrict__ pinv_list, int *__restrict__ pinv_count)
 {
     constexpr int PC = Q + 2;
+    const double SING_TOL = 1e-12;      // relative pivot size below which numpy's pinv (rcond 1e-15) may differ from inv
     const int cnt = *firth_count;
     if ((int64_t)blockIdx.x * 64 >= cnt) return;
     const int slot = blockIdx.x * 64 + threadIdx.x;
@@ -280,10 +282,10 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
     // F(beta_0)
     info_pass<Q, false, true>(T, Vpad, v, N, NB64, y, W, beta, A, dummy, ll, maxdev);
     double i11 = A[sidx(1, 1)];
-    ldl_factor<PC>(A, 0.0, &det);
+    bool singular = !ldl_factor<PC>(A, SING_TOL, &det);
     double Fcur = -(ll + 0.5 * log(det));                       // firth_likelihood, model.py:410-411
     double Fcand = Fcur, i11c = i11;
-    int state = live ? 0 : 3;          // 0: needs a score pass (new outer iteration), 1: needs F(cand), 2: converged, 3: done/failed
+    int state = (live && !singular) ? 0 : 3;          // 0: needs a score pass (new outer iteration), 1: needs F(cand), 2: converged, 3: done/failed
     int iter = 0, halvings = 0;
     double sn_prev = INFINITY;
     bool failed = false;
@@ -330,9 +332,10 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
         if (state == 1) {
             info_pass<Q, false, true>(T, Vpad, v, N, NB64, y, W, cand, A, dummy, ll, maxdev);
             i11c = A[sidx(1, 1)];
-            ldl_factor<PC>(A, 0.0, &det);
+            if (!ldl_factor<PC>(A, SING_TOL, &det)) { singular = true; state = 3; }
             Fcand = -(ll + 0.5 * log(det));
-            if (Fcand > Fcur) {                                              // step halving, model.py:467-474
+            if (state == 3) {
+            } else if (Fcand > Fcur) {                                              // step halving, model.py:467-474
 #pragma unroll
                 for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
                 if (++halvings > 1000) { failed = true; state = 3; }
@@ -352,6 +355,10 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
         }
     }
     if (!live) return;
+    if (singular) {                     // handled by k_glm_firth_pinv (numpy.linalg.pinv semantics, model.py:450)
+        const int s2 = atomicAdd(pinv_count, 1); pinv_list[s2] = (int)v;
+        return;
+    }
     uint32_t fl = flags[v];
     if (failed) {
         fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                           // model.py:357-362
@@ -364,6 +371,201 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
         double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
         out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0];   // bse = sqrt(I11), model.py:491
 #pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    }
+    flags[v] = fl;
+}
+
+
+// =====================================================================================================================
+// Firth slow path: literal restatement of fit_firth with numpy.linalg.pinv semantics (model.py:450) for variants whose
+// information matrix is (near-)singular, e.g. a k-mer that duplicates a binary covariate.  Arrays live in scratch and
+// loops are not unrolled: this kernel is about semantics, not speed, and sees a handful of variants per batch.
+// =====================================================================================================================
+template <int PC>
+__device__ __noinline__ void slow_info(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
+                                       const double *__restrict__ y, const double *__restrict__ W, const double *beta,
+                                       double *I, double *ll_out)
+{
+    constexpr int Q = PC - 2;
+    for (int a = 0; a < PC * PC; ++a) I[a] = 0.0;
+    double ll = 0.0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double x[PC];
+            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll 1
+            for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+            double eta = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+            const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+            ll += log(logit_cdf((2.0 * y[i] - 1.0) * eta));
+#pragma unroll 1
+            for (int a = 0; a < PC; ++a) {
+                const double wa = wgt * x[a];
+#pragma unroll 1
+                for (int c = 0; c < PC; ++c) I[a * PC + c] = fma(wa, x[c], I[a * PC + c]);
+            }
+        }
+    }
+    *ll_out = ll;
+}
+
+// numpy.linalg.det: LU with partial pivoting on a copy
+template <int PC>
+__device__ __noinline__ double slow_det(const double *Ain)
+{
+    double A[PC * PC];
+    for (int a = 0; a < PC * PC; ++a) A[a] = Ain[a];
+    double det = 1.0;
+#pragma unroll 1
+    for (int c = 0; c < PC; ++c) {
+        int p = c; double best = fabs(A[c * PC + c]);
+#pragma unroll 1
+        for (int r = c + 1; r < PC; ++r) { const double t = fabs(A[r * PC + c]); if (t > best) { best = t; p = r; } }
+        if (p != c) {
+#pragma unroll 1
+            for (int j = 0; j < PC; ++j) { const double t = A[c * PC + j]; A[c * PC + j] = A[p * PC + j]; A[p * PC + j] = t; }
+            det = -det;
+        }
+        const double d = A[c * PC + c];
+        det *= d;
+        if (d == 0.0) return 0.0;
+#pragma unroll 1
+        for (int r = c + 1; r < PC; ++r) {
+            const double f = A[r * PC + c] / d;
+#pragma unroll 1
+            for (int j = c + 1; j < PC; ++j) A[r * PC + j] = fma(-f, A[c * PC + j], A[r * PC + j]);
+        }
+    }
+    return det;
+}
+
+// numpy.linalg.pinv of a symmetric matrix: cyclic Jacobi eigen-decomposition, eigenvalues <= 1e-15 * max dropped
+template <int PC>
+__device__ __noinline__ void slow_pinv(const double *Ain, double *Pm)
+{
+    double A[PC * PC], Vv[PC * PC];
+    for (int a = 0; a < PC * PC; ++a) { A[a] = Ain[a]; Vv[a] = 0.0; }
+    for (int a = 0; a < PC; ++a) Vv[a * PC + a] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < PC; ++i) { dg = fma(A[i * PC + i], A[i * PC + i], dg); for (int j = i + 1; j < PC; ++j) off = fma(A[i * PC + j], A[i * PC + j], off); }
+        if (off <= 1e-34 * (dg + off) || off == 0.0) break;
+#pragma unroll 1
+        for (int p = 0; p < PC; ++p)
+#pragma unroll 1
+            for (int q = p + 1; q < PC; ++q) {
+                const double apq = A[p * PC + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * PC + q] - A[p * PC + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll 1
+                for (int k = 0; k < PC; ++k) { const double akp = A[k * PC + p], akq = A[k * PC + q]; A[k * PC + p] = c * akp - s * akq; A[k * PC + q] = s * akp + c * akq; }
+#pragma unroll 1
+                for (int k = 0; k < PC; ++k) { const double apk = A[p * PC + k], aqk = A[q * PC + k]; A[p * PC + k] = c * apk - s * aqk; A[q * PC + k] = s * apk + c * aqk; }
+#pragma unroll 1
+                for (int k = 0; k < PC; ++k) { const double vkp = Vv[k * PC + p], vkq = Vv[k * PC + q]; Vv[k * PC + p] = c * vkp - s * vkq; Vv[k * PC + q] = s * vkp + c * vkq; }
+            }
+    }
+    double smax = 0.0;
+    for (int i = 0; i < PC; ++i) smax = fmax(smax, fabs(A[i * PC + i]));
+#pragma unroll 1
+    for (int i = 0; i < PC; ++i)
+#pragma unroll 1
+        for (int j = 0; j < PC; ++j) {
+            double s = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < PC; ++k) { const double w = A[k * PC + k]; if (fabs(w) > 1e-15 * smax) s = fma(Vv[i * PC + k] / w, Vv[j * PC + k], s); }
+            Pm[i * PC + j] = s;
+        }
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_firth_pinv(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                       const double *__restrict__ y, const double *__restrict__ W,
+                                                       GlmParams P, const int *__restrict__ pinv_list,
+                                                       const int *__restrict__ pinv_count,
+                                                       double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    constexpr int PC = Q + 2;
+    const int cnt = *pinv_count;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= cnt) return;
+    const int64_t v = pinv_list[slot];
+    const int N = P.N, NB64 = P.NB64;
+    double beta[PC], cand[PC], I[PC * PC], Vm[PC * PC], U[PC];
+    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
+    beta[0] = P.ymean_logit;
+    double ll;
+    slow_info<PC>(T, Vpad, v, N, NB64, y, W, beta, I, &ll);
+    double Fcur = -(ll + 0.5 * log(slow_det<PC>(I)));
+    double i11 = I[PC + 1], sn_prev = INFINITY;
+    bool failed = false, conv = false;
+    for (int iter = 0; iter < 1000 && !failed && !conv; ++iter) {
+        slow_pinv<PC>(I, Vm);
+        for (int a = 0; a < PC; ++a) U[a] = 0.0;
+        for (int sb = 0; sb < NB64; ++sb) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; ++b) {
+                const int i = sb * 64 + b;
+                double x[PC];
+                x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll 1
+                for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+                double eta = 0.0, qf = 0.0;
+#pragma unroll 1
+                for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+                const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+#pragma unroll 1
+                for (int a = 0; a < PC; ++a) { double s = 0.0;
+#pragma unroll 1
+                    for (int c = 0; c < PC; ++c) s = fma(Vm[a * PC + c], x[c], s);
+                    qf = fma(x[a], s, qf); }
+                const double res = y[i] - mu + wgt * qf * (0.5 - mu);
+#pragma unroll 1
+                for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
+            }
+        }
+#pragma unroll 1
+        for (int a = 0; a < PC; ++a) { double s = 0.0;
+#pragma unroll 1
+            for (int c = 0; c < PC; ++c) s = fma(Vm[a * PC + c], U[c], s);
+            cand[a] = beta[a] + s; }
+        int halvings = 0; double Fcand;
+        for (;;) {
+            slow_info<PC>(T, Vpad, v, N, NB64, y, W, cand, I, &ll);
+            Fcand = -(ll + 0.5 * log(slow_det<PC>(I)));
+            if (!(Fcand > Fcur)) break;
+#pragma unroll 1
+            for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
+            if (++halvings > 1000) { failed = true; break; }
+        }
+        if (failed) break;
+        double sn = 0.0;
+#pragma unroll 1
+        for (int a = 0; a < PC; ++a) { const double d = cand[a] - beta[a]; sn = fma(d, d, sn); beta[a] = cand[a]; }
+        sn = sqrt(sn); Fcur = Fcand; i11 = I[PC + 1];
+        if (iter > 0 && sn_prev < 1e-4) conv = true;
+        sn_prev = sn;
+    }
+    if (!conv) failed = true;
+    uint32_t fl = flags[v];
+    if (failed) {
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;
+        out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
+    } else {
+        const double lrstat = -2.0 * (P.null_firth - (-Fcur));
+        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);
+        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0];
         for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
         if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
     }
@@ -463,11 +665,13 @@ __global__ __launch_bounds__(64) void k_glm_ols(const uint64_t *__restrict__ T, 
 template <int Q>
 static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
                              const double *W, const uint64_t *y1, const uint64_t *y0, const double *yc, const double *ZtZ,
-                             const double *Zty, GlmParams P, double *out, uint32_t *flags, int *flist, int *fcount)
+                             const double *Zty, GlmParams P, double *out, uint32_t *flags, int *flist, int *fcount,
+                             int *plist, int *pcount)
 {
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
     if (which == 0) hipLaunchKernelGGL(k_glm_logit<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, P, out, flags, flist, fcount);
-    else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags);
+    else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
+    else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags);
     return hipGetLastError();
 }
@@ -475,9 +679,9 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
 extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uint64_t *T, int64_t Vpad, int64_t V,
                                      const double *y, const double *W, const uint64_t *y1, const uint64_t *y0,
                                      const double *yc, const double *ZtZ, const double *Zty, GlmParams P, double *out,
-                                     uint32_t *flags, int *flist, int *fcount)
+                                     uint32_t *flags, int *flist, int *fcount, int *plist, int *pcount)
 {
-#define GLM_CASE(q) case q: return launch_glm<q>(st, which, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, flist, fcount);
+#define GLM_CASE(q) case q: return launch_glm<q>(st, which, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, flist, fcount, plist, pcount);
     switch (Q) {
         GLM_CASE(0) GLM_CASE(1) GLM_CASE(2) GLM_CASE(3) GLM_CASE(4) GLM_CASE(5) GLM_CASE(6) GLM_CASE(7)
         GLM_CASE(8) GLM_CASE(9) GLM_CASE(10) GLM_CASE(11) GLM_CASE(12) GLM_CASE(13) GLM_CASE(14)
