@@ -85,6 +85,42 @@ def cpu_baseline(U, S, y, C, h2, N, target_s=12.0):
                 sample="%d synthetic k-mers x %d samples, LMM block test (oracle/seer_oracle.c orc_lmm_block, OpenMP)" % (v1, N))
 
 
+def fixed_effects_extra(dev, local, N, q=10, V=1 << 18, reps=3):
+    """Secondary numbers for the fixed-effects half of the metric (BASELINE configs C2/C4 shapes at N samples):
+    logistic with 10 MDS-like covariates, and Firth forced on every variant.  Same packed-bit inputs, resident in HBM."""
+    import torch
+    from pyseer_amd.engine import Engine, row_bytes_for
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(1002)
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.3 + 1.5 * W[:, 0] - W[:, 1]
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-eta))).astype(np.float64)
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf
+    nf = fit_null(y, W, e0, False, firth=True)
+    out = {}
+    for name, force, v in (("logistic", False, V), ("firth", True, V // 2)):
+        eng = Engine(N, device=local); eng.use_torch_stream(); eng.set_af_filter(0.01, 0.99)
+        eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=force)
+        bits = synth_bits(v, N, row_bytes_for(N), 4242, dev)
+        o = torch.empty((5 + q, v), dtype=torch.float64, device=dev); f = torch.empty((v,), dtype=torch.int32, device=dev)
+        eng.glm_batch_dev(bits, o, f); torch.cuda.synchronize()
+        eng.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.glm_batch_dev(bits, o, f)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        kms, kl = eng.get_timing()
+        # SURVEY.md §8(d) work model: logistic ~1.1e6 fp64 flop/test at N=1000 (x N/1000), Firth ~9e6 at N=5000
+        flop = (1.1e6 * N / 1000.0) if not force else (9.0e6 * N / 5000.0)
+        out[name] = {"variants_per_s": v / dt, "n_samples": N, "q": q, "variants": v,
+                     "dominant_kernel": "k_glm_firth" if force else "k_glm_logit", "kernel_ms": kms / max(kl, 1),
+                     "fp64_vector_tflops_model": flop * v / (kms / max(kl, 1) * 1e-3) / 1e12, "fp64_vector_peak_tflops": 78.6}
+        eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +129,7 @@ def main():
     ap.add_argument("--variants-per-step", type=int, default=1 << 20)
     ap.add_argument("--limbs", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary fixed-effects measurements")
     args = ap.parse_args()
 
     import torch
@@ -166,6 +203,9 @@ def main():
                          "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9},
             "finite_fraction": frac_finite,
         }
+        if world == 1 and not args.no_extra:
+            res["extra"] = {"fixed_effects_N5000": fixed_effects_extra(dev, local, N_SAMPLES),
+                            "fixed_effects_N1000": fixed_effects_extra(dev, local, 1000, V=1 << 20)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(U, S, y, C, h2, N)
         print(json.dumps(res))

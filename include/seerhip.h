@@ -106,6 +106,9 @@ int sh_glm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
 /* d_out: (5+q)*V doubles SoA: prep,pvalue,kbeta,bse,intercept,betas[0..q) ; d_flags: V */
 int sh_glm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 
+/* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */
+int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);
+
 #ifdef __cplusplus
 }
 #endif

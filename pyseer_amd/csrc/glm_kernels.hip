@@ -82,7 +82,7 @@ template <int Q, bool SCORE, bool LOGLIK>
 __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
                                           const double *__restrict__ y, const double *__restrict__ W,
                                           const double (&beta)[Q + 2], double (&H)[(Q + 2) * (Q + 3) / 2],
-                                          double (&g)[Q + 2], double &ll, double &maxdev)
+                                          double (&g)[Q + 2], double &ll, double &maxdev, bool want_ll = true)
 {
     constexpr int P = Q + 2;
 #pragma unroll
@@ -105,11 +105,16 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
             double eta = fma(beta[1], xd, beta[0]);
 #pragma unroll
             for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], z[j], eta);
-            const double mu = logit_cdf(eta);
+            const double en = exp(-eta);
+            const double mu = 1.0 / (1.0 + en);                               // SM Logit.cdf
             const double wgt = mu * (1.0 - mu);
             const double r = yi - mu;
             maxdev = fmax(maxdev, fabs(r));
-            if (LOGLIK) ll += log(logit_cdf((2.0 * yi - 1.0) * eta));          // SM Logit.loglike
+            if (LOGLIK && want_ll) {
+                // SM Logit.loglike: log(cdf(q*eta)), q = 2y-1.  For y = 0: cdf(-eta) = 1/(1+exp(eta)), exp(eta) = 1/exp(-eta)
+                const double cq = (yi == 1.0) ? mu : ((yi == 0.0) ? 1.0 / (1.0 + 1.0 / en) : logit_cdf((2.0 * yi - 1.0) * eta));
+                ll += log(cq);
+            }
             if (SCORE) {
                 g[0] += r; g[1] = fma(r, xd, g[1]);
 #pragma unroll
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(64) void k_glm_logit(const uint64_t *__restrict__ T
     while (__any(active)) {
         if (active) {
             double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
-            info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev);
+            info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev, __any(fin));
             if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }                  // _check_perfect_pred
             else if (fin) {
                 llf = ll;
@@ -292,9 +297,9 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
     while (__any(state < 2)) {
         if (state == 0) {
             // ---- penalised score at beta with the factored information A = L D L^T:  h_i = w_i x_i^T I^-1 x_i
-            double U[PC];
+            double U[PC], dinv[PC];
 #pragma unroll
-            for (int a = 0; a < PC; ++a) U[a] = 0.0;
+            for (int a = 0; a < PC; ++a) { U[a] = 0.0; dinv[a] = 1.0 / A[sidx(a, a)]; }
             for (int sb = 0; sb < NB64; ++sb) {
                 const uint64_t w64 = T[(int64_t)sb * Vpad + v];
                 const int nb = min(64, N - sb * 64);
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
 #pragma unroll
                         for (int k = 0; k < a; ++k) s = fma(-A[sidx(a, k)], zt[k], s);
                         zt[a] = s;
-                        qf = fma(s * s, 1.0 / A[sidx(a, a)], qf);
+                        qf = fma(s * s, dinv[a], qf);
                     }
                     const double h = wgt * qf;                               // diagonal of the hat matrix, model.py:455-462
                     const double res = y[i] - mu + h * (0.5 - mu);
@@ -334,8 +339,15 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
             i11c = A[sidx(1, 1)];
             if (!ldl_factor<PC>(A, SING_TOL, &det)) { singular = true; state = 3; }
             Fcand = -(ll + 0.5 * log(det));
+            double stepmax = 0.0;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) stepmax = fmax(stepmax, fabs(cand[a] - beta[a]));
+            // F(new) > F(old) is decided by rounding noise once the step is ~1e-7 (|dF| ~ step^2 << ulp(F)); the reference then
+            // flips coins until one lands (moving beta by < 1e-10) or, rarely, exhausts step_limit on a 1-ulp tie.  Accept such
+            // steps outright: same result to 1e-10, no spurious 'firth-fail', no 50-pass stalls of the whole wavefront.
+            const bool noise_step = stepmax < 1e-10;
             if (state == 3) {
-            } else if (Fcand > Fcur) {                                              // step halving, model.py:467-474
+            } else if (Fcand > Fcur && !noise_step) {                               // step halving, model.py:467-474
 #pragma unroll
                 for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
                 if (++halvings > 1000) { failed = true; state = 3; }

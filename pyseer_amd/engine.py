@@ -131,6 +131,11 @@ class Engine(object):
                                               _dp(o[2]), _dp(o[3]), _dp(o[4]), _dp(betas), fl.ctypes.data_as(_abi.c_u32p)))
         return dict(prep=o[0], pvalue=o[1], kbeta=o[2], bse=o[3], intercept=o[4], betas=betas[:, :q], flags=fl)
 
+    def glm_info(self):
+        a = C.c_int64(); b = C.c_int64()
+        _abi.check(self._lib.sh_glm_info(self._h, C.byref(a), C.byref(b)))
+        return dict(firth_routed=a.value, pinv_routed=b.value)
+
     def glm_batch_dev(self, bits_t, out_t=None, flags_t=None):
         import torch
         V, rb = bits_t.shape
