@@ -18,7 +18,7 @@ extern "C" {
 hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
-hipError_t shk_lmm_quadform(hipStream_t, const int8_t *, const uint64_t *, int64_t, int, int, double *);
+hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, double *);
 hipError_t shk_lmm_finalize(hipStream_t, int64_t, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
                            unsigned long long *, int8_t *);
@@ -45,6 +45,7 @@ struct sh_ctx {
     uint64_t *d_y1 = nullptr, *d_y0 = nullptr;
     int8_t *d_G = nullptr;
     double quant_scale = 0.0;
+    int qf_variant = 0;           // hot-kernel variant (SEERHIP_QF=1 selects the first-generation kernel, for A/B runs)
     // ---- GLM state
     GlmState glm;
     // ---- per-batch workspace (grown on demand)
@@ -106,6 +107,7 @@ sh_ctx *sh_create(int device, int n_samples)
     if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
     sh_ctx *c = new sh_ctx();
     c->device = device; c->N = n_samples;
+    if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
     return c;
@@ -254,7 +256,8 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_G);
     c->d_vv = c->d_mdiag = c->d_yc = c->d_Qb = nullptr; c->d_y1 = c->d_y0 = nullptr; c->d_G = nullptr;
     const int NT = c->NT, L = n_limbs;
-    const size_t gbytes = (size_t)L * 2 * NT * (NT + 1) * 16384;
+    const int NR = 2 * NT;                                   // 128-sample row tiles
+    const size_t gbytes = (size_t)L * NR * (NR + 1) * 8192;
     double *d_W = nullptr, *d_sgn = nullptr, *d_M = nullptr; unsigned long long *d_amax = nullptr;
     HIPCHK(dmalloc(&c->d_vv, N)); HIPCHK(dmalloc(&c->d_mdiag, N)); HIPCHK(dmalloc(&c->d_yc, N));
     HIPCHK(dmalloc(&c->d_y1, c->NB64p)); HIPCHK(dmalloc(&c->d_y0, c->NB64p));
@@ -270,7 +273,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     HIPCHK(hipMemcpyAsync(c->d_y0, y0.data(), sizeof(uint64_t) * c->NB64p, hipMemcpyHostToDevice, st));
     if (DP) HIPCHK(hipMemcpyAsync(c->d_Qb, Qbp.data(), sizeof(double) * (size_t)N * DP, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_M, 0, sizeof(double) * (size_t)Np * Np, st));
-    HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NT, L, d_M, c->d_mdiag, d_amax, c->d_G));
+    HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NR, L, d_M, c->d_mdiag, d_amax, c->d_G));
     unsigned long long amax_bits = 0;
     HIPCHK(hipMemcpyAsync(&amax_bits, d_amax, sizeof(amax_bits), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -291,8 +294,8 @@ int sh_lmm_info(sh_ctx *c, int *n_limbs, int64_t *macs, double *qscale)
 {
     if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
     if (n_limbs) *n_limbs = c->L;
-    // executed int8 MACs per variant in k_lmm_quadform_i8: sum_I L * 4(I+1) K-steps * (256 rows * 64)
-    if (macs) *macs = (int64_t)c->L * 2 * c->NT * (c->NT + 1) * 256 * 64;
+    // executed int8 MACs per variant in k_lmm_quadform_i8: L * sum_I 2(I+1) tiles * (128 rows * 64), NR = 2*NT row tiles
+    if (macs) *macs = (int64_t)c->L * (2 * c->NT) * (2 * c->NT + 1) * 128 * 64;
     if (qscale) *qscale = c->quant_scale;
     return SH_OK;
 }
@@ -303,7 +306,7 @@ int sh_lmm_batch_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V
     if (V <= 0) return SH_OK;
     if (row_bytes * 8 < c->N) return fail(SH_ESHAPE, "row_bytes*8 < n_samples: shape mismatch between snps and Y");
     HIPCHK(hipSetDevice(c->device));
-    const int64_t Vpad = (V + 255) / 256 * 256;
+    const int64_t Vpad = (V + 511) / 512 * 512;
     int rc = ensure_ws(c, Vpad); if (rc) return rc;
     hipStream_t st = c->stream;
     LmmLinOut lo{c->d_t11, c->d_t01, c->d_m, c->d_xky, c->d_dg, c->d_rss, c->d_s1, c->d_q1};
@@ -312,7 +315,7 @@ int sh_lmm_batch_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V
                           c->fin.continuous, lo));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    HIPCHK(shk_lmm_quadform(st, c->d_G, c->d_T, Vpad, c->NT, c->L, c->d_q));
+    HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, c->d_q));
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->tev.emplace_back(e0, e1); }
     LmmFinParams P = c->fin; P.min_af = c->min_af; P.max_af = c->max_af; P.af_on = c->af_on;
     HIPCHK(shk_lmm_finalize(st, V, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags));

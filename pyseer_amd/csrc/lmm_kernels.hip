@@ -109,17 +109,30 @@ template __global__ void k_lmm_linear<32>(const uint64_t *, int64_t, int, int, c
 // ---------------------------------------------------------------------------------------------
 // THE hot kernel:  q[v] = sum_{i>j} x_i x_j Gq_ij   (exact integers; Gq = fixed-point 2*M_ij in L int8 limbs)
 //
-// Block = one tile of 256 variants, 512 threads = 8 waves as 2 (sample rows) x 4 (variants); each wave owns a
-// 128 x 64 int32 accumulator (4 x 2 MFMA 32x32 tiles = 128 VGPRs).  For every (row tile I, limb l) the block runs the
-// K loop over sample columns j < (I+1)*256 (G is strictly lower triangular, upper tiles are skipped), then folds the
-// accumulator against the variants' own bits for rows of tile I (x_i * (G x)_i) into an fp64 running sum.
+// Block = 512 variants x one 128-sample row tile at a time; 512 threads = 8 waves, wave w owns variants [64w, 64w+64) and
+// ALL 128 rows of the current row tile: a 128 x 64 int32 accumulator = 4 x 2 MFMA 32x32 tiles = 128 VGPRs.
+// For every (row tile I, limb l) the K loop runs over sample columns j < (I+1)*128 (G is strictly lower triangular; tiles
+// above the diagonal are never visited), then the accumulator is folded against the variants' own bits for the rows of
+// tile I (x_i * (G x)_i) into an fp64 running sum with weight 256^l.
 //
-// LDS image of a 256 x 64 int8 tile (rows = samples i or variants, 64 B of K per row): byte (r, c) lives at
-//   r*64 + 16*((c>>4) ^ ((r>>2)&3)) + (c&15)
-// so the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots (no bank conflicts).  G is stored in HBM already in
-// this image order (k_lmm_quantize), the variant tile is expanded bits->bytes on the fly.
+//  * A operand (G): 128 x 64 int8 tiles stored in HBM in LDS-image order: byte (r, c) at r*64 + 16*((c>>4) ^ ((r>>2)&3)) + (c&15),
+//    so (a) the HBM->LDS copy is a linear LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write) and (b) the
+//    16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots (no bank conflicts).  A stage = two consecutive tiles
+//    (128 deep in K, 16 KB), double-buffered; every G byte fetched feeds 512 variants.
+//  * B operand (variants): never touches LDS.  Each lane expands its own fragment (16 samples x 1 variant -> 16 int8) from the
+//    64-bit word of packed bits it loaded for that K tile: ((bits4 * 0x00204081) & 0x01010101) per 4 samples.
+//  * The (I, l, stage) nest is flattened into one stream with the next stage's DMA always in flight, so segment boundaries
+//    cost an epilogue, not a pipeline refill.
+//
+// History (V = 262144, N = 5000, L = 5; ms per launch): v1 LDS-staged B + register-staged A, 256x256 block: 20.3 ;
+// v2 register B + LDS-DMA A: 14.9 ; v3 128-deep stages: 14.0 (ablation: DMA 2.5 ms, bit expansion 0.8 ms, MFMA-only 9.7 ms) ;
+// v4 128 x 512 block + flattened (I,l,stage) stream, still one stage of DMA lookahead: 16.1 (LDS-DMA latency ~1.1 us > a stage) ;
+// v5 = this kernel: 4-slot LDS ring, every load in the loop is an LDS-DMA (G tiles AND the packed bits), counted vmcnt + raw
+// s_barrier so three stages of DMA stay in flight across every barrier: 14.3 (ablation: DMA 3.2, LDS fragment reads 1.8, bit
+// expansion 1.2, MFMA-only 9.65; `nt` on the bits DMA -4 %, s_setprio around the MFMAs +-0).
 // ---------------------------------------------------------------------------------------------
-#define QF_TILE_BYTES 16384
+#define QF_TILE_BYTES 8192          // 128 rows x 64 int8
+#define QF_BN 512                   // variants per block
 
 __device__ __forceinline__ int qf_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -133,119 +146,144 @@ __device__ __forceinline__ uint4 qf_expand16(uint32_t bits16)
     return r;
 }
 
-__global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
-                                                            int64_t Vpad, int NT, int L, double *__restrict__ qout)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const sA0 = smem, *const sB0 = smem + 2 * QF_TILE_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t v0 = (int64_t)blockIdx.x * 256;
-    const int bv = tid >> 1, bh = tid & 1;                       // B staging role: variant, 32-sample half
-    const int64_t TL = 2ll * NT * (NT + 1);                      // tiles per limb
-    double tot[2] = {0.0, 0.0};
+#define QF_NST 4                     // LDS ring depth (stages)
+#define QF_STAGE_BYTES (2 * QF_TILE_BYTES + 2 * QF_BN * 8)      // 16 KB of G + 8 KB of packed bits = 24 KB
 
-    for (int I = 0; I < NT; ++I) {
-        const int nks = 4 * (I + 1);
-        // the variants' own bits for the rows this wave accumulates (epilogue mask): x_i, i in tile I
-        uint32_t xw[4][2];
+// one stage HBM/L2 -> LDS by LDS-DMA, 3 wave-instructions of 1 KB per wave: two for the G tiles, one for the block's packed
+// bits of the two 64-sample blocks this stage spans.
+__device__ __forceinline__ void qf_dma_stage(const int8_t *gsrc, const uint64_t *tsrc, int64_t Vpad, char *slot, int wave, int lane)
+{
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            const int64_t vcol = v0 + wc * 64 + jt * 32 + l31;
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wave * 2 + j;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(slot + piece * 1024), 16, 0, 0);
+    }
+    // bits: row (wave>>2) of the stage's two sample blocks, variants [(wave&3)*128, +128) of the block, 2 words per lane
+    const uint64_t *src = tsrc + (int64_t)(wave >> 2) * Vpad + (wave & 3) * 128 + lane * 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(slot + 2 * QF_TILE_BYTES + wave * 1024), 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void qf_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ABL: timing ablations (results meaningless): 1 = no DMA, 2 = no LDS fragment reads, 4 = no bit expansion
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
+                                                            int64_t Vpad, int NR, int L, double *__restrict__ qout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // QF_NST slots x 24 KB (the ONLY LDS object)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t v0 = (int64_t)blockIdx.x * QF_BN;
+    const int64_t TL = (int64_t)NR * (NR + 1);                          // tiles per limb: sum_I 2(I+1)
+    const int total = L * (NR * (NR + 1) / 2);                          // stages in the flattened stream
+    int aoff[4][2];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int srow = I * 256 + wr * 128 + it * 32;
-                const uint64_t w = T[(int64_t)(srow >> 6) * Vpad + vcol];
-                xw[it][jt] = (uint32_t)(w >> (srow & 63));
-            }
-        }
-        double scale_l = 1.0;
-        for (int l = 0; l < L; ++l) {
-            const int8_t *Gt = G + ((int64_t)l * TL + 2ll * I * (I + 1)) * QF_TILE_BYTES;
-            v16i acc[4][2];
+    for (int it = 0; it < 4; ++it) { aoff[it][0] = qf_off(it * 32 + l31, lh); aoff[it][1] = qf_off(it * 32 + l31, 2 + lh); }
+    const int boff = 2 * QF_TILE_BYTES + (wave * 64 + l31) * 8;        // this lane's first variant column in the bits area
+
+    double tot[2] = {0.0, 0.0};
+    v16i acc[4][2];
+    int pI = 0, pl = 0, pst = 0, pslot = 0;                              // DMA cursor (QF_NST-1 stages ahead)
+    int cI = 0, cl = 0, cst = 0;                                        // compute cursor
+    double scale_l = 1.0;
+
+    auto fetch = [&]() {
+        const int8_t *g = G + ((int64_t)pl * TL + (int64_t)pI * (pI + 1) + 2 * pst) * QF_TILE_BYTES;
+        const uint64_t *t = T + (int64_t)(2 * pst) * Vpad + v0;
+        if (!(ABL & 1)) qf_dma_stage(g, t, Vpad, smem + pslot * QF_STAGE_BYTES, wave, lane);
+        if (++pslot == QF_NST) pslot = 0;
+        if (++pst == pI + 1) { pst = 0; if (++pl == L) { pl = 0; ++pI; } }
+    };
+
+#pragma unroll 1
+    for (int s = 0; s < QF_NST - 1 && s < total; ++s) fetch();
+
+    int slot = 0;
+#pragma unroll 1
+    for (int s = 0; s < total; ++s) {
+        // ---- stage s has landed for this wave once at most `newer` younger stages (3 DMAs each) are still in flight
+        const int newer = min(total - 1 - s, QF_NST - 2);
+        if (!(ABL & 1)) { if (newer >= 2) qf_wait_vm<6>(); else if (newer == 1) qf_wait_vm<3>(); else qf_wait_vm<0>(); }
+        __builtin_amdgcn_s_barrier();              // everyone's pieces of stage s landed; everyone finished reading stage s-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + QF_NST - 1 < total) fetch();        // refill the slot stage s-1 just vacated
+        if (cst == 0) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0;
-
-            uint4 ra0, ra1; uint32_t rb;
-            // ---- prologue: stage K-step 0 into buffer 0
-            ra0 = *reinterpret_cast<const uint4 *>(Gt + tid * 16);
-            ra1 = *reinterpret_cast<const uint4 *>(Gt + 8192 + tid * 16);
-            rb = (uint32_t)(T[v0 + bv] >> (32 * bh));
-            *reinterpret_cast<uint4 *>(sA0 + tid * 16) = ra0;
-            *reinterpret_cast<uint4 *>(sA0 + 8192 + tid * 16) = ra1;
-            *reinterpret_cast<uint4 *>(sB0 + qf_off(bv, 2 * bh)) = qf_expand16(rb & 0xFFFFu);
-            *reinterpret_cast<uint4 *>(sB0 + qf_off(bv, 2 * bh + 1)) = qf_expand16(rb >> 16);
-            __syncthreads();
-
-            for (int ks = 0; ks < nks; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                const bool more = (ks + 1 < nks);
-                if (more) {
-                    const int8_t *g = Gt + (int64_t)(ks + 1) * QF_TILE_BYTES;
-                    ra0 = *reinterpret_cast<const uint4 *>(g + tid * 16);
-                    ra1 = *reinterpret_cast<const uint4 *>(g + 8192 + tid * 16);
-                    rb = (uint32_t)(T[(int64_t)(ks + 1) * Vpad + v0 + bv] >> (32 * bh));
-                }
-                const char *a_base = sA0 + cur * QF_TILE_BYTES;
-                const char *b_base = sB0 + cur * QF_TILE_BYTES;
+        }
+        const char *a_base = smem + slot * QF_STAGE_BYTES;
+        uint64_t wb[2][2];
+        wb[0][0] = *reinterpret_cast<const uint64_t *>(a_base + boff);
+        wb[0][1] = *reinterpret_cast<const uint64_t *>(a_base + boff + 256);
+        wb[1][0] = *reinterpret_cast<const uint64_t *>(a_base + boff + QF_BN * 8);
+        wb[1][1] = *reinterpret_cast<const uint64_t *>(a_base + boff + QF_BN * 8 + 256);
+        v4i a_cur[4], a_nxt[4];
 #pragma unroll
-                for (int ksub = 0; ksub < 2; ++ksub) {
-                    v4i a[4], b[2];
+        for (int it = 0; it < 4; ++it)
+            a_cur[it] = (ABL & 2) ? (v4i){it, lane, s, 1} : *reinterpret_cast<const v4i *>(a_base + aoff[it][0]);
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        a[it] = *reinterpret_cast<const v4i *>(a_base + qf_off(wr * 128 + it * 32 + l31, ksub * 2 + lh));
+        for (int sub = 0; sub < 4; ++sub) {                          // sub = tile(0/1) * 2 + k-half(0/1)
+            if (sub < 3) {
+                const int nt = (sub + 1) >> 1, nk = (sub + 1) & 1;
 #pragma unroll
-                    for (int jt = 0; jt < 2; ++jt)
-                        b[jt] = *reinterpret_cast<const v4i *>(b_base + qf_off(wc * 64 + jt * 32 + l31, ksub * 2 + lh));
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-#pragma unroll
-                        for (int jt = 0; jt < 2; ++jt)
-                            acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[it], b[jt], acc[it][jt], 0, 0, 0);
-                }
-                if (more) {
-                    char *an = sA0 + nxt * QF_TILE_BYTES, *bn = sB0 + nxt * QF_TILE_BYTES;
-                    *reinterpret_cast<uint4 *>(an + tid * 16) = ra0;
-                    *reinterpret_cast<uint4 *>(an + 8192 + tid * 16) = ra1;
-                    *reinterpret_cast<uint4 *>(bn + qf_off(bv, 2 * bh)) = qf_expand16(rb & 0xFFFFu);
-                    *reinterpret_cast<uint4 *>(bn + qf_off(bv, 2 * bh + 1)) = qf_expand16(rb >> 16);
-                }
-                __syncthreads();
+                for (int it = 0; it < 4; ++it)
+                    a_nxt[it] = (ABL & 2) ? (v4i){it, lane, nt, nk}
+                                          : *reinterpret_cast<const v4i *>(a_base + nt * QF_TILE_BYTES + aoff[it][nk]);
             }
-            // ---- epilogue: s = sum_i x_i * acc_i for this wave's 128 rows, per variant column
+            const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
+            uint4 e0, e1;
+            if (ABL & 4) { e0 = make_uint4((uint32_t)wb[tl][0], ch, 1, 0); e1 = make_uint4((uint32_t)wb[tl][1], ch, 0, 1); }
+            else {
+                e0 = qf_expand16((uint32_t)(wb[tl][0] >> (16 * ch)) & 0xFFFFu);
+                e1 = qf_expand16((uint32_t)(wb[tl][1] >> (16 * ch)) & 0xFFFFu);
+            }
+            v4i b[2];
+            b[0] = (v4i){(int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w};
+            b[1] = (v4i){(int)e1.x, (int)e1.y, (int)e1.z, (int)e1.w};
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+                    acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[it], b[jt], acc[it][jt], 0, 0, 0);
+            // pin the issue order: next fragments' LDS reads first, then the 8 MFMAs (hipcc otherwise sinks each ds_read to just
+            // before its consumer and waits lgkmcnt(0) in front of every MFMA pair)
+            if (sub < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) a_cur[it] = a_nxt[it];
+        }
+        if (++slot == QF_NST) slot = 0;
+        if (++cst == cI + 1) {
+            // ---- segment epilogue: sum_i x_i * acc_i over the 128 rows of tile cI, per variant column.  The last stage of a
+            // segment spans exactly the row tile's own samples, so its bit words ARE the epilogue mask.
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                int s = 0;
+                int sum = 0;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const uint32_t w = xw[it][jt];
+                    const uint32_t w = (uint32_t)(wb[it >> 1][jt] >> ((it & 1) * 32));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;       // C/D layout of the 32x32 MFMA
-                        const int msk = -(int)((w >> row) & 1u);
-                        s += acc[it][jt][r] & msk;
+                        sum += acc[it][jt][r] & (-(int)((w >> row) & 1u));
                     }
                 }
-                tot[jt] = fma((double)s, scale_l, tot[jt]);
+                tot[jt] = fma((double)sum, scale_l, tot[jt]);
             }
-            scale_l *= 256.0;
+            cst = 0; scale_l *= 256.0;
+            if (++cl == L) { cl = 0; scale_l = 1.0; ++cI; }
         }
     }
-    // lanes l and l^32 hold different rows of the same variant; waves wr=0/1 hold different rows too
+    // lanes l and l^32 hold different rows of the same variant
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) tot[jt] += __shfl_xor(tot[jt], 32, 64);
-    double *red = reinterpret_cast<double *>(smem);
-    __syncthreads();
-    if (wr == 1 && lh == 0) { red[wc * 64 + l31] = tot[0]; red[wc * 64 + 32 + l31] = tot[1]; }
-    __syncthreads();
-    if (wr == 0 && lh == 0) {
-        qout[v0 + wc * 64 + l31] = tot[0] + red[wc * 64 + l31];
-        qout[v0 + wc * 64 + 32 + l31] = tot[1] + red[wc * 64 + 32 + l31];
-    }
+    if (lh == 0) { qout[v0 + wave * 64 + l31] = tot[0]; qout[v0 + wave * 64 + 32 + l31] = tot[1]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,22 +403,22 @@ __global__ void k_extract_diag(const double *__restrict__ M, int N, int Np, doub
     if (i < N) mdiag[i] = M[(int64_t)i * Np + i];
 }
 
-// fixed-point limbs in LDS-image order.  grid = (tile index within a limb), block = 256 threads (one tile row each).
-__global__ __launch_bounds__(256) void k_lmm_quantize(const double *__restrict__ M, int N, int Np, int NT, int L,
+// fixed-point limbs in LDS-image order.  grid = (tile index within a limb), block = 128 threads (one tile row each).
+__global__ __launch_bounds__(128) void k_lmm_quantize(const double *__restrict__ M, int N, int Np, int NR, int L,
                                                       const unsigned long long *__restrict__ amax_bits,
                                                       int8_t *__restrict__ G)
 {
-    // decode (I, ks) from the linear tile id: tiles of row tile I start at 2*I*(I+1)
+    // decode (I, ks) from the linear tile id: tiles of 128-row tile I start at I*(I+1) and there are 2(I+1) of them
     int t = blockIdx.x, I = 0;
-    while (2 * (I + 1) * (I + 2) <= t) ++I;
-    const int ks = t - 2 * I * (I + 1);
+    while ((I + 1) * (I + 2) <= t) ++I;
+    const int ks = t - I * (I + 1);
     const int r = threadIdx.x;
-    const int i = I * 256 + r;
+    const int i = I * 128 + r;
     const double amax = __longlong_as_double((long long)*amax_bits);
     double p256 = 1.0;
     for (int l = 0; l < L; ++l) p256 *= 256.0;
     const double scale = amax > 0 ? 0.49 * p256 / amax : 0.0;
-    const int64_t TL = 2ll * NT * (NT + 1);
+    const int64_t TL = (int64_t)NR * (NR + 1);
     for (int ch = 0; ch < 4; ++ch) {
         long long qv[16];
 #pragma unroll
@@ -433,14 +471,26 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_quadform(hipStream_t st, const int8_t *G, const uint64_t *T, int64_t Vpad, int NT, int L, double *q)
+hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, double *q)
 {
+    const dim3 g((unsigned)(Vpad / QF_BN)), b(512);
+    const size_t lds = QF_NST * QF_STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * QF_TILE_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_lmm_quadform_i8, dim3((unsigned)(Vpad / 256)), dim3(512), 4 * QF_TILE_BYTES, st, G, T, Vpad, NT, L, q);
+    switch (variant) {          // 30 + mask = timing ablations (results meaningless)
+    case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
+    case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
+    case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
+    case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
+    default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
+    }
     return hipGetLastError();
 }
 
@@ -451,7 +501,7 @@ hipError_t shk_lmm_finalize(hipStream_t st, int64_t V, LmmLinOut li, const doubl
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, int N, int Np, int kp, int NT, int L,
+hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, int N, int Np, int kp, int NR, int L,
                            double *M, double *mdiag, unsigned long long *amax, int8_t *G)
 {
     const int nb = Np / 128;
@@ -459,7 +509,7 @@ hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, i
     hipLaunchKernelGGL(k_syrk_f64, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, st, W, sgn, Np, kp, M);
     hipLaunchKernelGGL(k_lower_absmax, dim3((unsigned)N), dim3(256), 0, st, M, N, Np, amax);
     hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, M, N, Np, mdiag);
-    hipLaunchKernelGGL(k_lmm_quantize, dim3((unsigned)(2 * NT * (NT + 1))), dim3(256), 0, st, M, N, Np, NT, L, amax, G);
+    hipLaunchKernelGGL(k_lmm_quantize, dim3((unsigned)(NR * (NR + 1))), dim3(128), 0, st, M, N, Np, NR, L, amax, G);
     return hipGetLastError();
 }
 
