@@ -1,0 +1,286 @@
+"""`python -m pyseer_amd` -- pyseer's command line for the per-variant association tests, driving the HIP engine.
+
+Mirrors pyseer/__main__.py for the options that reach the hot path: k-mer / Rtab input, fixed effects (SEER) with MDS of
+a distance matrix or --no-distances, --lmm with a similarity matrix or --load-lmm cache, covariates, continuous
+phenotypes, the AF / missing / p-value filters, --print-samples / --print-filtered / --output-patterns, and the four
+end-of-run counters.  Variants are parsed in blocks of --block_size, packed, and tested block-wise on the GPU; rows are
+printed in the reference's order (fixed effects: input order; LMM: within a block the filtered variants first, then the
+tested ones -- fit_lmm returns them that way, lmm.py:160-224).
+
+Not supported (out of scope or not built yet): --vcf/--burden (pysam), --wg (enet/rf), --lineage.
+"""
+import argparse
+import os
+import sys
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from . import __version__
+from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
+from .input import (load_phenotypes, load_structure, load_covariates, open_variant_file, iter_packed_blocks)
+from .lmm import initialise_lmm, mask_like_fit_lmm
+from .model import fit_null, covariate_block
+from .utils import format_output
+
+
+def get_options(argv=None):
+    description = 'SEER (doi: 10.1038/ncomms12797), reimplemented in python -- MI355X engine (pyseer_amd)'
+    parser = argparse.ArgumentParser(description=description, prog="pyseer_amd")
+    ph = parser.add_argument_group('Phenotype')
+    ph.add_argument('--phenotypes', required=True, help='Phenotypes file (whitespace separated)')
+    ph.add_argument('--phenotype-column', default=None, help='Phenotype file column to use [Default: last column]')
+    va = parser.add_argument_group('Variants')
+    vg = va.add_mutually_exclusive_group(required=True)
+    vg.add_argument('--kmers', default=None, help='Kmers file')
+    vg.add_argument('--vcf', default=None, help='VCF file (not supported by this build)')
+    vg.add_argument('--pres', default=None, help='Presence/absence .Rtab matrix as produced by roary and piggy')
+    va.add_argument('--burden', help='(not supported by this build)')
+    di = parser.add_argument_group('Distances')
+    dg = di.add_mutually_exclusive_group()
+    dg.add_argument('--distances', help='Strains distance square matrix (fixed or lineage effects)')
+    dg.add_argument('--load-m', help='Load an existing matrix decomposition')
+    sg = di.add_mutually_exclusive_group()
+    sg.add_argument('--similarity', help='Strains similarity square matrix (for --lmm)')
+    sg.add_argument('--load-lmm', help='Load an existing lmm cache')
+    di.add_argument('--save-m', help='Prefix for saving matrix decomposition')
+    di.add_argument('--save-lmm', help='Prefix for saving LMM cache')
+    di.add_argument('--mds', default="classic", help='Type of multidimensional scaling [Default: classic]')
+    di.add_argument('--max-dimensions', type=int, default=10, help='Maximum number of dimensions to consider after MDS')
+    di.add_argument('--no-distances', action='store_true', default=False, help='Allow run without a distance matrix')
+    asc = parser.add_argument_group('Association options')
+    asc.add_argument('--continuous', action='store_true', default=False, help='Force continuous phenotype')
+    asc.add_argument('--lmm', action='store_true', default=False, help='Use random instead of fixed effects')
+    asc.add_argument('--wg', default=None, help='(not supported by this build)')
+    asc.add_argument('--lineage', action='store_true', help='(not supported by this build)')
+    asc.add_argument('--lineage-clusters', help='(not supported by this build)')
+    asc.add_argument('--lineage-file', default="lineage_effects.txt")
+    fi = parser.add_argument_group('Filtering options')
+    fi.add_argument('--min-af', type=float, default=0.01, help='Minimum AF [Default: 0.01]')
+    fi.add_argument('--max-af', type=float, default=0.99, help='Maximum AF [Default: 0.99]')
+    fi.add_argument('--max-missing', type=float, default=0.05, help='Maximum missing (vcf/Rtab) [Default: 0.05]')
+    fi.add_argument('--filter-pvalue', type=float, default=1, help='Prefiltering t-test pvalue threshold [Default: 1]')
+    fi.add_argument('--lrt-pvalue', type=float, default=1, help='Likelihood ratio test pvalue threshold [Default: 1]')
+    co = parser.add_argument_group('Covariates')
+    co.add_argument('--covariates', default=None, help='User-defined covariates file')
+    co.add_argument('--use-covariates', default=None, nargs='*', help="Covariates to use; 'q' suffix = quantitative")
+    ot = parser.add_argument_group('Other')
+    ot.add_argument('--print-samples', action='store_true', default=False, help='Print sample lists [Default: hide]')
+    ot.add_argument('--print-filtered', action='store_true', default=False, help='Print filtered variants [Default: hide]')
+    ot.add_argument('--output-patterns', default=False, help='File to print patterns to, useful for finding pvalue threshold')
+    ot.add_argument('--uncompressed', action='store_true', default=False, help='Uncompressed kmers file [Default: gzipped]')
+    ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
+    ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
+    ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--version', action='version', version='%(prog)s ' + __version__)
+    return parser.parse_args(argv)
+
+
+def _die(msg):
+    sys.stderr.write(msg)
+    sys.exit(1)
+
+
+def _host_prefilter(p, k, continuous):
+    """pre_filtering (model.py:31-70) for the rare variants that carry missing calls and therefore never reach the GPU."""
+    from scipy import stats
+    if continuous:
+        return stats.ttest_ind(p[k == 1], p[k == 0], equal_var=False)[1], False
+    table = np.array([[np.sum((p == 1) & (k == 1)), np.sum((p == 1) & (k == 0))],
+                      [np.sum((p == 0) & (k == 1)), np.sum((p == 0) & (k == 0))]])
+    bad = bool((table <= 1).sum() > 0 or (table <= 5).sum() > 1)
+    try:
+        prep = stats.chi2_contingency(table, correction=False)[1]
+    except ValueError:
+        prep = np.nan
+    return prep, bad
+
+
+def main(argv=None):
+    options = get_options(argv)
+    if options.vcf or options.burden:
+        _die('VCF / burden input needs pysam and is not supported by pyseer_amd\n')
+    if options.wg:
+        _die('Whole-genome models (--wg) are out of scope for pyseer_amd\n')
+    if options.lineage or options.lineage_clusters:
+        _die('Lineage effects (--lineage) are not built in this round of pyseer_amd\n')
+    if options.max_dimensions < 1:
+        _die('Minimum number of dimensions after MDS is 1\n')
+    if options.lmm and not options.similarity and not options.load_lmm:
+        _die('Must provide a similarity matrix or lmm cache for random effects\n')
+    if not options.no_distances:
+        if (options.lmm and (options.distances or options.load_m)) or (not options.lmm and (options.similarity or options.load_lmm)):
+            sys.stderr.write('Must use distance matrix with fixed effects, or similarity matrix with random effects\n')
+            _die('Unless performing a lineage analysis with random effects\n')
+        if not options.lmm and not options.distances and not options.load_m:
+            _die('Option --no-distances must be used when no distance matrix is provided\n')
+    else:
+        if options.distances or options.load_m:
+            _die('Cannot use --no-distances with --distances or --load-m\n')
+        if options.lmm:
+            _die('Cannot use --no-distances with --lmm\n')
+    if options.block_size < 1:
+        _die('Block size must be at least 1\n')
+    warnings.filterwarnings('ignore')
+
+    p = load_phenotypes(options.phenotypes, options.phenotype_column)
+    sys.stderr.write("Read " + str(len(p)) + " phenotypes\n")
+    if not options.continuous:
+        if p.values[(p.values != 0) & (p.values != 1)].size > 0:
+            options.continuous = True
+            sys.stderr.write("Detected continuous phenotype\n")
+        else:
+            sys.stderr.write("Detected binary phenotype\n")
+
+    if options.covariates is not None:
+        cov = load_covariates(options.covariates, options.use_covariates, p)
+        if cov is None:
+            sys.exit(1)
+    else:
+        cov = pd.DataFrame([])
+
+    m = np.empty(shape=(0, 0))
+    null_fit = firth_null = None
+    if not options.lmm:
+        if not options.no_distances:
+            if options.load_m and os.path.isfile(options.load_m):
+                mdf = pd.read_pickle(options.load_m)
+                sys.stderr.write("Loaded projection with dimension " + str(mdf.shape) + "\n")
+            else:
+                seed = os.environ.get('PYSEERSEED', None)
+                mdf = load_structure(options.distances, p, options.max_dimensions, options.mds, options.cpu,
+                                     int(seed) if seed is not None else None)
+                if options.save_m:
+                    mdf.to_pickle(options.save_m + ".pkl")
+            if options.max_dimensions > mdf.shape[1]:
+                sys.stderr.write('Population MDS scaling restricted to %d dimensions instead of requested %d\n' %
+                                 (mdf.shape[1], options.max_dimensions))
+                options.max_dimensions = mdf.shape[1]
+            inter = p.index.intersection(mdf.index)
+            sys.stderr.write("Analysing " + str(len(inter)) + " samples found in both phenotype and structure matrix\n")
+            p = p.loc[inter]
+            m = mdf.loc[p.index].values[:, :options.max_dimensions]
+        if cov.shape[1] > 0:
+            cov = cov.loc[p.index]
+        null_fit = fit_null(p.values, m, cov, options.continuous)
+        firth_null = fit_null(p.values, m, cov, options.continuous, True) if not options.continuous else True
+        if null_fit is None or firth_null is None:
+            _die('Could not fit null model, exiting\n')
+
+    from .engine import Engine
+    if options.lmm:
+        sys.stderr.write("Setting up LMM\n")
+        p, lmm, h2 = initialise_lmm(p, cov, options.similarity, options.load_lmm, options.save_lmm)
+        sys.stderr.write("h^2 = " + '{0:.2f}'.format(h2) + "\n")
+        eng = Engine(len(p), device=options.gpu)
+        eng.lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)
+    else:
+        eng = Engine(len(p), device=options.gpu)
+        eng.glm_setup(p.values, covariate_block(len(p), m, cov), options.continuous,
+                      np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
+                      options.filter_pvalue, options.lrt_pvalue)
+
+    all_strains = set(p.index)
+    var_type, var_file = ("kmers", options.kmers) if options.kmers else ("Rtab", options.pres)
+    infile, sample_order = open_variant_file(var_type, var_file, None, None, options.uncompressed)
+    patterns = open(options.output_patterns, 'wb') if options.output_patterns else None
+
+    header = ['variant', 'af', 'filter-pvalue', 'lrt-pvalue', 'beta', 'beta-std-err']
+    if not options.lmm:
+        header.append('intercept')
+        if not options.no_distances:
+            header += ['PC%d' % i for i in range(1, options.max_dimensions + 1)]
+        if options.covariates is not None:
+            header += [x for x in cov.columns]
+    else:
+        header.append('variant_h2')
+    if options.print_samples:
+        header += ['k-samples', 'nk-samples']
+    header.append('notes')
+    print('\t'.join(header))
+
+    model = 'lmm' if options.lmm else 'seer'
+    prefilter = tested = printed = 0
+    pv = p.values.astype(float)
+    nan = np.nan
+    out = sys.stdout
+
+    def emit(x):
+        nonlocal prefilter, tested, printed
+        if x.prefilter:
+            prefilter += 1
+            if options.print_filtered:
+                printed += 1
+                out.write(format_output(x, None, model, options.print_samples) + "\n")
+            return
+        tested += 1
+        if patterns is not None:
+            patterns.write(x.pattern)
+        if x.filter and not options.print_filtered:
+            return
+        printed += 1
+        out.write(format_output(x, None, model, options.print_samples) + "\n")
+
+    for blk in iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
+                                  options.max_missing, options.uncompressed, options.block_size):
+        if options.lmm:
+            r = mask_like_fit_lmm(eng.lmm_batch(blk.bits)) if blk.bits.shape[0] else None
+        else:
+            r = eng.glm_batch(blk.bits) if blk.bits.shape[0] else None
+        rows = []
+        for i, name in enumerate(blk.names):
+            st, af, ks, nks = blk.status[i], blk.afs[i], blk.kstrains[i], blk.nkstrains[i]
+            if st == 1:                                   # AF / missing filtered (model.py:255-260, lmm.py:160-167)
+                if options.lmm:
+                    rows.append(LMM(name, None, af, nan, nan, nan, nan, nan, None, ks, nks, {'af-filter'}, True, False))
+                else:
+                    rows.append(Seer(name, blk.patterns[i], af, nan, nan, nan, nan, nan, np.array([]), None, ks, nks,
+                                     {'af-filter'}, True, False))
+                continue
+            if st == 2:                                   # missing calls inside k: the reference's error path
+                prep, bad = _host_prefilter(pv, blk.ks[i], options.continuous)
+                notes = {'bad-chisq'} if bad else set()
+                thr = options.filter_pvalue
+                failed = (prep >= thr) if options.lmm else (prep > thr)
+                if failed or not np.isfinite(prep):
+                    notes.add('pre-filtering-failed')
+                    x = (LMM(name, blk.patterns[i], af, prep, nan, nan, nan, nan, None, ks, nks, notes, True, False)
+                         if options.lmm else
+                         Seer(name, blk.patterns[i], af, prep, nan, nan, nan, nan, np.array([]), None, ks, nks, notes, True, False))
+                elif options.lmm:                         # NaN propagates through fit_lmm_block -> lrt-filtering-failed
+                    notes.add('lrt-filtering-failed')
+                    x = LMM(name, blk.patterns[i], af, prep, nan, nan, nan, nan, None, ks, nks, notes, False, True)
+                else:                                     # statsmodels MissingDataError, model.py:371-377
+                    notes.add('missing-data-error')
+                    x = Seer(name, blk.patterns[i], af, prep, nan, nan, nan, nan, np.array([]), None, ks, nks, notes, False, True)
+                rows.append(x)
+                continue
+            j = blk.row_of[i]
+            fl = int(r["flags"][j])
+            notes = notes_from_flags(fl)
+            pf, ft = bool(fl & FLAG_PREFILTER), bool(fl & FLAG_FILTER)
+            if options.lmm:
+                rows.append(LMM(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["beta"][j], r["bse"][j],
+                                r["frac_h2"][j], None, ks, nks, notes, pf, ft))
+            else:
+                tested_ok = np.isfinite(r["kbeta"][j]) or np.isfinite(r["pvalue"][j])
+                betas = r["betas"][j] if (tested_ok and r["betas"].shape[1]) else np.array([])
+                rows.append(Seer(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["kbeta"][j], r["bse"][j],
+                                 r["intercept"][j], betas, None, ks, nks, notes, pf, ft))
+        if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
+            rows = [x for x in rows if x.prefilter] + [x for x in rows if not x.prefilter]
+        for x in rows:
+            emit(x)
+
+    if patterns is not None:
+        patterns.close()
+    eng.close()
+    sys.stderr.write('%d loaded variants\n' % (prefilter + tested))
+    sys.stderr.write('%d pre-filtered variants\n' % prefilter)
+    sys.stderr.write('%d tested variants\n' % tested)
+    sys.stderr.write('%d printed variants\n' % printed)
+
+
+if __name__ == "__main__":
+    main()

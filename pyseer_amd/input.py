@@ -1,0 +1,277 @@
+"""Variant stream and loaders, mirroring pyseer/input.py's contracts for k-mer and Rtab input.
+
+The generators keep the reference's tuple layouts (iter_variants: the 16-tuple that is the argument list of
+fixed_effects_regression, input.py:608-620; load_var_block: (variants, variant_mat, eof), input.py:678-707) so existing
+callers keep working; `iter_packed_blocks` is the feed of the GPU driver: the same parsing, but presence goes straight
+into packed bit rows.  VCF input needs pysam (absent here) and is not supported.
+"""
+import binascii
+import gzip
+import hashlib
+import sys
+
+import numpy as np
+import pandas as pd
+
+from . import classes as var_obj
+from .packing import row_bytes_for
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# loaders (once per run)
+# ---------------------------------------------------------------------------------------------------------------
+def _read_indexed_table(path, what, **kw):
+    t = pd.read_csv(path, index_col=0, sep='\t', **kw)
+    t.index = t.index.astype(str)
+    if np.any(t.index.duplicated()):
+        sys.stderr.write('%s file contains duplicated sample names\n' % what)
+        sys.exit(1)
+    return t
+
+
+def load_phenotypes(infile, column):
+    """pandas.Series of phenotypes indexed by sample (input.py:24-59): last column unless `column` is named."""
+    p = pd.read_csv(infile, index_col=0, sep='\t')
+    if p.shape[1] < 1:
+        sys.stderr.write('Phenotype file must contain at least one phenotype column\n')
+        sys.exit(1)
+    p.index = p.index.astype(str)
+    if np.any(p.index.duplicated()):
+        sys.stderr.write('Phenotype file contains duplicated sample names\n')
+        sys.exit(1)
+    p = (p[p.columns[-1]] if column is None else p[column]).dropna()
+    if not pd.api.types.is_numeric_dtype(p.values.dtype):
+        sys.stderr.write('Phenotypes must be numeric\n')
+        sys.exit(1)
+    return p
+
+
+def cmdscale(D):
+    """Classical MDS (cmdscale.py:15-54): double-centre the squared distances, keep positive-eigenvalue axes."""
+    D = np.asarray(D, dtype=float)
+    n = D.shape[0]
+    H = np.eye(n) - np.ones((n, n)) / n
+    B = -H.dot(D ** 2).dot(H) / 2
+    evals, evecs = np.linalg.eigh(B)
+    order = np.argsort(evals)[::-1]
+    evals, evecs = evals[order], evecs[:, order]
+    pos = evals > 0
+    return evecs[:, pos] * np.sqrt(evals[pos]), evals[pos]
+
+
+def load_structure(infile, p, max_dimensions, mds_type="classic", n_cpus=1, seed=None):
+    """Distance matrix -> MDS projection restricted to phenotyped samples, columns scaled by max-abs (input.py:62-137)."""
+    m = _read_indexed_table(infile, 'Structure')
+    sys.stderr.write("Structure matrix has dimension " + str(m.shape) + "\n")
+    keep = p.index.intersection(m.index).intersection(m.columns)
+    m = m.loc[keep, keep]
+    if len(keep) == 0:
+        sys.stderr.write('None of the phenotyped samples were found in population structure matrix\n')
+        sys.exit(1)
+    if mds_type == "classic":
+        projection, _ = cmdscale(m.values)
+    else:
+        from sklearn import manifold
+        metric = mds_type != "non-metric"
+        if mds_type not in ("metric", "non-metric"):
+            sys.stderr.write("Unsupported mds type chosen. Assuming metric\n")
+        mds = manifold.MDS(n_components=max_dimensions, metric=metric, n_jobs=n_cpus, random_state=seed,
+                           dissimilarity='precomputed')
+        projection = mds.fit_transform(m.values)
+    m = pd.DataFrame(projection, index=m.index)
+    for i in range(m.shape[1]):
+        m[i] = m[i] / max(abs(m[i]))
+    return m
+
+
+def load_covariates(infile, covariates, p):
+    """Covariate table -> design columns: 'Nq' quantitative, 'N' categorical dummy-encoded (input.py:184-248)."""
+    c = _read_indexed_table(infile, 'Covariate', header=0)
+    if len(p.index.difference(c.index)) > 0:
+        sys.stderr.write("All samples with a phenotype must be present in covariate file\n")
+        sys.exit(1)
+    c = c.loc[p.index.intersection(c.index)]
+    if covariates is None:
+        return pd.DataFrame([])
+    cols = []
+    for col in covariates:
+        cnum = int(col.rstrip('q'))
+        if cnum == 1 or cnum > c.shape[1] + 1:
+            sys.stderr.write('Covariates columns values should be > 1 and less than or equal to total number of ' +
+                             'columns (%d)\n' % (c.shape[1] + 1))
+            return None
+        series = c.iloc[:, cnum - 2]
+        if col[-1] == 'q':
+            cols.append(series)
+        else:
+            categories = set(series)
+            categories.pop()                       # one level is the reference class (arbitrary, as in the reference)
+            for i, categ in enumerate(categories):
+                cols.append(pd.Series([1 if x == categ else 0 for x in series.values], index=c.index,
+                                      name=c.columns[cnum - 2] + "_" + str(i)))
+    return pd.concat(cols, axis=1) if cols else pd.DataFrame([])
+
+
+def open_variant_file(var_type, var_file, burden_file=None, burden_regions=None, uncompressed=False):
+    """(handle, sample_order) (input.py:268-299)."""
+    if var_type == "kmers":
+        return (open(var_file) if uncompressed else gzip.open(var_file, 'r')), []
+    if var_type == "Rtab":
+        fh = open(var_file)
+        header = fh.readline().rstrip()
+        return fh, [str(x) for x in header.split()[1:]]
+    raise ValueError('Variants type not supported (VCF input needs pysam, which this build does not ship)')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# per-variant parsing
+# ---------------------------------------------------------------------------------------------------------------
+def hash_pattern(k):
+    """base64(md5(raw bytes of the presence vector)) + newline; the dtype of k matters (input.py:710-723)."""
+    return binascii.b2a_base64(hashlib.md5(k.view(np.uint8)).digest())
+
+
+def read_variant(infile, p, var_type, burden, burden_regions, uncompressed, all_strains, sample_order,
+                 keep_list=None, noparse=False):
+    """(eof, k, var_name, kstrains, nkstrains, af, missing) for the next line (input.py:301-454)."""
+    if var_type not in ('kmers', 'Rtab'):
+        raise ValueError('Variants type not supported')
+    line = infile.readline()
+    if not line or noparse:
+        return True, None, None, None, None, None, None
+    d = {}
+    if var_type == "kmers":
+        if not uncompressed:
+            line = line.decode()
+        var_name = line.split()[0]
+        strains = line.rstrip().split('|')[1].lstrip().split()
+        if keep_list is not None and var_name not in keep_list:
+            return False, None, None, None, None, None, None
+        d = {str(x.split(':')[0]): 1 for x in strains}
+    else:
+        try:
+            fields = line.rstrip().split('\t')
+        except TypeError:
+            fields = line.decode().rstrip().split('\t')
+        var_name, calls = fields[0], fields[1:]
+        if keep_list is not None and var_name not in keep_list:
+            return False, None, None, None, None, None, None
+        if len(calls) == 0:
+            raise ValueError('No sample data found; is this a Rtab file?')
+        if len(calls) != len(sample_order):
+            raise ValueError('Unexpected mismatch between header and data row')
+        for present, sample in zip(calls, sample_order):
+            if present not in ('0', '1', '.', ''):
+                raise ValueError('Rtab file not binary')
+            if present == '1':
+                d[sample] = 1
+            elif present in ('.', ''):
+                d[sample] = np.nan
+    kstrains = sorted(set(d.keys()).intersection(all_strains))        # missing calls count as present here
+    nkstrains = sorted(all_strains.difference(set(kstrains)))
+    for x in nkstrains:
+        d[x] = 0
+    af = float(len(kstrains)) / len(all_strains)
+    if len(kstrains) == 0:
+        sys.stderr.write("No observations of " + var_name + " in selected samples\n")
+    k = np.array([d[x] for x in p.index if x in d])
+    missing = float(np.sum(np.isnan(k))) / len(all_strains)
+    return False, k, var_name, kstrains, nkstrains, af, missing
+
+
+def iter_variants(p, m, cov, var_type, burden, burden_regions, infile, all_strains, sample_order, lineage_effects,
+                  lineage_clusters, min_af, max_af, max_missing, filter_pvalue, lrt_pvalue, null_fit, firth_null,
+                  uncompressed, continuous):
+    """Generator of fixed_effects_regression argument tuples (input.py:505-620); p slot is None for AF/missing-filtered."""
+    while True:
+        eof, k, var_name, kstrains, nkstrains, af, missing = read_variant(infile, p, var_type, burden, burden_regions,
+                                                                          uncompressed, all_strains, sample_order)
+        if eof:
+            return
+        pattern = hash_pattern(k) if k is not None else None
+        keep = (k is not None) and (min_af <= af <= max_af) and not (missing > max_missing)
+        yield (var_name, p.values if keep else None, k, m, cov.values, af, pattern, lineage_effects, lineage_clusters,
+               filter_pvalue, lrt_pvalue, null_fit, firth_null, kstrains, nkstrains, continuous)
+
+
+def load_var_block(var_type, p, burden, burden_regions, infile, all_strains, sample_order, min_af, max_af, max_missing,
+                   uncompressed, block_size):
+    """Generator of (variants, variant_mat, eof) blocks for the LMM (input.py:638-707)."""
+    while True:
+        variants = []
+        variant_mat = np.zeros((len(p), block_size))
+        eof = False
+        for var_idx in range(block_size):
+            eof, k, var_name, kstrains, nkstrains, af, missing = read_variant(infile, p, var_type, burden, burden_regions,
+                                                                              uncompressed, all_strains, sample_order)
+            if eof:
+                break
+            if k is None or af < min_af or af > max_af or missing > max_missing:
+                pattern = None
+            else:
+                pattern = hash_pattern(k)
+                variant_mat[:, var_idx] = k
+            variants.append((var_obj.LMM(var_name, pattern, af, np.nan, np.nan, np.nan, np.nan, np.nan, np.nan, kstrains,
+                                         nkstrains, set(), True, True), p.values, k))
+        yield (variants, variant_mat, eof)
+        if eof:
+            break
+    yield None, None, True
+
+
+def iter_variants_lmm(variant_iter, lmm, h2, lineage, lineage_clusters, covariates, continuous, filter_pvalue, lrt_pvalue):
+    """input.py:623-635"""
+    for variants, variant_mat, eof in variant_iter:
+        if len(variants) == 0:
+            break
+        yield (lmm, h2, variants, variant_mat, lineage, lineage_clusters, covariates, continuous, filter_pvalue, lrt_pvalue)
+        if eof:
+            break
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU feed
+# ---------------------------------------------------------------------------------------------------------------
+class PackedBlock(object):
+    """One block of parsed variants: metadata lists + packed presence rows for those that reach the engine."""
+    __slots__ = ("names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks")
+
+    def __init__(self, n_samples, capacity):
+        self.names, self.patterns, self.afs, self.kstrains, self.nkstrains = [], [], [], [], []
+        self.status = []            # 0 = to engine, 1 = af/missing filtered, 2 = carries missing calls (NaN in k)
+        self.ks = []                # the dense k only for status 2 (host-side handling of the error path)
+        self.row_of = []            # row in self.bits, or -1
+        self.bits = np.zeros((capacity, row_bytes_for(n_samples)), dtype=np.uint8)
+
+
+def iter_packed_blocks(p, var_type, infile, all_strains, sample_order, min_af, max_af, max_missing, uncompressed,
+                       block_size, want_patterns=True):
+    """Parse `block_size` variants at a time into a PackedBlock (same filters as iter_variants / load_var_block)."""
+    n = len(p)
+    while True:
+        blk = PackedBlock(n, block_size)
+        nrow = 0
+        eof = False
+        for _ in range(block_size):
+            eof, k, name, ks, nks, af, missing = read_variant(infile, p, var_type, False, None, uncompressed, all_strains,
+                                                              sample_order)
+            if eof:
+                break
+            blk.names.append(name); blk.afs.append(af); blk.kstrains.append(ks); blk.nkstrains.append(nks)
+            if k is None or not (min_af <= af <= max_af) or missing > max_missing:
+                blk.patterns.append(hash_pattern(k) if k is not None else None)
+                blk.status.append(1); blk.row_of.append(-1); blk.ks.append(None)
+                continue
+            blk.patterns.append(hash_pattern(k) if want_patterns else b'')
+            if missing > 0:
+                blk.status.append(2); blk.row_of.append(-1); blk.ks.append(k)
+                continue
+            packed = np.packbits(k.astype(bool), bitorder="little")
+            blk.bits[nrow, :packed.shape[0]] = packed
+            blk.status.append(0); blk.row_of.append(nrow); blk.ks.append(None)
+            nrow += 1
+        blk.bits = blk.bits[:nrow]
+        if blk.names:
+            yield blk
+        if eof:
+            return

@@ -114,3 +114,62 @@ def initialise_lmm_arrays(K, y, covar=None, use_gpu=False):
     U, S = spectral_decomposition(K, C, use_gpu=use_gpu)
     h2, nll = find_h2(U, S, y, C)
     return U, S, h2, nll, C
+
+
+class LmmState(object):
+    """What the per-variant path needs from the reference's fastlmm LMM object: U, S, Y (phenotype column), X (covariates
+    with the intercept LAST).  Attribute names follow pyseer/fastlmm/lmm_cov.py so cache files and call sites carry over."""
+    __slots__ = ("U", "S", "Y", "X")
+
+    def __init__(self, U, S, Y, X):
+        self.U, self.S, self.Y, self.X = U, S, Y, X
+
+
+def initialise_lmm(p, cov, K_in, lmm_cache_in=None, lmm_cache_out=None, lineage_samples=None, use_gpu=False):
+    """pyseer/lmm.py:26-122: returns (p restricted to the samples of the similarity matrix, LmmState, h2).
+    Reads / writes the reference's cache layout (np.savez: arr_0 = U, arr_1 = S, arr_2 = [h2])."""
+    import os
+    import sys
+    import math
+    import pandas as pd
+
+    def covariates_for(pp):
+        if len(pp.index.intersection(cov.index)) == pp.shape[0]:
+            return np.c_[cov.loc[pp.index].values, np.ones((pp.shape[0], 1))]
+        if (cov.shape[0] == 0 and cov.shape[1] == 0) or len(cov.shape) == 0:
+            return np.ones((pp.shape[0], 1))
+        sys.stderr.write("Phenotype and covariate file should have matching samples for LMM\n")
+        sys.exit(1)
+
+    if lmm_cache_in is not None and os.path.exists(lmm_cache_in):
+        covar = covariates_for(p)
+        with np.load(lmm_cache_in) as data:
+            U, S, h2 = data['arr_0'], data['arr_1'], float(data['arr_2'][0])
+        if U.shape[0] != len(p):
+            sys.stderr.write("Phenotype different length from cache file\n")
+            sys.exit(1)
+        return p, LmmState(np.ascontiguousarray(U), S, p.values.astype(float), covar), h2
+
+    K = pd.read_csv(K_in, index_col=0, sep='\t')
+    K.index = K.index.astype(str)
+    sys.stderr.write("Similarity matrix has dimension " + str(K.shape) + "\n")
+    if lineage_samples is not None and set(K.index) != set(lineage_samples):
+        sys.stderr.write("Lineage file and similarity matrix contain different sets of samples\n")
+        sys.exit(1)
+    inter = p.index.intersection(K.index)
+    sys.stderr.write("Analysing " + str(len(inter)) + " samples found in both phenotype and similarity matrix\n")
+    p = p.loc[inter]
+    K = K.loc[p.index, p.index]
+    covar = covariates_for(p)
+    factor = float(len(p)) / np.diag(K.values).sum()
+    if factor == math.inf:
+        sys.stderr.write("Invalid similarity matrix. Did you use --calc-C?\n")
+        sys.exit(1)
+    Kv = K.values.astype(float)
+    if abs(factor - 1.0) > 1e-15:
+        Kv = Kv * factor
+    U, S = spectral_decomposition(Kv, covar, use_gpu=use_gpu)
+    h2, _ = find_h2(U, S, p.values.astype(float), covar)
+    if lmm_cache_out is not None and not os.path.exists(lmm_cache_out):
+        np.savez(lmm_cache_out, U, S, np.array([h2]))
+    return p, LmmState(U, S, p.values.astype(float), covar), h2
