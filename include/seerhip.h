@@ -106,6 +106,15 @@ int sh_glm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
 /* d_out: (5+q)*V doubles SoA: prep,pvalue,kbeta,bse,intercept,betas[0..q) ; d_flags: V */
 int sh_glm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 
+/* ---------------------------------------------------------------------------------------------
+ * Lineage effect (replaces pyseer/model.py:151 fit_lineage_effect): logistic regression of each VARIANT on
+ * [1, lin, cov]; lin: n x l row-major (MDS components or cluster indicators, pyseer/__main__.py:417-432), cov: n x j
+ * (or NULL, j = 0).  max_lineage[v] = argmax_j |beta_j|/bse_j over the l lineage columns, -1 = None (separation or
+ * singular, model.py:193-197).  1 + l + j <= 16 in this build.
+ * ------------------------------------------------------------------------------------------- */
+int sh_lineage_setup(sh_ctx *ctx, const double *lin, int l, const double *cov, int j);
+int sh_lineage_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V, int32_t *max_lineage);
+
 /* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */
 int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);
 

@@ -179,3 +179,13 @@ class LmmOracle(object):
             raise AssertionError("length of LMM result does not match number of variants")
         return dict(prep=rows[:, 0], pvalue=rows[:, 1], kbeta=rows[:, 2], bse=rows[:, 3], frac_h2=rows[:, 4],
                     notes=notes, prefilter=pf, filter=fl)
+
+
+def lineage_effect(lin, cov, k):
+    """fit_lineage_effect (model.py:151-199): index of the most significant lineage or None."""
+    lin = _d(lin); n, l = lin.shape
+    k = _d(k)
+    j = 0 if cov is None or np.size(cov) == 0 else np.asarray(cov).reshape(n, -1).shape[1]
+    c = _d(np.asarray(cov).reshape(n, -1)) if j else np.zeros(1)
+    r = lib().orc_lineage_effect(_p(lin), l, _p(c), j, _p(k), n)
+    return None if r < 0 else int(r)

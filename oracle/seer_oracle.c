@@ -733,4 +733,27 @@ ORC_API void orc_firth_batch(const double *y, const double *Kv, const double *Z,
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * a6: fit_lineage_effect (pyseer/model.py:151-199): Logit(k ~ [1, lin, c]).fit(newton) with the default zero start;
+ * returns argmax over the lineage columns of |params|/bse, or -1 (None) on PerfectSeparationError / LinAlgError.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_lineage_effect(const double *lin, int l, const double *cov, int j, const double *k, int n)
+{
+    int pc = 1 + l + j;
+    double *X = (double *)malloc(sizeof(double) * (size_t)n * pc);
+    for (int i = 0; i < n; i++) {
+        X[(size_t)i * pc] = 1.0;
+        for (int a = 0; a < l; a++) X[(size_t)i * pc + 1 + a] = lin[(size_t)i * l + a];
+        for (int a = 0; a < j; a++) X[(size_t)i * pc + 1 + l + a] = cov[(size_t)i * j + a];
+    }
+    double start[64], beta[64], bse[64], llf; int iters;
+    for (int a = 0; a < pc; a++) start[a] = 0;
+    int st = orc_logit_newton(X, k, n, pc, start, 1, beta, bse, &llf, &iters);
+    free(X);
+    if (st) return -1;
+    int best = 0; double bw = fabs(beta[1]) / bse[1];
+    for (int a = 1; a < l; a++) { double w = fabs(beta[1 + a]) / bse[1 + a]; if (w > bw) { bw = w; best = a; } }
+    return best;
+}
+
 ORC_API int orc_abi_version(void) { return 1; }

@@ -7,7 +7,9 @@ end-of-run counters.  Variants are parsed in blocks of --block_size, packed, and
 printed in the reference's order (fixed effects: input order; LMM: within a block the filtered variants first, then the
 tested ones -- fit_lmm returns them that way, lmm.py:160-224).
 
-Not supported (out of scope or not built yet): --vcf/--burden (pysam), --wg (enet/rf), --lineage.
+--lineage (MDS components or --lineage-clusters) runs fit_lineage_effect on the GPU as well (1 + lineages + covariates <= 16).
+
+Not supported (out of scope): --vcf/--burden (pysam), --wg (enet/rf).
 """
 import argparse
 import os
@@ -19,7 +21,8 @@ import pandas as pd
 
 from . import __version__
 from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
-from .input import (load_phenotypes, load_structure, load_covariates, open_variant_file, iter_packed_blocks)
+from .input import (load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
+                    iter_packed_blocks)
 from .lmm import initialise_lmm, mask_like_fit_lmm
 from .model import fit_null, covariate_block
 from .utils import format_output
@@ -53,9 +56,9 @@ def get_options(argv=None):
     asc.add_argument('--continuous', action='store_true', default=False, help='Force continuous phenotype')
     asc.add_argument('--lmm', action='store_true', default=False, help='Use random instead of fixed effects')
     asc.add_argument('--wg', default=None, help='(not supported by this build)')
-    asc.add_argument('--lineage', action='store_true', help='(not supported by this build)')
-    asc.add_argument('--lineage-clusters', help='(not supported by this build)')
-    asc.add_argument('--lineage-file', default="lineage_effects.txt")
+    asc.add_argument('--lineage', action='store_true', help='Report lineage effects')
+    asc.add_argument('--lineage-clusters', help='Custom clusters to use as lineages [Default: MDS components]')
+    asc.add_argument('--lineage-file', default="lineage_effects.txt", help='File to write lineage association to')
     fi = parser.add_argument_group('Filtering options')
     fi.add_argument('--min-af', type=float, default=0.01, help='Minimum AF [Default: 0.01]')
     fi.add_argument('--max-af', type=float, default=0.99, help='Maximum AF [Default: 0.99]')
@@ -103,21 +106,23 @@ def main(argv=None):
         _die('VCF / burden input needs pysam and is not supported by pyseer_amd\n')
     if options.wg:
         _die('Whole-genome models (--wg) are out of scope for pyseer_amd\n')
-    if options.lineage or options.lineage_clusters:
-        _die('Lineage effects (--lineage) are not built in this round of pyseer_amd\n')
     if options.max_dimensions < 1:
         _die('Minimum number of dimensions after MDS is 1\n')
     if options.lmm and not options.similarity and not options.load_lmm:
         _die('Must provide a similarity matrix or lmm cache for random effects\n')
     if not options.no_distances:
-        if (options.lmm and (options.distances or options.load_m)) or (not options.lmm and (options.similarity or options.load_lmm)):
+        if (options.lmm and (options.distances or options.load_m) and not options.lineage) or (not options.lmm and (options.similarity or options.load_lmm)):
             sys.stderr.write('Must use distance matrix with fixed effects, or similarity matrix with random effects\n')
             _die('Unless performing a lineage analysis with random effects\n')
+        if options.lmm and not (options.distances or options.load_m) and options.lineage:
+            _die('Must also provide a distance matrix to report lineage effects\n')
         if not options.lmm and not options.distances and not options.load_m:
             _die('Option --no-distances must be used when no distance matrix is provided\n')
     else:
         if options.distances or options.load_m:
             _die('Cannot use --no-distances with --distances or --load-m\n')
+        if not options.lmm and not options.lineage_clusters and options.lineage:
+            _die('Must provide a lineage clusters file when --no-distances and --lineage are used together in fixed-effects mode\n')
         if options.lmm:
             _die('Cannot use --no-distances with --lmm\n')
     if options.block_size < 1:
@@ -142,7 +147,7 @@ def main(argv=None):
 
     m = np.empty(shape=(0, 0))
     null_fit = firth_null = None
-    if not options.lmm:
+    if (options.lineage and not options.lineage_clusters) or not options.lmm:
         if not options.no_distances:
             if options.load_m and os.path.isfile(options.load_m):
                 mdf = pd.read_pickle(options.load_m)
@@ -164,9 +169,39 @@ def main(argv=None):
         if cov.shape[1] > 0:
             cov = cov.loc[p.index]
         null_fit = fit_null(p.values, m, cov, options.continuous)
-        firth_null = fit_null(p.values, m, cov, options.continuous, True) if not options.continuous else True
+        firth_null = fit_null(p.values, m, cov, options.continuous, True) if not (options.continuous or options.lmm) else True
         if null_fit is None or firth_null is None:
             _die('Could not fit null model, exiting\n')
+
+    # lineage effects (pyseer/__main__.py:388-444)
+    lineage_clusters = None
+    lineage_dict = None
+    if options.lineage_clusters:
+        lineage_clusters, lineage_dict = load_lineage(options.lineage_clusters, p)
+    if options.lineage:
+        from scipy.stats import norm
+        lineage_wald = {}
+        if options.lineage_clusters:
+            # one-hot clusters are not full rank: drop the cluster least associated with the phenotype
+            for lineage, design in zip(lineage_dict, lineage_clusters.T):
+                lf = fit_null(p.values, design.reshape(-1, 1).astype(float), cov, options.continuous)
+                if lf is None:
+                    _die('Could not fit lineage null model, exiting\n')
+                lineage_wald[lineage] = np.absolute(lf.params[1]) / lf.bse[1]
+            min_lineage = min(lineage_wald.items(), key=lambda kv: kv[1])[0]
+            drop = lineage_dict.index(min_lineage)
+            lineage_clusters = np.delete(lineage_clusters, drop, 1)
+            del lineage_dict[drop]
+        else:
+            lineage_dict = ["MDS" + str(i + 1) for i in range(options.max_dimensions)]
+            lineage_clusters = m
+            for lineage, slope, se in zip(lineage_dict, null_fit.params[1:], null_fit.bse[1:]):
+                lineage_wald[lineage] = np.absolute(slope) / se
+        sys.stderr.write('Writing lineage effects to %s\n' % options.lineage_file)
+        with open(options.lineage_file, 'w') as lineage_out:
+            lineage_out.write("\t".join(["lineage", "wald_test", "p-value"]) + "\n")
+            for lineage, wald in sorted(lineage_wald.items(), key=lambda kv: kv[1], reverse=True):
+                lineage_out.write("\t".join([lineage, str(wald), str(2 * (1 - norm.cdf(wald)))]) + "\n")
 
     from .engine import Engine
     if options.lmm:
@@ -180,6 +215,11 @@ def main(argv=None):
         eng.glm_setup(p.values, covariate_block(len(p), m, cov), options.continuous,
                       np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
                       options.filter_pvalue, options.lrt_pvalue)
+
+    if options.lineage:
+        eng.lineage_setup(np.asarray(lineage_clusters, dtype=float), cov.values if cov.shape[1] > 0 else None)
+    if not options.lineage:
+        lineage_dict = None
 
     all_strains = set(p.index)
     var_type, var_file = ("kmers", options.kmers) if options.kmers else ("Rtab", options.pres)
@@ -195,6 +235,8 @@ def main(argv=None):
             header += [x for x in cov.columns]
     else:
         header.append('variant_h2')
+    if options.lineage:
+        header.append('lineage')
     if options.print_samples:
         header += ['k-samples', 'nk-samples']
     header.append('notes')
@@ -212,7 +254,7 @@ def main(argv=None):
             prefilter += 1
             if options.print_filtered:
                 printed += 1
-                out.write(format_output(x, None, model, options.print_samples) + "\n")
+                out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
             return
         tested += 1
         if patterns is not None:
@@ -220,7 +262,7 @@ def main(argv=None):
         if x.filter and not options.print_filtered:
             return
         printed += 1
-        out.write(format_output(x, None, model, options.print_samples) + "\n")
+        out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
 
     for blk in iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
                                   options.max_missing, options.uncompressed, options.block_size):
@@ -268,6 +310,15 @@ def main(argv=None):
                 betas = r["betas"][j] if (tested_ok and r["betas"].shape[1]) else np.array([])
                 rows.append(Seer(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["kbeta"][j], r["bse"][j],
                                  r["intercept"][j], betas, None, ks, nks, notes, pf, ft))
+        if options.lineage:
+            # fit_lineage_effect: fixed effects -> every variant that reached the fit (model.py:379-382; firth-fail and
+            # missing-data return earlier); LMM -> only variants that pass the LRT filter (lmm.py:209-213)
+            need = [i for i, x in enumerate(rows) if blk.status[i] == 0 and not x.prefilter and
+                    ((not x.filter) if options.lmm else ('firth-fail' not in x.notes))]
+            if need:
+                ml = eng.lineage_batch(blk.bits[[blk.row_of[i] for i in need]])
+                for i, v in zip(need, ml):
+                    rows[i] = rows[i]._replace(max_lineage=(None if v < 0 else int(v)))
         if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
             rows = [x for x in rows if x.prefilter] + [x for x in rows if not x.prefilter]
         for x in rows:

@@ -131,6 +131,25 @@ class Engine(object):
                                               _dp(o[2]), _dp(o[3]), _dp(o[4]), _dp(betas), fl.ctypes.data_as(_abi.c_u32p)))
         return dict(prep=o[0], pvalue=o[1], kbeta=o[2], bse=o[3], intercept=o[4], betas=betas[:, :q], flags=fl)
 
+    # ---- lineage effect ------------------------------------------------------------------------
+    def lineage_setup(self, lin, cov=None):
+        """lin (n, l): MDS components or cluster indicators; cov (n, j) or None (model.py:151-199)."""
+        lin = np.ascontiguousarray(np.asarray(lin, dtype=np.float64).reshape(self.n, -1))
+        j = 0
+        covp = None
+        if cov is not None and np.size(cov) and np.asarray(cov).shape[0] == self.n:
+            cov = np.ascontiguousarray(np.asarray(cov, dtype=np.float64).reshape(self.n, -1)); j = cov.shape[1]; covp = _dp(cov)
+        _abi.check(self._lib.sh_lineage_setup(self._h, _dp(lin), lin.shape[1], covp, j))
+
+    def lineage_batch(self, bits):
+        """-> int array of max-lineage indices, -1 where the reference returns None."""
+        bits = self._bits(bits)
+        out = np.full(bits.shape[0], -1, dtype=np.int32)
+        if bits.shape[0]:
+            _abi.check(self._lib.sh_lineage_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], bits.shape[0],
+                                                  out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
     def glm_info(self):
         a = C.c_int64(); b = C.c_int64()
         _abi.check(self._lib.sh_glm_info(self._h, C.byref(a), C.byref(b)))

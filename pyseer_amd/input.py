@@ -112,6 +112,23 @@ def load_covariates(infile, covariates, p):
     return pd.concat(cols, axis=1) if cols else pd.DataFrame([])
 
 
+def load_lineage(infile, p):
+    """Cluster file (sample<ws>cluster) -> (n x clusters 0/1 matrix, sorted labels) (input.py:140-181)."""
+    names, labels = [], []
+    for line in open(infile):
+        f = line.rstrip().split()
+        names.append(f[0]); labels.append(f[1])
+    lin = pd.Series(labels, index=pd.Index(names).astype(str))
+    lin = lin.loc[~lin.index.duplicated()]
+    if len(p.index.difference(lin.index)) > 0:
+        sys.stderr.write("All samples with a phenotype must be present in lineage file\n")
+        sys.exit(1)
+    lin = lin.loc[p.index.intersection(lin.index)]
+    lineages = sorted(set(lin.values))
+    mat = np.stack([(lin.values == c).astype(int) for c in lineages], axis=1)
+    return mat, lineages
+
+
 def open_variant_file(var_type, var_file, burden_file=None, burden_regions=None, uncompressed=False):
     """(handle, sample_order) (input.py:268-299)."""
     if var_type == "kmers":

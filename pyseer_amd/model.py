@@ -91,9 +91,10 @@ def fit_firth_host(X, y, start, step_limit=1000, convergence_limit=1e-4):
 class NullFit(object):
     """What the driver needs from statsmodels' results object: .llf (pyseer/__main__.py:449-450)."""
 
-    def __init__(self, llf, params):
+    def __init__(self, llf, params, bse=None):
         self.llf = llf
         self.params = params
+        self.bse = bse
 
 
 def null_design(p, m, cov):
@@ -115,7 +116,8 @@ def fit_null(p, m, cov, continuous, firth=False):
         beta, res, rank, sv = np.linalg.lstsq(v, p, rcond=None)
         ssr = float(np.sum((p - v.dot(beta)) ** 2)); n = p.shape[0]
         llf = -0.5 * n * (np.log(2 * np.pi) + np.log(ssr / n) + 1.0)
-        return NullFit(llf, beta)
+        bse = np.sqrt(np.diag(np.linalg.pinv(v.T.dot(v))) * ssr / (n - rank))
+        return NullFit(llf, beta, bse)
     start = np.zeros(v.shape[1])
     start[0] = np.log(np.mean(p) / (1 - np.mean(p)))
     if firth:
@@ -132,7 +134,7 @@ def fit_null(p, m, cov, continuous, firth=False):
     except PerfectSeparation:
         sys.stderr.write('Perfectly separable data error for null model\n')
         return None
-    return NullFit(llf, beta)
+    return NullFit(llf, beta, np.sqrt(np.diag(np.linalg.inv(_info(v, beta)))))
 
 
 # ---------------------------------------------------------------------------------------------------------------

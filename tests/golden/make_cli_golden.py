@@ -53,6 +53,10 @@ s = pd.read_csv(os.path.join(REF, "similarity.tsv.gz"), index_col=0, sep="\t"); 
 keep = p.index.intersection(s.index)
 s.loc[keep, keep].to_csv(os.path.join(CLI, "similarity50.tsv"), sep="\t")
 
+# lineage clusters for the phenotyped samples: 4 groups assigned round-robin along the sample order of the distance matrix
+with open(os.path.join(CLI, "clusters50.txt"), "w") as out:
+    for i, name in enumerate(sorted(_samples)):
+        out.write("%s\tBAPS_%d\n" % (name, 1 + (i * 7 % 11) % 4))
 K, P, D, S, C, R = "kmers.gz", "subset.pheno", "distances50.tsv", "similarity50.tsv", "covariates.txt", "kmers120.Rtab"
 CASES = {
     "fixed": ["--kmers", K, "--phenotypes", P, "--distances", D],
@@ -65,6 +69,9 @@ CASES = {
     "cont": ["--kmers", K, "--phenotypes", P, "--distances", D, "--max-dimensions", "3", "--phenotype-column", "continuous", "--print-filtered"],
     "cont_forced": ["--kmers", K, "--phenotypes", P, "--distances", D, "--max-dimensions", "3", "--continuous"],
     "rtab": ["--pres", R, "--phenotypes", P, "--distances", D, "--max-dimensions", "3", "--print-filtered"],
+    "fixed_lineage": ["--kmers", K, "--phenotypes", P, "--distances", D, "--max-dimensions", "3", "--lineage", "--lineage-file", "lineage_fixed.txt"],
+    "fixed_lineage_clusters": ["--kmers", K, "--phenotypes", P, "--distances", D, "--max-dimensions", "3", "--lineage", "--lineage-clusters", "clusters50.txt", "--lineage-file", "lineage_clusters.txt"],
+    "lmm_lineage": ["--kmers", K, "--phenotypes", P, "--similarity", S, "--lmm", "--lineage", "--distances", D, "--max-dimensions", "3", "--lineage-file", "lineage_lmm.txt"],
     "lmm": ["--kmers", K, "--phenotypes", P, "--similarity", S, "--lmm"],
     "lmm_all": ["--kmers", K, "--phenotypes", P, "--similarity", S, "--lmm", "--print-filtered", "--block_size", "50"],
     "lmm_cov": ["--kmers", K, "--phenotypes", P, "--similarity", S, "--lmm", "--covariates", C, "--use-covariates", "2q", "3"],
@@ -82,4 +89,7 @@ for name, args in CASES.items():
     open(os.path.join(EXP, name + ".log"), "wb").write(r.stdout)
     open(os.path.join(EXP, name + ".err"), "wb").write(r.stderr)
     print(name, len(r.stdout.splitlines()), "rows;", r.stderr.decode().strip().splitlines()[-4:])
+    if "--lineage-file" in args:
+        lf = args[args.index("--lineage-file") + 1]
+        shutil.move(os.path.join(CLI, lf), os.path.join(EXP, lf))
 json.dump(CASES, open(os.path.join(CLI, "cases.json"), "w"), indent=1)

@@ -421,8 +421,26 @@ def run_boundary():
     print("boundary:", len(items), "format cases,", len(hashes), "hashes")
 
 
+def run_lineage_case(name, seed, N, nl, j, V, clusters=False):
+    """fit_lineage_effect (model.py:151-199) over a block of variants."""
+    rng, lin_id, m, y = synth_design(seed, N, max(nl, 2), nlin=nl + 1 if clusters else 8)
+    if clusters:
+        lin = np.stack([(lin_id == c).astype(float) for c in range(nl + 1)], axis=1)[:, 1:]    # one cluster dropped (__main__.py:409-412)
+    else:
+        lin = m[:, :nl]
+    cov = rng.standard_normal((N, j)) if j else np.empty((0,))
+    K = synth_variants(rng, lin_id, y, m, V, nlin=nl + 1 if clusters else 8)
+    if clusters:
+        K[9] = lin[:, 0]                       # variant == a cluster indicator -> separation
+    out = np.array([-1 if (lambda r: r is None)(fit_lineage_effect(lin, cov, K[v])) else int(fit_lineage_effect(lin, cov, K[v]))
+                    for v in range(V)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), N=N, nl=nl, j=j, V=V, lin=lin, cov=cov if j else np.zeros((N, 0)),
+                        K=K.astype(np.uint8), max_lineage=out)
+    print(name, "None:", int((out < 0).sum()), "hist:", np.bincount(out[out >= 0], minlength=nl))
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["unit", "glm", "lmm", "boundary"]
+    what = sys.argv[1:] or ["unit", "glm", "lmm", "lineage", "boundary"]
     if "unit" in what:
         run_model_unit()
         run_lmm_unit()
@@ -442,5 +460,9 @@ if __name__ == "__main__":
         run_lmm_case("lmm_N300_D1", 32, 300, 1, 64, [0.0, 0.25, 0.5, 0.9])
         run_lmm_case("lmm_N300_D3", 33, 300, 3, 64, [0.0, 0.5, 0.9])
         run_lmm_case("lmm_N200_D2_cont", 34, 200, 2, 48, [0.3], continuous=True)
+    if "lineage" in what:
+        run_lineage_case("lineage_N200_l3", 41, 200, 3, 0, 48)
+        run_lineage_case("lineage_N300_l10_j2", 42, 300, 10, 2, 48)
+        run_lineage_case("lineage_N300_clusters5", 43, 300, 5, 0, 48, clusters=True)
     if "boundary" in what:
         run_boundary()

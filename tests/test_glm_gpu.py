@@ -7,6 +7,8 @@ import os
 
 import numpy as np
 import pytest
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -107,3 +109,17 @@ def test_fixed_effects_vs_oracle_random(N, q, V, cont):
         close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
     close(r["betas"][~firth], want["betas"][~firth], atol=1e-12, what="betas")
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "lineage_*.npz"))))
+def test_lineage_effect_golden(path):
+    """a6 fit_lineage_effect (model.py:151-199) through k_glm_lineage."""
+    from pyseer_amd.engine import Engine, pack_variants
+    d = np.load(path)
+    e = Engine(int(d["N"]))
+    e.lineage_setup(d["lin"], d["cov"] if int(d["j"]) else None)
+    got = e.lineage_batch(pack_variants(d["K"]))
+    e.close()
+    from test_oracle_golden import _same_or_tied
+    _same_or_tied([None if x < 0 else int(x) for x in got], [None if x < 0 else int(x) for x in d["max_lineage"]], d["lin"],
+                  d["cov"] if int(d["j"]) else None, d["K"])
