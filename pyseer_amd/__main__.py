@@ -76,6 +76,9 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--lmm-lineage-per-variant', action='store_true', default=False,
+                    help='With --lmm --lineage, fit the lineage effect of each variant itself. [Default: reproduce the reference, '
+                         'which fits the LAST variant of each block for every variant of that block]')
     ot.add_argument('--version', action='version', version='%(prog)s ' + __version__)
     return parser.parse_args(argv)
 
@@ -315,7 +318,18 @@ def main(argv=None):
             # missing-data return earlier); LMM -> only variants that pass the LRT filter (lmm.py:209-213)
             need = [i for i, x in enumerate(rows) if blk.status[i] == 0 and not x.prefilter and
                     ((not x.filter) if options.lmm else ('firth-fail' not in x.notes))]
-            if need:
+            if options.lmm and not options.lmm_lineage_per_variant:
+                # Reference behaviour (pyseer/lmm.py:209-213): inside fit_lmm's second loop `k` still holds the LAST variant
+                # unpacked by the first loop, so every passing variant of a block reports the lineage of that last variant.
+                kl = blk.last_k
+                ml = -1
+                if kl is not None and not np.isnan(np.asarray(kl, dtype=float)).any():
+                    from .packing import pack_variants
+                    ml = int(eng.lineage_batch(pack_variants(np.asarray(kl).reshape(1, -1)))[0])
+                for i, x in enumerate(rows):
+                    if not x.prefilter and not x.filter:
+                        rows[i] = x._replace(max_lineage=(None if ml < 0 else ml))
+            elif need:
                 ml = eng.lineage_batch(blk.bits[[blk.row_of[i] for i in need]])
                 for i, v in zip(need, ml):
                     rows[i] = rows[i]._replace(max_lineage=(None if v < 0 else int(v)))

@@ -726,9 +726,11 @@ __global__ __launch_bounds__(64) void k_glm_lineage(const uint64_t *__restrict__
             double det;
             if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }
             else if (fin) {
-                if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
+                // numpy.linalg.inv only fails on an EXACT zero pivot; a numerically rank-deficient Hessian (quasi-separation after
+                // 35 iterations) yields huge/NaN standard errors and the argmax simply moves on (np.argmax: first NaN wins).
+                if (!ldl_factor<PC>(H, 0.0, &det)) status = 2;
                 else {
-                    double bestw = -1.0;
+                    double bestw = -1.0; int first_nan = -1;
 #pragma unroll
                     for (int a = 1; a < PC; ++a) {
                         double e[PC];
@@ -736,8 +738,12 @@ __global__ __launch_bounds__(64) void k_glm_lineage(const uint64_t *__restrict__
                         for (int c = 0; c < PC; ++c) e[c] = (c == a) ? 1.0 : 0.0;
                         ldl_solve<PC>(H, e);
                         const double wald = fabs(beta[a]) / sqrt(e[a] / nobs);
-                        if (a <= nlin && (wald > bestw || (isnan(wald) && !isnan(bestw) && best < 0))) { bestw = wald; best = a - 1; }
+                        if (a <= nlin) {
+                            if (isnan(wald)) { if (first_nan < 0) first_nan = a - 1; }
+                            else if (wald > bestw) { bestw = wald; best = a - 1; }
+                        }
                     }
+                    if (first_nan >= 0) best = first_nan;
                 }
                 active = false;
             } else {

@@ -251,13 +251,14 @@ def iter_variants_lmm(variant_iter, lmm, h2, lineage, lineage_clusters, covariat
 # ---------------------------------------------------------------------------------------------------------------
 class PackedBlock(object):
     """One block of parsed variants: metadata lists + packed presence rows for those that reach the engine."""
-    __slots__ = ("names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks")
+    __slots__ = ("names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks", "last_k")
 
     def __init__(self, n_samples, capacity):
         self.names, self.patterns, self.afs, self.kstrains, self.nkstrains = [], [], [], [], []
         self.status = []            # 0 = to engine, 1 = af/missing filtered, 2 = carries missing calls (NaN in k)
         self.ks = []                # the dense k only for status 2 (host-side handling of the error path)
         self.row_of = []            # row in self.bits, or -1
+        self.last_k = None          # dense k of the LAST variant parsed into the block (see __main__: lmm.py:209-213)
         self.bits = np.zeros((capacity, row_bytes_for(n_samples)), dtype=np.uint8)
 
 
@@ -275,6 +276,7 @@ def iter_packed_blocks(p, var_type, infile, all_strains, sample_order, min_af, m
             if eof:
                 break
             blk.names.append(name); blk.afs.append(af); blk.kstrains.append(ks); blk.nkstrains.append(nks)
+            blk.last_k = k
             if k is None or not (min_af <= af <= max_af) or missing > max_missing:
                 blk.patterns.append(hash_pattern(k) if k is not None else None)
                 blk.status.append(1); blk.row_of.append(-1); blk.ks.append(None)
