@@ -25,6 +25,7 @@ struct GlmParams {
     double yc_sum, yc_sq;         // centred-phenotype sums (Welch prefilter)
     double null_llf, null_firth, pret, lrtt;
     double min_af, max_af; int af_on;
+    int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
 };
 
 // ---- LDL^T of a packed symmetric P x P matrix, in place (no pivoting; tolerates indefinite matrices) ----------------
@@ -162,28 +163,88 @@ __device__ __forceinline__ double glm_prefilter(const uint64_t *__restrict__ T, 
 
 // =====================================================================================================================
 // Logistic Newton (binary phenotype) -- one variant per lane
+//
+// Three phases per wavefront, all following statsmodels' Newton (start vector, ridge, |d beta|_inf <= 1e-8, 35 iterations,
+// separation callback after every update):
+//  A. fast iterations: score and mu in fp64 (the fixed point of the iteration is the exact MLE), the Hessian accumulated in
+//     fp32 (77 accumulators in 77 VGPRs instead of 154; fp32 FMAs at twice the fp64 rate).  An inexact Hessian only changes the
+//     path, not the limit: with X^T W X good to ~1e-5 the error contracts by ~1e-5 per step once inside the quadratic basin, and
+//     the stopping rule is the reference's.  A lane leaves phase A as "converged" only if it converges within 12 iterations with
+//     healthy pivots and no separation signal;
+//  B. anything else (separation, divergence, ill-conditioning, slow convergence) is RESTARTED from the start vector with the
+//     all-fp64 iteration, which reproduces the reference's trajectory and therefore its notes (matrix-inversion-error vs
+//     perfectly-separable-data vs high-bse are decided by that trajectory);
+//  C. one fp64 pass at the final beta for llf, the separation check and bse[1] = sqrt((X^T W X)^-1_11) (no ridge).
 // =====================================================================================================================
 template <int Q>
-__global__ __launch_bounds__(64) void k_glm_logit(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
-                                                  const double *__restrict__ y, const double *__restrict__ W,
-                                                  const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
-                                                  const double *__restrict__ yc, GlmParams P,
-                                                  double *__restrict__ out, uint32_t *__restrict__ flags,
-                                                  int *__restrict__ firth_list, int *__restrict__ firth_count)
+__device__ __forceinline__ void fast_pass(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
+                                          const double *__restrict__ y, const double *__restrict__ W,
+                                          const float *__restrict__ Wf, const double (&beta)[Q + 2],
+                                          float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], double &maxdev)
+{
+    constexpr int P = Q + 2;
+#pragma unroll
+    for (int a = 0; a < P * (P + 1) / 2; ++a) H[a] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < P; ++a) g[a] = 0.0;
+    maxdev = 0.0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            const bool xb = (w64 >> b) & 1ull;
+            const double xd = xb ? 1.0 : 0.0;
+            double eta = fma(beta[1], xd, beta[0]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], W[(int64_t)i * Q + j], eta);
+            const double mu = 1.0 / (1.0 + exp(-eta));
+            const double r = y[i] - mu;
+            maxdev = fmax(maxdev, fabs(r));
+            g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, W[(int64_t)i * Q + j], g[2 + j]);
+            const float wf = (float)(mu * (1.0 - mu));
+            const float wx = xb ? wf : 0.0f;
+            H[sidx(0, 0)] += wf;
+            H[sidx(1, 0)] += wx;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const float zj = Wf[(int64_t)i * Q + j];
+                const float wz = wf * zj;
+                H[sidx(2 + j, 0)] += wz;
+                H[sidx(2 + j, 1)] = fmaf(wx, zj, H[sidx(2 + j, 1)]);
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = fmaf(wz, Wf[(int64_t)i * Q + k], H[sidx(2 + j, 2 + k)]);
+            }
+        }
+    }
+    H[sidx(1, 1)] = H[sidx(1, 0)];
+}
+
+// beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
+struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; };
+
+// ---- kernel 1: a1 prefilter + routing + phase A (fast Newton) ---------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(64, 2) void k_glm_fast(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                 const double *__restrict__ y, const double *__restrict__ W,
+                                                 const float *__restrict__ Wf,
+                                                 const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                 const double *__restrict__ yc, GlmParams P, GlmWork wk,
+                                                 double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                 int *__restrict__ firth_list, int *__restrict__ firth_count)
 {
     constexpr int PC = Q + 2;
     const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool live = v < V;
     const int64_t vr = live ? v : 0;           // dead lanes shadow variant 0 and never write
     const int N = P.N, NB64 = P.NB64;
+    const double nobs = (double)N;
     uint32_t fl = 0;
-    double prep = NAN, pval = NAN, kbeta = NAN, kbse = NAN, icpt = NAN;
-    double beta[PC];
-#pragma unroll
-    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
-    bool want_fit = live, to_firth = false;
-    bool bad = false; int m = 0;
-    prep = glm_prefilter(T, Vpad, vr, NB64, N, y1, y0, yc, P, &bad, &m);
+    bool want_fit = live, to_firth = false, bad = false;
+    int m = 0;
+    double prep = glm_prefilter(T, Vpad, vr, NB64, N, y1, y0, yc, P, &bad, &m);
     if (P.af_on) {
         const double af = (double)m / (double)N;
         if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; want_fit = false; prep = NAN; }
@@ -194,33 +255,81 @@ __global__ __launch_bounds__(64) void k_glm_logit(const uint64_t *__restrict__ T
     }
     if (want_fit && (bad || P.force_firth)) { to_firth = true; want_fit = false; }
 
-    // ---- statsmodels Newton: all lanes of the wave iterate together; finished lanes idle
+    double beta[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
     beta[0] = P.ymean_logit;
-    int it = 0; bool fin = false, active = want_fit;
-    int status = 0;                     // 0 ok, 1 separation, 2 linalg
-    double llf = NAN, bse1 = NAN;
+    bool need_slow = want_fit && (P.newton_mode == 1);
+    bool active = want_fit && !need_slow;
+    int it = 0;
+    while (__any(active)) {
+        if (active) {
+            float Hf[PC * (PC + 1) / 2];
+            double g[PC], maxdev;
+            fast_pass<Q>(T, Vpad, vr, N, NB64, y, W, Wf, beta, Hf, g, maxdev);
+            if (it > 0 && maxdev <= 1e-8) { need_slow = true; active = false; }
+            else {
+                double A[PC * (PC + 1) / 2];
+#pragma unroll
+                for (int a = 0; a < PC * (PC + 1) / 2; ++a) A[a] = (double)Hf[a] / nobs;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) { A[sidx(a, a)] -= 1e-10; g[a] = g[a] / nobs; }
+                double det;
+                if (!ldl_factor<PC>(A, 1e-4, &det)) { need_slow = true; active = false; }          // fp32 cannot resolve this design
+                else {
+                    ldl_solve<PC>(A, g);
+                    bool moving = false, finite = true;
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); finite = finite && isfinite(beta[a]); }
+                    ++it;
+                    if (!finite) { need_slow = true; active = false; }
+                    else if (!moving) active = false;                                               // converged
+                    else if (it >= 12) { need_slow = true; active = false; }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    out[v] = prep; out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
+    flags[v] = fl;
+    wk.state[v] = (want_fit && !need_slow) ? 1 : 0;
+    if (want_fit && !need_slow) {
+#pragma unroll
+        for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
+    }
+    if (need_slow) { const int slot = atomicAdd(wk.slow_count, 1); wk.slow_list[slot] = (int)v; }
+    if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
+}
+
+// ---- kernel 2: phase B, the reference's all-fp64 iteration restarted for the listed variants -------------------------------
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_slow(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                 const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                 GlmWork wk, uint32_t *__restrict__ flags,
+                                                 int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    constexpr int PC = Q + 2;
+    const int cnt = *wk.slow_count;
+    if ((int64_t)blockIdx.x * 64 >= cnt) return;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const bool live = slot < cnt;
+    const int64_t v = wk.slow_list[live ? slot : 0];
+    const int N = P.N, NB64 = P.NB64;
     const double nobs = (double)N;
+    double beta[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
+    beta[0] = P.ymean_logit;
+    int it = 0, status = 0;
+    bool active = live;
     while (__any(active)) {
         if (active) {
             double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
-            info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev, __any(fin));
-            if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }                  // _check_perfect_pred
-            else if (fin) {
-                llf = ll;
-                // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534); only bse[1] is used (model.py:332)
-#pragma unroll
-                for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
-                double det;
-                if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
-                else {
-                    double e[PC];
-#pragma unroll
-                    for (int a = 0; a < PC; ++a) e[a] = (a == 1) ? 1.0 : 0.0;
-                    ldl_solve<PC>(H, e);
-                    bse1 = sqrt(e[1] / nobs);
-                }
-                active = false;
-            } else {
+            info_pass<Q, true, false>(T, Vpad, v, N, NB64, y, W, beta, H, g, ll, maxdev, false);
+            if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }                      // _check_perfect_pred
+            else {
                 // newparams = oldparams - inv(H/n + 1e-10 I) . score/n   with H = -X^T W X   (optimizer.py:415-423)
 #pragma unroll
                 for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
@@ -234,29 +343,77 @@ __global__ __launch_bounds__(64) void k_glm_logit(const uint64_t *__restrict__ T
 #pragma unroll
                     for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
                     ++it;
-                    if (!moving || it >= 35) fin = true;
+                    if (!moving || it >= 35) active = false;
                 }
             }
         }
     }
-    if (want_fit) {
-        if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }
-        else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
-        else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }                 // model.py:332-334
+    if (!live) return;
+    if (status == 0) {
+        wk.state[v] = 1;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
+    } else {
+        flags[v] |= (status == 1) ? SH_NOTE_PERFECT_SEP : SH_NOTE_MATRIX_INV;                   // model.py:345-352
+        const int s2 = atomicAdd(firth_count, 1); firth_list[s2] = (int)v;
+    }
+}
+
+// ---- kernel 3: phase C, fp64 evaluation at the final beta + the decisions of model.py:332-344, 384 --------------------------
+template <int Q>
+__global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                  const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                  GlmWork wk, double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                  int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    constexpr int PC = Q + 2;
+    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool fin = (v < V) && (wk.state[v < V ? v : 0] == 1);
+    if (!__any(fin)) return;
+    const int64_t vr = fin ? v : 0;
+    const int N = P.N, NB64 = P.NB64;
+    const double nobs = (double)N;
+    double beta[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = fin ? wk.bw[(int64_t)a * Vpad + vr] : 0.0;
+    int status = 0;
+    double llf = NAN, bse1 = NAN;
+    if (fin) {
+        double H[PC * (PC + 1) / 2], dummy[PC], ll, maxdev;
+        info_pass<Q, false, true>(T, Vpad, vr, N, NB64, y, W, beta, H, dummy, ll, maxdev, true);
+        if (maxdev <= 1e-8) status = 1;                                                          // callback after the last update
         else {
-            const double lrstat = -2.0 * (P.null_llf - llf);
-            pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);                        // model.py:336-339
-            icpt = beta[0]; kbeta = beta[1]; kbse = bse1;
-            if (pval > P.lrtt || !isfinite(pval) || !isfinite(kbeta)) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
+            llf = ll;
+            // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534); only bse[1] is used (model.py:332)
+#pragma unroll
+            for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
+            double det;
+            if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
+            else {
+                double e[PC];
+#pragma unroll
+                for (int a = 0; a < PC; ++a) e[a] = (a == 1) ? 1.0 : 0.0;
+                ldl_solve<PC>(H, e);
+                bse1 = sqrt(e[1] / nobs);
+            }
         }
     }
-    if (live) {
-        out[v] = prep; out[V + v] = pval; out[2 * V + v] = kbeta; out[3 * V + v] = kbse; out[4 * V + v] = icpt;
+    if (!fin) return;
+    uint32_t fl = flags[v];
+    bool to_firth = false;
+    if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }
+    else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
+    else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }                         // model.py:332-334
+    else {
+        const double lrstat = -2.0 * (P.null_llf - llf);
+        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);                        // model.py:336-339
+        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = bse1; out[4 * V + v] = beta[0];
 #pragma unroll
-        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = (to_firth || !want_fit) ? NAN : beta[2 + j];
-        flags[v] = fl;
-        if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
     }
+    flags[v] = fl;
+    if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
 }
 
 // =====================================================================================================================
@@ -783,12 +940,14 @@ extern "C" hipError_t shk_glm_lineage(hipStream_t st, int PC, const uint64_t *T,
 // ---------------------------------------------------------------------------------------------------------------------
 template <int Q>
 static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
-                             const double *W, const uint64_t *y1, const uint64_t *y0, const double *yc, const double *ZtZ,
+                             const double *W, const float *Wf, const uint64_t *y1, const uint64_t *y0, const double *yc, const double *ZtZ,
                              const double *Zty, GlmParams P, double *out, uint32_t *flags, int *flist, int *fcount,
-                             int *plist, int *pcount)
+                             int *plist, int *pcount, GlmWork wk)
 {
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
-    if (which == 0) hipLaunchKernelGGL(k_glm_logit<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, P, out, flags, flist, fcount);
+    if (which == 0) hipLaunchKernelGGL(k_glm_fast<Q>, grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
+    else if (which == 4) hipLaunchKernelGGL(k_glm_slow<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
+    else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags);
@@ -796,11 +955,13 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
 }
 
 extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uint64_t *T, int64_t Vpad, int64_t V,
-                                     const double *y, const double *W, const uint64_t *y1, const uint64_t *y0,
+                                     const double *y, const double *W, const float *Wf, const uint64_t *y1, const uint64_t *y0,
                                      const double *yc, const double *ZtZ, const double *Zty, GlmParams P, double *out,
-                                     uint32_t *flags, int *flist, int *fcount, int *plist, int *pcount)
+                                     uint32_t *flags, int *flist, int *fcount, int *plist, int *pcount, double *bw, int *state,
+                                     int *slow_list, int *slow_count)
 {
-#define GLM_CASE(q) case q: return launch_glm<q>(st, which, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, flist, fcount, plist, pcount);
+    GlmWork wk{bw, state, slow_list, slow_count};
+#define GLM_CASE(q) case q: return launch_glm<q>(st, which, T, Vpad, V, y, W, Wf, y1, y0, yc, ZtZ, Zty, P, out, flags, flist, fcount, plist, pcount, wk);
     switch (Q) {
         GLM_CASE(0) GLM_CASE(1) GLM_CASE(2) GLM_CASE(3) GLM_CASE(4) GLM_CASE(5) GLM_CASE(6) GLM_CASE(7)
         GLM_CASE(8) GLM_CASE(9) GLM_CASE(10) GLM_CASE(11) GLM_CASE(12) GLM_CASE(13) GLM_CASE(14)
