@@ -115,6 +115,20 @@ int sh_glm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t
 int sh_lineage_setup(sh_ctx *ctx, const double *lin, int l, const double *cov, int j);
 int sh_lineage_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V, int32_t *max_lineage);
 
+/* ---------------------------------------------------------------------------------------------
+ * Native k-mer text reader / packer (host code; replaces the k-mer branch of pyseer/input.py:301 read_variant for the GPU
+ * feed).  Lines "KMER | sample:count sample:count ..." (gzip or plain) -> packed presence rows over `sample_names`
+ * (= p.index, phenotype order), carrier counts (af = count / n, input.py:446) and the variant names.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sh_reader sh_reader;
+sh_reader  *sh_reader_open(const char *path, const char *const *sample_names, int n_samples);
+void        sh_reader_close(sh_reader *r);
+const char *sh_reader_error(void);
+/* parses up to max_variants lines; returns how many (0 = end of file, -1 = error).  bits: max_variants*row_bytes;
+ * names: concatenated variant names, name_off[v] .. name_off[v+1] (max_variants+1 offsets). */
+int64_t     sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_t row_bytes, int32_t *counts,
+                           char *names, int64_t names_cap, int64_t *name_off);
+
 /* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */
 int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);
 

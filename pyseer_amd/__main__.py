@@ -22,7 +22,7 @@ import pandas as pd
 from . import __version__
 from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
 from .input import (load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
-                    iter_packed_blocks)
+                    iter_packed_blocks, iter_packed_blocks_native)
 from .lmm import initialise_lmm, mask_like_fit_lmm
 from .model import fit_null, covariate_block
 from .utils import format_output
@@ -76,6 +76,8 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--python-reader', action='store_true', default=False,
+                    help='Parse k-mer files with the Python reader instead of the native C++ one')
     ot.add_argument('--lmm-lineage-per-variant', action='store_true', default=False,
                     help='With --lmm --lineage, fit the lineage effect of each variant itself. [Default: reproduce the reference, '
                          'which fits the LAST variant of each block for every variant of that block]')
@@ -226,7 +228,9 @@ def main(argv=None):
 
     all_strains = set(p.index)
     var_type, var_file = ("kmers", options.kmers) if options.kmers else ("Rtab", options.pres)
-    infile, sample_order = open_variant_file(var_type, var_file, None, None, options.uncompressed)
+    native = (var_type == "kmers") and not options.python_reader
+    if not native:
+        infile, sample_order = open_variant_file(var_type, var_file, None, None, options.uncompressed)
     patterns = open(options.output_patterns, 'wb') if options.output_patterns else None
 
     header = ['variant', 'af', 'filter-pvalue', 'lrt-pvalue', 'beta', 'beta-std-err']
@@ -267,8 +271,13 @@ def main(argv=None):
         printed += 1
         out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
 
-    for blk in iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
-                                  options.max_missing, options.uncompressed, options.block_size):
+    if native:
+        blocks = iter_packed_blocks_native(p, var_file, options.min_af, options.max_af, options.block_size,
+                                           want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
+    else:
+        blocks = iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
+                                    options.max_missing, options.uncompressed, options.block_size)
+    for blk in blocks:
         if options.lmm:
             r = mask_like_fit_lmm(eng.lmm_batch(blk.bits)) if blk.bits.shape[0] else None
         else:

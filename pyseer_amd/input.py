@@ -294,3 +294,93 @@ def iter_packed_blocks(p, var_type, infile, all_strains, sample_order, min_af, m
             yield blk
         if eof:
             return
+
+
+class NativeKmerReader(object):
+    """Blocks of packed k-mer presence rows straight from the text file through libseerhip's reader (csrc/reader.cpp):
+    gzip inflate + tokenise + sample lookup + bit packing in C++ (OpenMP over the lines of a block).  No GPU needed."""
+
+    def __init__(self, path, sample_names, block_size=3000, max_name=256):
+        import ctypes as C
+        from . import _abi
+        self._C, self._abi = C, _abi
+        self._lib = _abi.load()
+        self.samples = [str(x) for x in sample_names]
+        self.n = len(self.samples)
+        arr = (C.c_char_p * self.n)(*[x.encode() for x in self.samples])
+        h = self._lib.sh_reader_open(str(path).encode(), arr, self.n)
+        if not h:
+            raise IOError(self._lib.sh_reader_error().decode())
+        self._h = C.c_void_p(h)
+        self.block_size = int(block_size)
+        self.row_bytes = row_bytes_for(self.n)
+        self._names = C.create_string_buffer(self.block_size * max_name)
+        self._off = np.zeros(self.block_size + 1, dtype=np.int64)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sh_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __iter__(self):
+        C, abi = self._C, self._abi
+        while True:
+            bits = np.zeros((self.block_size, self.row_bytes), dtype=np.uint8)
+            counts = np.zeros(self.block_size, dtype=np.int32)
+            nv = self._lib.sh_reader_next(self._h, self.block_size, bits.ctypes.data_as(abi.c_u8p), self.row_bytes,
+                                          counts.ctypes.data_as(C.POINTER(C.c_int32)), self._names, len(self._names),
+                                          self._off.ctypes.data_as(C.POINTER(C.c_int64)))
+            if nv < 0:
+                raise IOError(self._lib.sh_reader_error().decode())
+            if nv == 0:
+                return
+            raw = self._names.raw
+            names = [raw[self._off[v]:self._off[v + 1]].decode() for v in range(nv)]
+            yield names, bits[:nv], counts[:nv]
+
+
+def strains_from_bits(row, samples_sorted_idx, samples):
+    """(kstrains, nkstrains), both lexicographically sorted like read_variant's (input.py:439-440), from one packed row."""
+    present = np.unpackbits(row, bitorder="little")[:len(samples)].astype(bool)
+    ks = [samples[i] for i in samples_sorted_idx if present[i]]
+    nks = [samples[i] for i in samples_sorted_idx if not present[i]]
+    return ks, nks
+
+
+def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False):
+    """Same PackedBlock stream as iter_packed_blocks for k-mer files, fed by the native reader."""
+    samples = [str(x) for x in p.index]
+    order = sorted(range(len(samples)), key=lambda i: samples[i])
+    n = len(samples)
+    for names, bits, counts in NativeKmerReader(path, samples, block_size):
+        blk = PackedBlock(n, 0)
+        afs = counts.astype(np.float64) / n
+        keep = (afs >= min_af) & (afs <= max_af)
+        blk.names = names
+        blk.afs = afs.tolist()
+        blk.status = [0 if k_ else 1 for k_ in keep]
+        rows = np.cumsum(keep) - 1
+        blk.row_of = [int(rows[i]) if keep[i] else -1 for i in range(len(names))]
+        blk.ks = [None] * len(names)
+        blk.bits = np.ascontiguousarray(bits[keep])
+        if want_samples:
+            sp = [strains_from_bits(bits[i], order, samples) for i in range(len(names))]
+            blk.kstrains = [a for a, _ in sp]; blk.nkstrains = [b for _, b in sp]
+        else:
+            blk.kstrains = [[] for _ in names]; blk.nkstrains = [[] for _ in names]
+        if want_patterns:
+            dense = np.unpackbits(bits, axis=1, bitorder="little")[:, :n].astype(np.int64)
+            blk.patterns = [hash_pattern(dense[i]) for i in range(len(names))]
+        else:
+            blk.patterns = [b''] * len(names)
+        for i in range(len(names)):
+            if counts[i] == 0:
+                sys.stderr.write("No observations of " + names[i] + " in selected samples\n")
+        blk.last_k = np.unpackbits(bits[len(names) - 1], bitorder="little")[:n].astype(np.int64)
+        yield blk

@@ -1,0 +1,60 @@
+"""Native k-mer reader (pyseer_amd/csrc/reader.cpp) against the Python restatement of pyseer/input.py:read_variant, on the
+reference's own kmers.gz and on synthetic gz / plain files with the format's corner cases."""
+import gzip
+import os
+
+import numpy as np
+import pandas as pd
+
+from pyseer_amd.input import (NativeKmerReader, iter_packed_blocks, iter_packed_blocks_native, open_variant_file,
+                              read_variant, hash_pattern)
+
+CLI = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli")
+
+
+def _pheno():
+    p = pd.read_csv(os.path.join(CLI, "subset.pheno"), index_col=0, sep="\t")["binary"]
+    p.index = p.index.astype(str)
+    return p
+
+
+def test_native_equals_python_on_reference_kmers():
+    p = _pheno()
+    nat = list(iter_packed_blocks_native(p, os.path.join(CLI, "kmers.gz"), 0.01, 0.99, 37, want_patterns=True, want_samples=True))
+    fh, _ = open_variant_file("kmers", os.path.join(CLI, "kmers.gz"))
+    py = list(iter_packed_blocks(p, "kmers", fh, set(p.index), [], 0.01, 0.99, 0.05, False, 37))
+    assert len(nat) == len(py) and sum(len(b.names) for b in nat) == 200
+    for a, b in zip(nat, py):
+        assert a.names == b.names and a.status == b.status and a.row_of == b.row_of
+        assert np.array_equal(a.bits, b.bits) and np.allclose(a.afs, b.afs)
+        assert a.patterns == b.patterns and a.kstrains == b.kstrains and a.nkstrains == b.nkstrains
+        assert np.array_equal(a.last_k, np.asarray(b.last_k))
+
+
+def test_corner_cases(tmp_path):
+    samples = ["s%d" % i for i in range(70)] + ["dup"]
+    lines = [
+        "AAAA | s0:1 s1:3 s69:2",
+        "CCCC\t|  s5:1   s5:7 unknown:1 dup:1 ",             # repeated sample, unknown sample, extra blanks
+        "GGGG | s1:1 | s2:1",                                 # only the segment between the first two bars counts
+        "TTTT |",                                             # no carriers
+        "ACAC | " + " ".join("s%d:1" % i for i in range(70)),
+    ]
+    p = pd.Series(np.arange(len(samples), dtype=float), index=samples)
+    for name, opener in (("k.txt", open), ("k.gz", gzip.open)):
+        path = str(tmp_path / name)
+        with opener(path, "wt") as fh:
+            fh.write("\n".join(lines))                        # no trailing newline on purpose
+        got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples, 2)]
+        names = sum((g[0] for g in got), [])
+        bits = np.concatenate([g[1] for g in got]); counts = np.concatenate([g[2] for g in got])
+        assert names == ["AAAA", "CCCC", "GGGG", "TTTT", "ACAC"]
+        assert counts.tolist() == [3, 2, 1, 0, 70]
+        # the Python restatement of the reference parser gives the same presence vectors
+        fh = open(path) if name.endswith(".txt") else gzip.open(path, "r")
+        for v in range(5):
+            eof, k, var_name, ks, nks, af, missing = read_variant(fh, p, "kmers", False, None, name.endswith(".txt"),
+                                                                  set(samples), [])
+            dense = np.unpackbits(bits[v], bitorder="little")[:len(samples)]
+            assert var_name == names[v] and np.array_equal(dense, k) and abs(af - counts[v] / len(samples)) < 1e-15
+            assert hash_pattern(dense.astype(np.int64)) == hash_pattern(np.asarray(k))
