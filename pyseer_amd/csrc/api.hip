@@ -18,8 +18,8 @@ extern "C" {
 hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
-hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, double *);
-hipError_t shk_lmm_finalize(hipStream_t, int64_t, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
+hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *);
+hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
                            unsigned long long *, int8_t *);
 }
@@ -45,6 +45,7 @@ struct sh_ctx {
     uint64_t *d_y1 = nullptr, *d_y0 = nullptr;
     int8_t *d_G = nullptr;
     double quant_scale = 0.0;
+    int qf_split = 1;             // 1: one block per (variant tile, limb) (SEERHIP_QF_SPLIT=0: one block per tile loops over the limbs)
     int qf_variant = 0;           // hot-kernel variant (SEERHIP_QF=1 selects the first-generation kernel, for A/B runs)
     // ---- GLM state
     GlmState glm;
@@ -76,7 +77,7 @@ static int ensure_ws(sh_ctx *c, int64_t Vpad)
     HIPCHK(dmalloc(&c->d_T, (size_t)Vpad * c->NB64p));
     HIPCHK(dmalloc(&c->d_t11, Vpad)); HIPCHK(dmalloc(&c->d_t01, Vpad)); HIPCHK(dmalloc(&c->d_m, Vpad));
     HIPCHK(dmalloc(&c->d_xky, Vpad)); HIPCHK(dmalloc(&c->d_dg, Vpad)); HIPCHK(dmalloc(&c->d_rss, Vpad));
-    HIPCHK(dmalloc(&c->d_s1, Vpad)); HIPCHK(dmalloc(&c->d_q1, Vpad)); HIPCHK(dmalloc(&c->d_q, Vpad));
+    HIPCHK(dmalloc(&c->d_s1, Vpad)); HIPCHK(dmalloc(&c->d_q1, Vpad)); HIPCHK(dmalloc(&c->d_q, Vpad * 8));
     c->capV = Vpad;
     return SH_OK;
 }
@@ -108,6 +109,7 @@ sh_ctx *sh_create(int device, int n_samples)
     sh_ctx *c = new sh_ctx();
     c->device = device; c->N = n_samples;
     if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
+    if (const char *qs = std::getenv("SEERHIP_QF_SPLIT")) c->qf_split = std::atoi(qs);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
     return c;
@@ -315,10 +317,11 @@ int sh_lmm_batch_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V
                           c->fin.continuous, lo));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, c->d_q));
+    const int lsplit = c->qf_split ? c->L : 1;
+    HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q));
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->tev.emplace_back(e0, e1); }
     LmmFinParams P = c->fin; P.min_af = c->min_af; P.max_af = c->max_af; P.af_on = c->af_on;
-    HIPCHK(shk_lmm_finalize(st, V, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags));
+    HIPCHK(shk_lmm_finalize(st, V, Vpad, lsplit, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags));
     return SH_OK;
 }
 

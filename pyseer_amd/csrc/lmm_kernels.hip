@@ -170,14 +170,22 @@ template <int N> __device__ __forceinline__ void qf_wait_vm() { asm volatile("s_
 // ABL: timing ablations (results meaningless): 1 = no DMA, 2 = no LDS fragment reads, 4 = no bit expansion
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
-                                                            int64_t Vpad, int NR, int L, double *__restrict__ qout)
+                                                            int64_t Vpad, int NR, int L, int lsplit, double *__restrict__ qout)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // QF_NST slots x 24 KB (the ONLY LDS object)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t v0 = (int64_t)blockIdx.x * QF_BN;
+    // Block -> (variant tile, limb group).  With lsplit = L every block owns ONE limb of one 512-variant tile and the L blocks of
+    // a tile are neighbours on the same XCD (block b runs on XCD b % 8): they re-read the same packed bits, which then stay in that
+    // XCD's L2 instead of being re-fetched from the Infinity Cache for every (row tile, limb) segment.
+    const int ntiles = (int)(Vpad / QF_BN);
+    int tile, lgrp;
+    if ((ntiles & 7) == 0) { const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3; tile = (w / lsplit) * 8 + xcd; lgrp = w % lsplit; }
+    else { tile = blockIdx.x / lsplit; lgrp = blockIdx.x % lsplit; }
+    const int nl = (L - lgrp + lsplit - 1) / lsplit;                    // limbs handled here: lgrp, lgrp + lsplit, ...
+    const int64_t v0 = (int64_t)tile * QF_BN;
     const int64_t TL = (int64_t)NR * (NR + 1);                          // tiles per limb: sum_I 2(I+1)
-    const int total = L * (NR * (NR + 1) / 2);                          // stages in the flattened stream
+    const int total = nl * (NR * (NR + 1) / 2);                         // stages in the flattened stream
     int aoff[4][2];
 #pragma unroll
     for (int it = 0; it < 4; ++it) { aoff[it][0] = qf_off(it * 32 + l31, lh); aoff[it][1] = qf_off(it * 32 + l31, 2 + lh); }
@@ -187,14 +195,17 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
     v16i acc[4][2];
     int pI = 0, pl = 0, pst = 0, pslot = 0;                              // DMA cursor (QF_NST-1 stages ahead)
     int cI = 0, cl = 0, cst = 0;                                        // compute cursor
-    double scale_l = 1.0;
+    double scale0 = 1.0, step = 1.0;
+    for (int i = 0; i < lgrp; ++i) scale0 *= 256.0;
+    for (int i = 0; i < lsplit; ++i) step *= 256.0;
+    double scale_l = scale0;
 
     auto fetch = [&]() {
-        const int8_t *g = G + ((int64_t)pl * TL + (int64_t)pI * (pI + 1) + 2 * pst) * QF_TILE_BYTES;
+        const int8_t *g = G + ((int64_t)(lgrp + pl * lsplit) * TL + (int64_t)pI * (pI + 1) + 2 * pst) * QF_TILE_BYTES;
         const uint64_t *t = T + (int64_t)(2 * pst) * Vpad + v0;
         if (!(ABL & 1)) qf_dma_stage(g, t, Vpad, smem + pslot * QF_STAGE_BYTES, wave, lane);
         if (++pslot == QF_NST) pslot = 0;
-        if (++pst == pI + 1) { pst = 0; if (++pl == L) { pl = 0; ++pI; } }
+        if (++pst == pI + 1) { pst = 0; if (++pl == nl) { pl = 0; ++pI; } }
     };
 
 #pragma unroll 1
@@ -276,14 +287,14 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
                 }
                 tot[jt] = fma((double)sum, scale_l, tot[jt]);
             }
-            cst = 0; scale_l *= 256.0;
-            if (++cl == L) { cl = 0; scale_l = 1.0; ++cI; }
+            cst = 0; scale_l *= step;
+            if (++cl == nl) { cl = 0; scale_l = scale0; ++cI; }
         }
     }
     // lanes l and l^32 hold different rows of the same variant
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) tot[jt] += __shfl_xor(tot[jt], 32, 64);
-    if (lh == 0) { qout[v0 + wave * 64 + l31] = tot[0]; qout[v0 + wave * 64 + 32 + l31] = tot[1]; }
+    if (lh == 0) { double *qo = qout + (int64_t)lgrp * Vpad; qo[v0 + wave * 64 + l31] = tot[0]; qo[v0 + wave * 64 + 32 + l31] = tot[1]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -298,7 +309,7 @@ struct LmmFinParams {
     double min_af, max_af; int af_on;
 };
 
-__global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, LmmLinOut li, const double *__restrict__ q,
+__global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, int nq, LmmLinOut li, const double *__restrict__ q,
                                                       LmmFinParams P, double *__restrict__ out, uint32_t *__restrict__ flags)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -325,7 +336,9 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, LmmLinOut li, c
         if (prep >= P.pret || !isfinite(prep)) fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER;      // lmm.py:174 (>=)
         // statistics (computed for every AF-passing variant; masking by flags is the caller's, lmm.py:176-217)
         const bool zeroed = sqrt(li.rss[v] / (double)P.N) <= 1e-10;                              // lmm_cov.py:179-181
-        const double xKx = zeroed ? 0.0 : (li.dg[v] + q[v] * P.inv_scale);
+        double qs = 0.0;
+        for (int a = 0; a < nq; ++a) qs += q[(int64_t)a * Vpad + v];          // per-limb-group partial sums, fixed order
+        const double xKx = zeroed ? 0.0 : (li.dg[v] + qs * P.inv_scale);
         const double xKy = zeroed ? 0.0 : li.xky[v];
         double b = xKy / xKx;
         if (isnan(b) && xKy == 0.0) b = 0.0;                                                      // lmm_cov.py:802-805
@@ -471,9 +484,9 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, double *q)
+hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q)
 {
-    const dim3 g((unsigned)(Vpad / QF_BN)), b(512);
+    const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(512);
     const size_t lds = QF_NST * QF_STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -485,19 +498,19 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         attr_set = true;
     }
     switch (variant) {          // 30 + mask = timing ablations (results meaningless)
-    case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
-    case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
-    case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
-    case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
-    default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, q); break;
+    case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     }
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_finalize(hipStream_t st, int64_t V, LmmLinOut li, const double *q, LmmFinParams P, double *out,
+hipError_t shk_lmm_finalize(hipStream_t st, int64_t V, int64_t Vpad, int nq, LmmLinOut li, const double *q, LmmFinParams P, double *out,
                             uint32_t *flags)
 {
-    hipLaunchKernelGGL(k_lmm_finalize, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, li, q, P, out, flags);
+    hipLaunchKernelGGL(k_lmm_finalize, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, Vpad, nq, li, q, P, out, flags);
     return hipGetLastError();
 }
 

@@ -32,3 +32,59 @@ def gather_in_order(local_rows, group=None):
     parts = [None] * dist.get_world_size(group)
     dist.all_gather_object(parts, np.asarray(local_rows), group=group)
     return np.concatenate(parts, axis=0)
+
+
+class ShardedEngine(object):
+    """One Engine per device, driven by one host thread each (the C ABI calls release the GIL); a batch of packed rows is
+    split into contiguous shards (shard_bounds), per-run constants are replicated by each context's own *_setup, results
+    come back in input order.  No device-to-device traffic at all."""
+
+    def __init__(self, n_samples, devices):
+        from .engine import Engine
+        self.devices = list(devices)
+        self.engines = [Engine(n_samples, device=d) for d in self.devices]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def _each(self, fn):
+        import threading
+        out = [None] * len(self.engines)
+        err = []
+
+        def run(i):
+            try:
+                out[i] = fn(i, self.engines[i])
+            except BaseException as ex:      # re-raised in the caller's thread
+                err.append(ex)
+        th = [threading.Thread(target=run, args=(i,)) for i in range(len(self.engines))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    def set_af_filter(self, lo, hi):
+        self._each(lambda i, e: e.set_af_filter(lo, hi))
+
+    def lmm_setup(self, *a, **k):
+        self._each(lambda i, e: e.lmm_setup(*a, **k))
+
+    def glm_setup(self, *a, **k):
+        self._each(lambda i, e: e.glm_setup(*a, **k))
+
+    def _sharded(self, bits, method):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        world = len(self.engines)
+        spans = [shard_bounds(bits.shape[0], r, world) for r in range(world)]
+        parts = self._each(lambda i, e: getattr(e, method)(bits[spans[i][0]:spans[i][1]]))
+        return {k_: np.concatenate([p[k_] for p in parts], axis=0) for k_ in parts[0]}
+
+    def lmm_batch(self, bits):
+        return self._sharded(bits, "lmm_batch")
+
+    def glm_batch(self, bits):
+        return self._sharded(bits, "glm_batch")

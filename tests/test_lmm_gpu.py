@@ -177,3 +177,18 @@ def test_lmm_full_size_properties(engine_mod):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy()[2], r6["beta"]) and np.array_equal(fl.cpu().numpy().astype(np.uint32), r6["flags"])
     e.close()
+
+
+def test_sharded_engine_matches_single(engine_mod):
+    """Multi-GPU sharding path (one context + host thread per device; here two contexts on device 0): same numbers, input order."""
+    Engine, pack = engine_mod
+    from pyseer_amd.parallel import ShardedEngine
+    d = np.load(os.path.join(G, "lmm_N300_D3.npz"))
+    bits = pack(np.tile(d["Kv"], (5, 1))[:301])
+    e = Engine(300); e.lmm_setup(d["U"], d["S"], d["y"], d["covar"], float(d["h2"]))
+    want = e.lmm_batch(bits); e.close()
+    s = ShardedEngine(300, [0, 0, 0])
+    s.lmm_setup(d["U"], d["S"], d["y"], d["covar"], float(d["h2"]))
+    got = s.lmm_batch(bits); s.close()
+    for k in want:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
