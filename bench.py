@@ -121,6 +121,17 @@ def fixed_effects_extra(dev, local, N, q=10, V=1 << 18, reps=3):
     return out
 
 
+def measured_traffic(Vs):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (they cannot run inside
+    this process: counters need their own rocprofv3 runs), scaled by variants per launch.  None if no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic_lmm.json")
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path))
+    per_variant = (t["FETCH_SIZE_KB"] * t["fetch_correction"] + t["WRITE_SIZE_KB"]) * 1024.0 / t["variants_per_dispatch"]
+    return per_variant * Vs, t["source"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +197,7 @@ def main():
         kern_s = kms / max(klaunch, 1) * 1e-3
         int8_ops = 2.0 * info["int8_macs_per_variant"] * Vs
         achieved = int8_ops / kern_s / 1e12
+        traffic, traffic_src = measured_traffic(Vs)
         res = {
             "metric": "k-mer tests/sec at N=5000 samples (LMM), whole job",
             "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,9 +208,10 @@ def main():
                                    "D=1, k=%d, h2=%.4f, inputs resident in HBM" % (Vs, N, U.shape[1], h2),
                        "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                         "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
+                         "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "kernel": "k_lmm_quadform_i8", "kernel_ms": kern_s * 1e3, "launches": klaunch,
-                         "ops": "int8 multiply-adds x2 actually issued: L*2*NT*(NT+1)*256*64 per variant",
+                         "ops": "int8 multiply-adds x2 actually issued: L*NR*(NR+1)*128*64 per variant, NR = ceil(N/128)",
                          "fp64_equiv_tflops": FP64_FLOP_PER_TEST * Vs / kern_s / 1e12,
                          "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9},
             "finite_fraction": frac_finite,
