@@ -123,3 +123,40 @@ def test_lineage_effect_golden(path):
     from test_oracle_golden import _same_or_tied
     _same_or_tied([None if x < 0 else int(x) for x in got], [None if x < 0 else int(x) for x in d["max_lineage"]], d["lin"],
                   d["cov"] if int(d["j"]) else None, d["K"])
+
+
+@pytest.mark.parametrize("N,q,cont", [(130, 0, False), (333, 14, False), (200, 1, False), (333, 14, True), (130, 0, True)])
+def test_design_width_extremes_vs_oracle(N, q, cont):
+    """Narrowest (no covariates) and widest (q = 14) register-resident designs, odd sample counts."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(7 + N + q)
+    W = rng.standard_normal((N, q)); W = W / np.abs(W).max(axis=0) if q else W
+    eta = -0.2 + (0.8 * W[:, 0] if q else 0.0)
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    K = (rng.random((96, N)) < rng.uniform(0.1, 0.9, 96)[:, None]).astype(np.uint8)
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W if q else e0, e0, cont).llf
+    nf = np.nan if cont else fit_null(y, W if q else e0, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W if q else None, cont, 1.0, 1.0, nl, nf)
+    e = Engine(N); e.glm_setup(y, W, cont, nl, nf)
+    r = e.glm_batch(pack_variants(K)); e.close()
+    firth = (want["notes"] & 0x7C) != 0
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(r[f][~firth], want[f][~firth], atol=1e-12 if f in ("kbeta", "intercept") else 0.0, what=f)   # exact zeros come out as +-1e-16
+        close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
+    if q:
+        close(r["betas"][~firth], want["betas"][~firth], atol=1e-12, what="betas")
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+
+
+def test_empty_and_single_variant_batches():
+    from pyseer_amd.engine import Engine, pack_variants
+    d = np.load(os.path.join(G, "glm_N100_q3.npz"))
+    e = Engine(100); e.glm_setup(d["y"], d["m"], False, float(d["null_llf"]), float(d["null_firth"]))
+    r0 = e.glm_batch(np.zeros((0, 16), dtype=np.uint8))
+    assert r0["kbeta"].shape == (0,) and r0["betas"].shape == (0, 3)
+    r1 = e.glm_batch(pack_variants(d["K"][20:21]))
+    close(r1["kbeta"], d["main"][20:21, 2], atol=FA); close(r1["pvalue"], d["main"][20:21, 1])
+    e.close()

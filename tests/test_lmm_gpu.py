@@ -192,3 +192,24 @@ def test_sharded_engine_matches_single(engine_mod):
     got = s.lmm_batch(bits); s.close()
     for k in want:
         assert np.array_equal(got[k], want[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("N,D,cont", [(129, 6, False), (640, 9, True), (64, 1, True)])
+def test_lmm_many_covariates_and_continuous_vs_oracle(engine_mod, N, D, cont):
+    """Wider covariate panels (DP = 8, 16 residual kernels), continuous-phenotype prefilter, sample counts at tile edges."""
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    U, S, covar, y, Kv = _random_lmm(N, D, 99 + N, 200)
+    if cont:
+        y = np.random.default_rng(N).standard_normal(N)
+    L = orc.LmmOracle(U, S, y, covar)
+    wb, ws, wf, wp = L.block(0.6, Kv.astype(float))
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.6, continuous=cont)
+    r = e.lmm_batch(pack(Kv))
+    close(r["beta"], wb, atol=1e-12); close(r["bse"], ws); close(r["frac_h2"], wf, atol=1e-9); close(r["pvalue"], wp, atol=1e-300)
+    for v in range(0, 200, 17):
+        pr, bad = orc.pre_filtering(y, Kv[v].astype(float), cont)
+        close(r["prep"][v], pr, what="prep"); assert bool(r["flags"][v] & 4) == bad
+    assert e.lmm_batch(np.zeros((0, (N + 63) // 64 * 8), dtype=np.uint8))["beta"].shape == (0,)
+    e.close()
