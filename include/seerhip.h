@@ -69,6 +69,11 @@ int     sh_synchronize(sh_ctx *ctx);
  * recorded on the context's stream.  sh_get_timing synchronises on the recorded events and returns their sum. */
 int     sh_set_timing(sh_ctx *ctx, int on);
 int     sh_get_timing(sh_ctx *ctx, double *total_ms, int64_t *launches);
+/* Pattern de-duplication (pyseer/input.py:710 hash_pattern, scripts/count_patterns.py): when on, every later
+ * *_batch / *_batch_dev call tests each DISTINCT packed row once (exact row comparison, the hash only finds candidates) and fans
+ * the result out to all variants that share it.  Outputs are unchanged.  Costs one stream synchronisation per batch. */
+int     sh_set_dedup(sh_ctx *ctx, int on);
+int     sh_dedup_info(sh_ctx *ctx, int64_t *unique_last_batch);
 /* AF filter of the variant stream (pyseer/input.py:608,693): keep min_af <= count/n <= max_af (inclusive);
  * others get SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER and NaN statistics.  Default: disabled (0, 1). */
 int     sh_set_af_filter(sh_ctx *ctx, double min_af, double max_af);

@@ -76,6 +76,8 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--no-dedup', action='store_true', default=False,
+                    help='Test every variant separately [Default: each distinct presence pattern of a block is tested once]')
     ot.add_argument('--python-reader', action='store_true', default=False,
                     help='Parse k-mer files with the Python reader instead of the native C++ one')
     ot.add_argument('--lmm-lineage-per-variant', action='store_true', default=False,
@@ -221,6 +223,7 @@ def main(argv=None):
                       np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
                       options.filter_pvalue, options.lrt_pvalue)
 
+    eng.set_dedup(not options.no_dedup)
     if options.lineage:
         eng.lineage_setup(np.asarray(lineage_clusters, dtype=float), cov.values if cov.shape[1] > 0 else None)
     if not options.lineage:

@@ -25,6 +25,8 @@ SIGNATURES = {
     "sh_synchronize": (C.c_int, [C.c_void_p]),
     "sh_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sh_get_timing": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int64)]),
+    "sh_set_dedup": (C.c_int, [C.c_void_p, C.c_int]),
+    "sh_dedup_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "sh_set_af_filter": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "sh_lmm_setup": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_int,
                                C.c_double, C.c_double, C.c_int]),

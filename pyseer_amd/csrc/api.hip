@@ -22,6 +22,9 @@ hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, 
 hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
                            unsigned long long *, int8_t *);
+hipError_t shk_dd_find(hipStream_t, const uint64_t *, int64_t, int64_t, int, uint64_t *, uint64_t, unsigned long long *, int *, int *, int *, int *);
+hipError_t shk_dd_gather(hipStream_t, const uint8_t *, int64_t, int64_t, const int *, const int *, uint8_t *);
+hipError_t shk_dd_scatter(hipStream_t, int64_t, int64_t, int, const int *, const int *, const double *, const uint32_t *, double *, uint32_t *);
 }
 #include "glm_api.inc"
 
@@ -57,6 +60,10 @@ struct sh_ctx {
     // ---- optional timing of the dominant kernel (sh_set_timing / sh_get_timing)
     int timing = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
+    // ---- pattern de-duplication (sh_set_dedup)
+    int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
+    uint64_t *dd_h = nullptr; unsigned long long *dd_keys = nullptr; int *dd_idx = nullptr, *dd_rep = nullptr, *dd_slot = nullptr, *dd_n = nullptr;
+    uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0;
     // ---- staging for the host-pointer entry points
     int64_t cap_bits = 0, cap_out = 0;
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
@@ -79,6 +86,42 @@ static int ensure_ws(sh_ctx *c, int64_t Vpad)
     HIPCHK(dmalloc(&c->d_xky, Vpad)); HIPCHK(dmalloc(&c->d_dg, Vpad)); HIPCHK(dmalloc(&c->d_rss, Vpad));
     HIPCHK(dmalloc(&c->d_s1, Vpad)); HIPCHK(dmalloc(&c->d_q1, Vpad)); HIPCHK(dmalloc(&c->d_q, Vpad * 8));
     c->capV = Vpad;
+    return SH_OK;
+}
+
+// Runs `inner` (sh_lmm_batch_dev / sh_glm_batch_dev body) on the distinct patterns only and fans the results out.
+static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
+static int glm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
+
+template <typename F>
+static int dedup_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags, int nrow, F inner)
+{
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int64_t Vpad = (V + 511) / 512 * 512;
+    int rc = ensure_ws(c, Vpad); if (rc) return rc;
+    if (V > c->dd_capV) {
+        hipFree(c->dd_h); hipFree(c->dd_keys); hipFree(c->dd_idx); hipFree(c->dd_rep); hipFree(c->dd_slot); hipFree(c->dd_n);
+        c->dd_h = nullptr; c->dd_keys = nullptr; c->dd_idx = c->dd_rep = c->dd_slot = c->dd_n = nullptr;
+        uint64_t cap = 1024; while (cap < (uint64_t)V * 2) cap <<= 1;
+        HIPCHK(dmalloc(&c->dd_h, V)); HIPCHK(dmalloc(&c->dd_keys, cap)); HIPCHK(dmalloc(&c->dd_idx, cap));
+        HIPCHK(dmalloc(&c->dd_rep, V)); HIPCHK(dmalloc(&c->dd_slot, V)); HIPCHK(dmalloc(&c->dd_n, 1));
+        c->dd_cap = (int64_t)cap; c->dd_capV = V;
+    }
+    if (V * row_bytes > c->dd_cap_bits) { hipFree(c->dd_bits); c->dd_bits = nullptr; HIPCHK(hipMalloc((void **)&c->dd_bits, V * row_bytes)); c->dd_cap_bits = V * row_bytes; }
+    if (V * nrow > c->dd_cap_out) {
+        hipFree(c->dd_out); hipFree(c->dd_flags); c->dd_out = nullptr; c->dd_flags = nullptr;
+        HIPCHK(dmalloc(&c->dd_out, V * nrow)); HIPCHK(dmalloc(&c->dd_flags, V)); c->dd_cap_out = V * nrow;
+    }
+    HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
+    HIPCHK(shk_dd_find(st, c->d_T, Vpad, V, c->NB64, c->dd_h, (uint64_t)c->dd_cap, c->dd_keys, c->dd_idx, c->dd_rep, c->dd_slot, c->dd_n));
+    int nu = 0;
+    HIPCHK(hipMemcpyAsync(&nu, c->dd_n, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));                     // the number of distinct patterns sizes the launches below
+    c->dd_last_unique = nu;
+    HIPCHK(shk_dd_gather(st, (const uint8_t *)d_bits, row_bytes, V, c->dd_rep, c->dd_slot, c->dd_bits));
+    rc = inner(c->dd_bits, (int64_t)nu, c->dd_out, c->dd_flags); if (rc) return rc;
+    HIPCHK(shk_dd_scatter(st, V, nu, nrow, c->dd_rep, c->dd_slot, c->dd_out, c->dd_flags, (double *)d_out, (uint32_t *)d_flags));
     return SH_OK;
 }
 
@@ -152,6 +195,15 @@ int sh_get_timing(sh_ctx *c, double *total_ms, int64_t *launches)
     for (auto &p : c->tev) { HIPCHK(hipEventSynchronize(p.second)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, p.first, p.second)); tot += ms; }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int64_t)c->tev.size();
+    return SH_OK;
+}
+
+int sh_set_dedup(sh_ctx *c, int on) { if (!c) return fail(SH_EINVAL, "null ctx"); c->dedup = on; return SH_OK; }
+
+int sh_dedup_info(sh_ctx *c, int64_t *unique_last_batch)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    if (unique_last_batch) *unique_last_batch = c->dd_last_unique;
     return SH_OK;
 }
 
@@ -305,6 +357,16 @@ int sh_lmm_info(sh_ctx *c, int *n_limbs, int64_t *macs, double *qscale)
 int sh_lmm_batch_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags)
 {
     if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
+    if (V <= 0) return SH_OK;
+    if (row_bytes * 8 < c->N) return fail(SH_ESHAPE, "row_bytes*8 < n_samples: shape mismatch between snps and Y");
+    if (c->dedup)
+        return dedup_wrap(c, d_bits, row_bytes, V, d_out, d_flags, 5,
+                          [&](const void *b, int64_t n, void *o, void *f) { return lmm_batch_dev_inner(c, b, row_bytes, n, o, f); });
+    return lmm_batch_dev_inner(c, d_bits, row_bytes, V, d_out, d_flags);
+}
+
+static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags)
+{
     if (V <= 0) return SH_OK;
     if (row_bytes * 8 < c->N) return fail(SH_ESHAPE, "row_bytes*8 < n_samples: shape mismatch between snps and Y");
     HIPCHK(hipSetDevice(c->device));

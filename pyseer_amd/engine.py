@@ -60,6 +60,15 @@ class Engine(object):
         _abi.check(self._lib.sh_get_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def set_dedup(self, on=True):
+        """Test each distinct presence pattern once and fan the result out (exact; see include/seerhip.h)."""
+        _abi.check(self._lib.sh_set_dedup(self._h, int(bool(on))))
+
+    def dedup_info(self):
+        n = C.c_int64()
+        _abi.check(self._lib.sh_dedup_info(self._h, C.byref(n)))
+        return n.value
+
     def set_af_filter(self, min_af, max_af):
         _abi.check(self._lib.sh_set_af_filter(self._h, float(min_af), float(max_af)))
 

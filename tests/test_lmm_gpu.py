@@ -213,3 +213,31 @@ def test_lmm_many_covariates_and_continuous_vs_oracle(engine_mod, N, D, cont):
         close(r["prep"][v], pr, what="prep"); assert bool(r["flags"][v] & 4) == bad
     assert e.lmm_batch(np.zeros((0, (N + 63) // 64 * 8), dtype=np.uint8))["beta"].shape == (0,)
     e.close()
+
+
+def test_pattern_dedup_is_exact_and_transparent(engine_mod):
+    """sh_set_dedup: duplicated patterns are tested once, outputs identical to the plain path (LMM and fixed effects)."""
+    Engine, pack = engine_mod
+    d = np.load(os.path.join(G, "lmm_N300_D3.npz"))
+    rng = np.random.default_rng(3)
+    Kv = d["Kv"][rng.integers(0, d["Kv"].shape[0], 1500)]           # 64 distinct patterns, 1500 rows, shuffled
+    bits = pack(Kv)
+    e = Engine(300); e.lmm_setup(d["U"], d["S"], d["y"], d["covar"], float(d["h2"]), filter_pvalue=0.5, lrt_pvalue=0.5)
+    want = e.lmm_batch(bits)
+    e.set_dedup(True)
+    got = e.lmm_batch(bits)
+    assert e.dedup_info() == len(np.unique(bits, axis=0))
+    for k in want:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    e.close()
+    g = np.load(os.path.join(G, "glm_N300_q10.npz"))
+    Kg = g["K"][rng.integers(0, g["K"].shape[0], 700)]
+    e = Engine(300); e.set_af_filter(0.01, 0.99)
+    e.glm_setup(g["y"], g["m"], False, float(g["null_llf"]), float(g["null_firth"]))
+    want = e.glm_batch(pack(Kg))
+    e.set_dedup(True)
+    got = e.glm_batch(pack(Kg))
+    assert e.dedup_info() == len(np.unique(pack(Kg), axis=0))
+    for k in want:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    e.close()
