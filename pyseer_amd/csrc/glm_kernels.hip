@@ -191,6 +191,7 @@ __device__ __forceinline__ void fast_pass(const uint64_t *__restrict__ T, int64_
     for (int sb = 0; sb < NB64; ++sb) {
         const uint64_t w64 = T[(int64_t)sb * Vpad + v];
         const int nb = min(64, N - sb * 64);
+#pragma unroll 2
         for (int b = 0; b < nb; ++b) {
             const int i = sb * 64 + b;
             const bool xb = (w64 >> b) & 1ull;
