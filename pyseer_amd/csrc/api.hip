@@ -64,6 +64,10 @@ struct sh_ctx {
     int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
     uint64_t *dd_h = nullptr; unsigned long long *dd_keys = nullptr; int *dd_idx = nullptr, *dd_rep = nullptr, *dd_slot = nullptr, *dd_n = nullptr;
     uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0;
+    // ---- pipelined host-pointer batches (host_batch)
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    uint8_t *hb_bits[2] = {nullptr, nullptr}; double *hb_out[2] = {nullptr, nullptr}; uint32_t *hb_flags[2] = {nullptr, nullptr};
+    int64_t hb_cap_bits = 0, hb_cap_out = 0;
     // ---- staging for the host-pointer entry points
     int64_t cap_bits = 0, cap_out = 0;
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
@@ -90,6 +94,66 @@ static int ensure_ws(sh_ctx *c, int64_t Vpad)
 }
 
 // Runs `inner` (sh_lmm_batch_dev / sh_glm_batch_dev body) on the distinct patterns only and fans the results out.
+static int ensure_staging(sh_ctx *c, int64_t bits_bytes, int64_t out_doubles, int64_t V)
+{
+    if (bits_bytes > c->cap_bits) { hipFree(c->d_bits); c->d_bits = nullptr; HIPCHK(hipMalloc((void **)&c->d_bits, bits_bytes)); c->cap_bits = bits_bytes; }
+    if (out_doubles > c->cap_out) {
+        hipFree(c->d_out); hipFree(c->d_flags); c->d_out = nullptr; c->d_flags = nullptr;
+        HIPCHK(dmalloc(&c->d_out, out_doubles)); HIPCHK(dmalloc(&c->d_flags, V)); c->cap_out = out_doubles;
+    }
+    return SH_OK;
+}
+
+// Host-pointer batches, pipelined: the packed rows of chunk i+1 cross PCIe on a copy stream while chunk i runs its kernels
+// on the compute stream (two device staging sets; the results of chunk i-1 are copied back after chunk i has been queued).
+// outs[a] receives row a of the (nrow x V) SoA result; rows >= 5 of the GLM result are delivered row-major through `betas`.
+template <typename F>
+static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, int nrow, double *const *outs, double *betas,
+                      int q, uint32_t *flags, F inner_dev)
+{
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t CH = 1 << 18;
+    const int64_t cap = std::min(CH, V);
+    if (!c->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) { HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming)); }
+    }
+    if (cap * row_bytes > c->hb_cap_bits || cap * nrow > c->hb_cap_out) {
+        for (int b = 0; b < 2; ++b) {
+            hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]);
+            c->hb_bits[b] = nullptr; c->hb_out[b] = nullptr; c->hb_flags[b] = nullptr;
+            HIPCHK(hipMalloc((void **)&c->hb_bits[b], cap * row_bytes)); HIPCHK(dmalloc(&c->hb_out[b], cap * nrow)); HIPCHK(dmalloc(&c->hb_flags[b], cap));
+        }
+        c->hb_cap_bits = cap * row_bytes; c->hb_cap_out = cap * nrow;
+    }
+    std::vector<double> tmp;
+    const int64_t nchunk = (V + CH - 1) / CH;
+    auto drain = [&](int64_t i) -> int {                 // chunk i's results: copy stream, after its kernels (not behind chunk i+1's)
+        const int b = (int)(i & 1);
+        const int64_t s = i * CH, n = std::min(CH, V - s);
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
+        for (int a = 0; a < 5; ++a)
+            HIPCHK(hipMemcpyAsync(outs[a] + s, c->hb_out[b] + (size_t)a * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
+        if (q > 0) { tmp.resize((size_t)q * n); HIPCHK(hipMemcpyAsync(tmp.data(), c->hb_out[b] + (size_t)5 * n, sizeof(double) * q * n, hipMemcpyDeviceToHost, c->copy_stream)); }
+        HIPCHK(hipMemcpyAsync(flags + s, c->hb_flags[b], sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+        for (int j = 0; j < q; ++j) for (int64_t v = 0; v < n; ++v) betas[(size_t)(s + v) * q + j] = tmp[(size_t)j * n + v];
+        return SH_OK;
+    };
+    for (int64_t i = 0; i < nchunk; ++i) {
+        const int b = (int)(i & 1);
+        const int64_t s = i * CH, n = std::min(CH, V - s);
+        // staging set b is free: chunk i-2 was drained (copy stream synchronised) before this point
+        HIPCHK(hipMemcpyAsync(c->hb_bits[b], bits + s * row_bytes, n * row_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(hipEventRecord(c->ev_h2d[b], c->copy_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
+        int rc = inner_dev(c->hb_bits[b], n, c->hb_out[b], c->hb_flags[b]); if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_done[b], c->stream));
+        if (i >= 1) { rc = drain(i - 1); if (rc) return rc; }
+    }
+    return drain(nchunk - 1);
+}
+
 static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 static int glm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 
@@ -165,6 +229,9 @@ void sh_destroy(sh_ctx *c)
     free_ws(c);
     hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0);
     hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);
+    for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    hipFree(c->dd_h); hipFree(c->dd_keys); hipFree(c->dd_idx); hipFree(c->dd_rep); hipFree(c->dd_slot); hipFree(c->dd_n); hipFree(c->dd_bits); hipFree(c->dd_out); hipFree(c->dd_flags);
     glm_free(&c->glm);
     delete c;
 }
@@ -387,35 +454,15 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     return SH_OK;
 }
 
-static int ensure_staging(sh_ctx *c, int64_t bits_bytes, int64_t out_doubles, int64_t V)
-{
-    if (bits_bytes > c->cap_bits) { hipFree(c->d_bits); c->d_bits = nullptr; HIPCHK(hipMalloc((void **)&c->d_bits, bits_bytes)); c->cap_bits = bits_bytes; }
-    if (out_doubles > c->cap_out) {
-        hipFree(c->d_out); hipFree(c->d_flags); c->d_out = nullptr; c->d_flags = nullptr;
-        HIPCHK(dmalloc(&c->d_out, out_doubles)); HIPCHK(dmalloc(&c->d_flags, V)); c->cap_out = out_doubles;
-    }
-    return SH_OK;
-}
-
 int sh_lmm_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, double *prep, double *pvalue,
                  double *beta, double *bse, double *frac_h2, uint32_t *flags)
 {
     if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
     if (!bits || !prep || !pvalue || !beta || !bse || !frac_h2 || !flags) return fail(SH_EINVAL, "null argument");
-    HIPCHK(hipSetDevice(c->device));
-    const int64_t CH = 1 << 20;
+    if (V <= 0) return SH_OK;
     double *outs[5] = {prep, pvalue, beta, bse, frac_h2};
-    for (int64_t s = 0; s < V; s += CH) {
-        const int64_t n = std::min(CH, V - s);
-        int rc = ensure_staging(c, n * row_bytes, std::min(CH, V) * 5, std::min(CH, V)); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->d_bits, bits + s * row_bytes, n * row_bytes, hipMemcpyHostToDevice, c->stream));
-        rc = sh_lmm_batch_dev(c, c->d_bits, row_bytes, n, c->d_out, c->d_flags); if (rc) return rc;
-        for (int a = 0; a < 5; ++a)
-            HIPCHK(hipMemcpyAsync(outs[a] + s, c->d_out + (size_t)a * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(flags + s, c->d_flags, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    return SH_OK;
+    return host_batch(c, bits, row_bytes, V, 5, outs, nullptr, 0, flags,
+                      [&](const void *b, int64_t n, void *o, void *f) { return sh_lmm_batch_dev(c, b, row_bytes, n, o, f); });
 }
 
 #include "glm_api_impl.inc"
