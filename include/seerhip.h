@@ -121,6 +121,18 @@ int sh_lineage_setup(sh_ctx *ctx, const double *lin, int l, const double *cov, i
 int sh_lineage_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V, int32_t *max_lineage);
 
 /* ---------------------------------------------------------------------------------------------
+ * Similarity (kinship) matrix from variant presence: replaces pyseer/similarity.py:99-113 (G assembled from
+ * load_var_block, pyseer/input.py:678-707, then np.matmul(G, G.T)).  K[i][j] = number of variants carried by both
+ * samples among those passing sh_set_af_filter (filtered variants are all-zero columns in the reference, input.py:690-697).
+ * sh_sim_begin zeroes the accumulator; accumulate any number of batches (host or device rows, same packed layout as
+ * sh_lmm_batch); sh_sim_finish writes the dense N*N row-major fp64 matrix (exact integers) to host memory.
+ * --------------------------------------------------------------------------------------------- */
+int sh_sim_begin(sh_ctx *ctx);
+int sh_sim_accumulate(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V);
+int sh_sim_accumulate_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V);
+int sh_sim_finish(sh_ctx *ctx, double *K);
+
+/* ---------------------------------------------------------------------------------------------
  * Native k-mer text reader / packer (host code; replaces the k-mer branch of pyseer/input.py:301 read_variant for the GPU
  * feed).  Lines "KMER | sample:count sample:count ..." (gzip or plain) -> packed presence rows over `sample_names`
  * (= p.index, phenotype order), carrier counts (af = count / n, input.py:446) and the variant names.

@@ -189,3 +189,13 @@ def lineage_effect(lin, cov, k):
     c = _d(np.asarray(cov).reshape(n, -1)) if j else np.zeros(1)
     r = lib().orc_lineage_effect(_p(lin), l, _p(c), j, _p(k), n)
     return None if r < 0 else int(r)
+
+
+def similarity(Kv, min_af=0.0, max_af=1.0):
+    """pyseer/similarity.py:99-113 over load_var_block (pyseer/input.py:678-707): variants failing `af < min_af or af > max_af`
+    stay all-zero columns of G; K = G G^T.  Kv: (V, n) 0/1 variant-major."""
+    Kv = np.asarray(Kv, dtype=np.float64)
+    V, n = Kv.shape
+    af = Kv.sum(axis=1) / n
+    G = np.where(((af < min_af) | (af > max_af))[:, None], 0.0, Kv).T
+    return np.matmul(G, G.T)

@@ -38,6 +38,10 @@ SIGNATURES = {
     "sh_glm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
     "sh_lineage_setup": (C.c_int, [C.c_void_p, c_dp, C.c_int, c_dp, C.c_int]),
     "sh_lineage_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
+    "sh_sim_begin": (C.c_int, [C.c_void_p]),
+    "sh_sim_accumulate": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64]),
+    "sh_sim_accumulate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "sh_sim_finish": (C.c_int, [C.c_void_p, c_dp]),
     "sh_reader_open": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
     "sh_reader_close": (None, [C.c_void_p]),
     "sh_reader_error": (C.c_char_p, []),

@@ -15,6 +15,9 @@ struct LmmFinParams {
     double min_af, max_af; int af_on;
 };
 extern "C" {
+hipError_t shk_sim_accumulate(hipStream_t st, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64, double min_af, double max_af,
+                              int af_on, uint64_t *keep, uint64_t *S, int NS, unsigned long long *Kacc);
+hipError_t shk_sim_finish(hipStream_t st, const unsigned long long *Kacc, int NS, int N, double *K);
 hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
@@ -64,6 +67,8 @@ struct sh_ctx {
     int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
     uint64_t *dd_h = nullptr; unsigned long long *dd_keys = nullptr; int *dd_idx = nullptr, *dd_rep = nullptr, *dd_slot = nullptr, *dd_n = nullptr;
     uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0;
+    // ---- similarity accumulation (sim_kernels.hip)
+    unsigned long long *sim_K = nullptr; uint64_t *sim_S = nullptr, *sim_keep = nullptr; double *sim_out = nullptr; int64_t sim_capV = 0; int NS = 0;
     // ---- pipelined host-pointer batches (host_batch)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     uint8_t *hb_bits[2] = {nullptr, nullptr}; double *hb_out[2] = {nullptr, nullptr}; uint32_t *hb_flags[2] = {nullptr, nullptr};
@@ -232,6 +237,7 @@ void sh_destroy(sh_ctx *c)
     for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     hipFree(c->dd_h); hipFree(c->dd_keys); hipFree(c->dd_idx); hipFree(c->dd_rep); hipFree(c->dd_slot); hipFree(c->dd_n); hipFree(c->dd_bits); hipFree(c->dd_out); hipFree(c->dd_flags);
+    hipFree(c->sim_K); hipFree(c->sim_S); hipFree(c->sim_keep); hipFree(c->sim_out);
     glm_free(&c->glm);
     delete c;
 }
@@ -463,6 +469,69 @@ int sh_lmm_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, d
     double *outs[5] = {prep, pvalue, beta, bse, frac_h2};
     return host_batch(c, bits, row_bytes, V, 5, outs, nullptr, 0, flags,
                       [&](const void *b, int64_t n, void *o, void *f) { return sh_lmm_batch_dev(c, b, row_bytes, n, o, f); });
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// Similarity (kinship) matrix: pyseer/similarity.py:99-113  K = G G^T over the AF-kept variants.
+// -------------------------------------------------------------------------------------------------------------
+int sh_sim_begin(sh_ctx *c)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    c->NS = (c->N + 127) / 128 * 128;
+    if (!c->sim_K) HIPCHK(dmalloc(&c->sim_K, (size_t)c->NS * c->NS));
+    HIPCHK(hipMemsetAsync(c->sim_K, 0, sizeof(unsigned long long) * (size_t)c->NS * c->NS, c->stream));
+    return SH_OK;
+}
+
+int sh_sim_accumulate_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V)
+{
+    if (!c || !c->sim_K) return fail(SH_EINVAL, "sh_sim_begin has not run");
+    if (!d_bits) return fail(SH_EINVAL, "null argument");
+    if (row_bytes * 8 < c->N) return fail(SH_ESHAPE, "row_bytes too small for n_samples");
+    if (V <= 0) return SH_OK;
+    if (V > ((int64_t)1 << 31)) return fail(SH_EINVAL, "at most 2^31 variants per call (32-bit partial counts)");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t Vpad = (V + 511) / 512 * 512;
+    int rc = ensure_ws(c, Vpad); if (rc) return rc;
+    if (Vpad > c->sim_capV) {
+        hipFree(c->sim_S); hipFree(c->sim_keep); c->sim_S = nullptr; c->sim_keep = nullptr;
+        const int64_t VWp = (Vpad / 64 + 15) / 16 * 16;
+        HIPCHK(dmalloc(&c->sim_S, (size_t)VWp * c->NS)); HIPCHK(dmalloc(&c->sim_keep, (size_t)VWp));
+        c->sim_capV = Vpad;
+    }
+    HIPCHK(shk_repack_bits(c->stream, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
+    HIPCHK(shk_sim_accumulate(c->stream, c->d_T, Vpad, V, c->N, c->NB64, c->min_af, c->max_af, c->af_on, c->sim_keep, c->sim_S, c->NS, c->sim_K));
+    return SH_OK;
+}
+
+int sh_sim_accumulate(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V)
+{
+    if (!c || !c->sim_K) return fail(SH_EINVAL, "sh_sim_begin has not run");
+    if (!bits) return fail(SH_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t CH = 1 << 20;
+    for (int64_t s = 0; s < V; s += CH) {
+        const int64_t n = std::min(CH, V - s);
+        int rc = ensure_staging(c, n * row_bytes, 0, 0); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_bits, bits + s * row_bytes, n * row_bytes, hipMemcpyHostToDevice, c->stream));
+        rc = sh_sim_accumulate_dev(c, c->d_bits, row_bytes, n); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SH_OK;
+}
+
+int sh_sim_finish(sh_ctx *c, double *K)
+{
+    if (!c || !c->sim_K) return fail(SH_EINVAL, "sh_sim_begin has not run");
+    if (!K) return fail(SH_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)c->N * c->N;
+    if (!c->sim_out) HIPCHK(dmalloc(&c->sim_out, n));
+    HIPCHK(shk_sim_finish(c->stream, c->sim_K, c->NS, c->N, c->sim_out));
+    HIPCHK(hipMemcpyAsync(K, c->sim_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SH_OK;
 }
 
 #include "glm_api_impl.inc"

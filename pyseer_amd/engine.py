@@ -159,6 +159,24 @@ class Engine(object):
                                                   out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
+    # ---- similarity (kinship) accumulation: pyseer/similarity.py:99-113
+    def sim_begin(self):
+        _abi.check(self._lib.sh_sim_begin(self._h))
+
+    def sim_accumulate(self, bits):
+        bits = self._bits(bits)
+        if bits.shape[0]:
+            _abi.check(self._lib.sh_sim_accumulate(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], bits.shape[0]))
+
+    def sim_accumulate_dev(self, bits_t):
+        V, rb = bits_t.shape
+        _abi.check(self._lib.sh_sim_accumulate_dev(self._h, C.c_void_p(bits_t.data_ptr()), rb, V))
+
+    def sim_finish(self):
+        K = np.empty((self.n, self.n), dtype=np.float64)
+        _abi.check(self._lib.sh_sim_finish(self._h, K.ctypes.data_as(_abi.c_dp)))
+        return K
+
     def glm_info(self):
         a = C.c_int64(); b = C.c_int64()
         _abi.check(self._lib.sh_glm_info(self._h, C.byref(a), C.byref(b)))

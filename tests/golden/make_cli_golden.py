@@ -93,3 +93,16 @@ for name, args in CASES.items():
         lf = args[args.index("--lineage-file") + 1]
         shutil.move(os.path.join(CLI, lf), os.path.join(EXP, lf))
 json.dump(CASES, open(os.path.join(CLI, "cases.json"), "w"), indent=1)
+
+# ---- the reference's `similarity` script (pyseer/similarity.py) on the same fixtures
+shutil.copy(os.path.join(REF, "samples.txt"), os.path.join(CLI, "samples50.txt"))
+SIM_CASES = {
+    "similarity_kmers": ["samples50.txt", "--kmers", K],
+    "similarity_rtab": ["samples50.txt", "--pres", R, "--min-af", "0.1", "--max-af", "0.8"],
+}
+for name, args in SIM_CASES.items():
+    r = subprocess.run([sys.executable, "-W", "ignore", os.path.join(HERE, "_harness", "run_similarity.py")] + args, cwd=CLI, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, (name, r.stderr.decode()[-500:])
+    open(os.path.join(EXP, name + ".tsv"), "wb").write(r.stdout)
+    open(os.path.join(EXP, name + ".err"), "wb").write(r.stderr)
