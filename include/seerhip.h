@@ -149,6 +149,19 @@ int64_t     sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, in
 /* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */
 int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);
 
+/* ---------------------------------------------------------------------------------------------
+ * Result sink: array-backed results -> the reference's TSV rows (pyseer/utils.py:39-105 format_output, the print loop of
+ * pyseer/__main__.py:805-827).  CPU only (OpenMP).  For every selected row v = sel[r], in order:
+ *   name \t cols[0][v] \t ... \t cols[ncol-1][v] [\t betas[v*q .. v*q+q) if betas_valid[v]] [\t label | NA] \t notes \n
+ * numbers as '%.2E', non-finite -> empty field; notes = names of flag bits 0..8 joined by ','.
+ * names/name_off: concatenated variant names as sh_reader_next delivers them.  lineage may be NULL (no column).
+ * Returns the number of bytes written, or -(needed+1) when cap is too small (nothing written), -1 on bad arguments.
+ * --------------------------------------------------------------------------------------------- */
+int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t *sel, int64_t nsel,
+                       const double *const *cols, int ncol, const double *betas, int q, const uint8_t *betas_valid,
+                       const int32_t *lineage, const char *const *lineage_labels, int n_labels,
+                       const uint32_t *flags, char *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

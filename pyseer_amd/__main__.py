@@ -80,6 +80,8 @@ def get_options(argv=None):
                     help='Test every variant separately [Default: each distinct presence pattern of a block is tested once]')
     ot.add_argument('--python-reader', action='store_true', default=False,
                     help='Parse k-mer files with the Python reader instead of the native C++ one')
+    ot.add_argument('--python-sink', action='store_true', default=False,
+                    help='Format every output row in Python (one result tuple per variant) instead of the native block sink')
     ot.add_argument('--lmm-lineage-per-variant', action='store_true', default=False,
                     help='With --lmm --lineage, fit the lineage effect of each variant itself. [Default: reproduce the reference, '
                          'which fits the LAST variant of each block for every variant of that block]')
@@ -280,11 +282,80 @@ def main(argv=None):
     else:
         blocks = iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
                                     options.max_missing, options.uncompressed, options.block_size)
+    # ---- block sink (csrc/writer.cpp): results stay arrays from the engine to the TSV text; the per-variant tuple path below
+    # is kept for --print-samples, for variants carrying missing calls, and as the cross-check (--python-sink)
+    from .sink import RowFormatter, names_blob
+    from .packing import pack_variants
+    formatter = RowFormatter(lineage_dict if options.lineage else None)
+    NOTE_AF, NOTE_FIRTH_FAIL = 1, 1 << 6
+    q_out = 0
+
+    def sink_block(blk, r):
+        nonlocal prefilter, tested, printed
+        nb = len(blk.names)
+        status = np.asarray(blk.status, dtype=np.int64)
+        on = status == 0
+        j = np.asarray(blk.row_of, dtype=np.int64)[on]
+        flags = np.zeros(nb, dtype=np.uint32)
+        flags[status == 1] = NOTE_AF | FLAG_PREFILTER
+        keys = ("prep", "pvalue", "beta", "bse", "frac_h2") if options.lmm else ("prep", "pvalue", "kbeta", "bse", "intercept")
+        cols = [np.asarray(blk.afs, dtype=np.float64)]
+        for kname in keys:
+            c = np.full(nb, np.nan)
+            if r is not None:
+                c[on] = r[kname][j]
+            cols.append(c)
+        betas = valid = None
+        if r is not None:
+            flags[on] = r["flags"][j]
+            if not options.lmm and r["betas"].shape[1]:
+                betas = np.full((nb, r["betas"].shape[1]), np.nan)
+                betas[on] = r["betas"][j]
+                valid = np.zeros(nb, dtype=np.uint8)
+                valid[on] = np.isfinite(r["kbeta"][j]) | np.isfinite(r["pvalue"][j])
+        pf = (flags & FLAG_PREFILTER) != 0
+        ft = (flags & FLAG_FILTER) != 0
+        lineage = None
+        if options.lineage:
+            lineage = np.full(nb, -1, dtype=np.int32)
+            if options.lmm and not options.lmm_lineage_per_variant:
+                kl = blk.last_k                      # pyseer/lmm.py:209-213: the stale `k` of fit_lmm's first loop
+                ml = -1
+                if kl is not None and not np.isnan(np.asarray(kl, dtype=float)).any():
+                    ml = int(eng.lineage_batch(pack_variants(np.asarray(kl).reshape(1, -1)))[0])
+                lineage[~pf & ~ft] = ml
+            else:
+                need = on & ~pf & (~ft if options.lmm else ((flags & NOTE_FIRTH_FAIL) == 0))
+                if need.any():
+                    lineage[need] = eng.lineage_batch(blk.bits[np.asarray(blk.row_of, dtype=np.int64)[need]])
+        order = np.arange(nb)
+        if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
+            order = np.concatenate([order[pf], order[~pf]])
+        npf = int(pf.sum())
+        prefilter += npf
+        tested += nb - npf
+        if patterns is not None:
+            patterns.write(b''.join(blk.patterns[i] for i in order if not pf[i]))
+        show = np.ones(nb, dtype=bool) if options.print_filtered else (~pf & ~ft)
+        sel = order[show[order]]
+        printed += int(sel.shape[0])
+        if sel.shape[0]:
+            blob, off = (blk.names_blob, blk.name_off) if getattr(blk, "names_blob", None) is not None else names_blob(blk.names)
+            text = formatter.format(blob, off, sel, cols, flags, betas, valid, lineage)
+            if hasattr(sys.stdout, "buffer"):
+                sys.stdout.flush()
+                sys.stdout.buffer.write(text)
+            else:
+                sys.stdout.write(text.decode())
+
     for blk in blocks:
         if options.lmm:
             r = mask_like_fit_lmm(eng.lmm_batch(blk.bits)) if blk.bits.shape[0] else None
         else:
             r = eng.glm_batch(blk.bits) if blk.bits.shape[0] else None
+        if not options.python_sink and not options.print_samples and 2 not in blk.status:
+            sink_block(blk, r)
+            continue
         rows = []
         for i, name in enumerate(blk.names):
             st, af, ks, nks = blk.status[i], blk.afs[i], blk.kstrains[i], blk.nkstrains[i]

@@ -1,0 +1,75 @@
+// writer.cpp -- native result sink: array-backed results -> the reference's TSV rows.
+//
+// Replaces the per-row Python of pyseer/utils.py:39-105 (format_output) and the print loop of pyseer/__main__.py:805-827:
+//   variant \t af \t filter-pvalue \t lrt-pvalue \t beta \t beta-std-err \t (variant_h2 | intercept [\t covariate betas...])
+//   [\t lineage] \t notes
+// numbers as '%.2E' (utils.py:60-75: '%.2E' % Decimal(x), i.e. the correctly rounded 3-significant-digit form, which glibc's
+// printf also produces), non-finite -> empty field; lineage label or NA; notes joined by ',' in the flag-bit order of
+// include/seerhip.h.  Rows are formatted in parallel (OpenMP) into per-thread buffers and concatenated in order.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../../include/seerhip.h"
+
+static const char *const kNotes[9] = {"af-filter", "pre-filtering-failed", "bad-chisq", "high-bse", "perfectly-separable-data",
+                                      "matrix-inversion-error", "firth-fail", "missing-data-error", "lrt-filtering-failed"};
+
+static inline void put_num(std::string &s, double x)
+{
+    if (std::isfinite(x)) { char b[40]; const int n = snprintf(b, sizeof b, "%.2E", x); s.append(b, (size_t)n); }
+}
+
+extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t *sel, int64_t nsel,
+                                  const double *const *cols, int ncol, const double *betas, int q, const uint8_t *betas_valid,
+                                  const int32_t *lineage, const char *const *lineage_labels, int n_labels,
+                                  const uint32_t *flags, char *out, int64_t cap)
+{
+    if (!names || !name_off || !sel || !cols || !flags || nsel < 0 || ncol < 1) return -1;
+    if (q > 0 && (!betas || !betas_valid)) return -1;
+    int nth = 1;
+#ifdef _OPENMP
+    nth = omp_get_max_threads();
+#endif
+    if (nsel < 4096) nth = 1;
+    std::vector<std::string> parts((size_t)nth);
+#pragma omp parallel num_threads(nth)
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        const int64_t lo = nsel * t / nth, hi = nsel * (t + 1) / nth;
+        std::string &s = parts[(size_t)t];
+        s.reserve((size_t)(hi - lo) * 96);
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t v = sel[r];
+            s.append(names + name_off[v], (size_t)(name_off[v + 1] - name_off[v]));
+            for (int c = 0; c < ncol; ++c) { s.push_back('\t'); put_num(s, cols[c][v]); }
+            if (q > 0 && betas_valid[v])
+                for (int j = 0; j < q; ++j) { s.push_back('\t'); put_num(s, betas[(size_t)v * q + j]); }
+            if (lineage) {
+                s.push_back('\t');
+                const int32_t l = lineage[v];
+                if (l >= 0 && l < n_labels) s.append(lineage_labels[l]); else s.append("NA");
+            }
+            s.push_back('\t');
+            const uint32_t f = flags[v];
+            bool first = true;
+            for (int b = 0; b < 9; ++b)
+                if ((f >> b) & 1u) { if (!first) s.push_back(','); s.append(kNotes[b]); first = false; }
+            s.push_back('\n');
+        }
+    }
+    int64_t total = 0;
+    for (auto &p : parts) total += (int64_t)p.size();
+    if (!out || total > cap) return -(total + 1);       // caller retries with at least `total` bytes
+    char *w = out;
+    for (auto &p : parts) { memcpy(w, p.data(), p.size()); w += p.size(); }
+    return total;
+}

@@ -251,13 +251,15 @@ def iter_variants_lmm(variant_iter, lmm, h2, lineage, lineage_clusters, covariat
 # ---------------------------------------------------------------------------------------------------------------
 class PackedBlock(object):
     """One block of parsed variants: metadata lists + packed presence rows for those that reach the engine."""
-    __slots__ = ("names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks", "last_k")
+    __slots__ = ("names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks", "last_k",
+                 "names_blob", "name_off")
 
     def __init__(self, n_samples, capacity):
         self.names, self.patterns, self.afs, self.kstrains, self.nkstrains = [], [], [], [], []
         self.status = []            # 0 = to engine, 1 = af/missing filtered, 2 = carries missing calls (NaN in k)
         self.ks = []                # the dense k only for status 2 (host-side handling of the error path)
         self.row_of = []            # row in self.bits, or -1
+        self.names_blob = self.name_off = None     # concatenated names + offsets when the native reader supplied them
         self.last_k = None          # dense k of the LAST variant parsed into the block (see __main__: lmm.py:209-213)
         self.bits = np.zeros((capacity, row_bytes_for(n_samples)), dtype=np.uint8)
 
@@ -342,6 +344,7 @@ class NativeKmerReader(object):
                 return
             raw = self._names.raw
             names = [raw[self._off[v]:self._off[v + 1]].decode() for v in range(nv)]
+            self.last_blob, self.last_off = raw[:self._off[nv]], self._off[:nv + 1].copy()      # for the block sink
             yield names, bits[:nv], counts[:nv]
 
 
@@ -358,8 +361,10 @@ def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns
     samples = [str(x) for x in p.index]
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
-    for names, bits, counts in NativeKmerReader(path, samples, block_size):
+    reader = NativeKmerReader(path, samples, block_size)
+    for names, bits, counts in reader:
         blk = PackedBlock(n, 0)
+        blk.names_blob, blk.name_off = reader.last_blob, reader.last_off
         afs = counts.astype(np.float64) / n
         keep = (afs >= min_af) & (afs <= max_af)
         blk.names = names

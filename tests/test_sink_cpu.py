@@ -1,0 +1,69 @@
+"""Native result sink (csrc/writer.cpp, sh_format_rows) against the per-row formatter (pyseer_amd/utils.format_output, itself
+checked against the reference's logs by the CLI goldens)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _cols(rng, n, k):
+    cols = [10.0 ** rng.uniform(-320, 300, n) * rng.choice([-1, 1], n) for _ in range(k)]
+    for c in cols:
+        c[rng.random(n) < 0.1] = np.nan
+    cols[2][5] = np.inf; cols[1][7] = 0.0; cols[3][8] = 9.995e-5; cols[3][9] = 1.005; cols[3][10] = -0.0
+    cols[0][11] = 5e-324; cols[0][12] = 1.7976931348623157e308; cols[4][13] = 0.5; cols[4][14] = 9.995; cols[4][15] = 99949.99999
+    return cols
+
+
+def test_lmm_rows_match_format_output():
+    from pyseer_amd.sink import RowFormatter, names_blob
+    from pyseer_amd.utils import format_output
+    from pyseer_amd.classes import LMM, notes_from_flags
+    rng = np.random.default_rng(0)
+    n = 12000                                                 # > 4096: exercises the multi-threaded concatenation
+    names = ["K%d_%s" % (i, "ACGT" * (i % 7)) for i in range(n)]
+    cols = _cols(rng, n, 6)
+    flags = rng.integers(0, 512, n).astype(np.uint32) | (rng.integers(0, 4, n).astype(np.uint32) << 16)
+    lin = rng.integers(-1, 3, n).astype(np.int32)
+    labels = ["a", "bb", "c"]
+    blob, off = names_blob(names)
+    sel = rng.permutation(n)[:9000]
+    txt = RowFormatter(labels).format(blob, off, sel, cols, flags, lineage=lin).decode().split("\n")
+    assert txt[-1] == "" and len(txt) == len(sel) + 1
+    for r, v in enumerate(sel):
+        x = LMM(names[v], None, cols[0][v], cols[1][v], cols[2][v], cols[3][v], cols[4][v], cols[5][v],
+                None if lin[v] < 0 else int(lin[v]), [], [], notes_from_flags(flags[v]), False, False)
+        assert format_output(x, labels, 'lmm', False) == txt[r]
+
+
+def test_seer_rows_with_and_without_betas():
+    from pyseer_amd.sink import RowFormatter, names_blob
+    from pyseer_amd.utils import format_output
+    from pyseer_amd.classes import Seer, notes_from_flags
+    rng = np.random.default_rng(1)
+    n, q = 500, 4
+    names = ["v%d" % i for i in range(n)]
+    cols = _cols(rng, n, 6)
+    betas = rng.normal(size=(n, q)); betas[3, 1] = np.nan
+    valid = (rng.random(n) < 0.7).astype(np.uint8)
+    flags = rng.integers(0, 512, n).astype(np.uint32)
+    blob, off = names_blob(names)
+    sel = np.arange(n)
+    txt = RowFormatter().format(blob, off, sel, cols, flags, betas, valid).decode().split("\n")
+    for v in range(n):
+        x = Seer(names[v], None, cols[0][v], cols[1][v], cols[2][v], cols[3][v], cols[4][v], cols[5][v],
+                 betas[v] if valid[v] else np.array([]), None, [], [], notes_from_flags(flags[v]), False, False)
+        assert format_output(x, None, 'seer', False) == txt[v]
+    assert RowFormatter().format(blob, off, np.zeros(0, dtype=np.int64), cols, flags) == b''
+
+
+def test_small_buffer_is_regrown():
+    from pyseer_amd.sink import RowFormatter, names_blob
+    import ctypes as C
+    names = ["x" * 300 for _ in range(50)]
+    blob, off = names_blob(names)
+    f = RowFormatter(); f._buf = C.create_string_buffer(16)
+    out = f.format(blob, off, np.arange(50), [np.zeros(50)], np.zeros(50, dtype=np.uint32))
+    assert out.count(b"\n") == 50 and out.startswith(b"x" * 300 + b"\t0.00E+00\t\n")
