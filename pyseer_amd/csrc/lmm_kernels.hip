@@ -241,19 +241,10 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
         wb[0][1] = *reinterpret_cast<const uint64_t *>(a_base + boff + 256);
         wb[1][0] = *reinterpret_cast<const uint64_t *>(a_base + boff + QF_BN * 8);
         wb[1][1] = *reinterpret_cast<const uint64_t *>(a_base + boff + QF_BN * 8 + 256);
-        v4i a_cur[4], a_nxt[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            a_cur[it] = (ABL & 2) ? (v4i){it, lane, s, 1} : *reinterpret_cast<const v4i *>(a_base + aoff[it][0]);
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {                          // sub = tile(0/1) * 2 + k-half(0/1)
-            if (sub < 3) {
-                const int nt = (sub + 1) >> 1, nk = (sub + 1) & 1;
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    a_nxt[it] = (ABL & 2) ? (v4i){it, lane, nt, nk}
-                                          : *reinterpret_cast<const v4i *>(a_base + nt * QF_TILE_BYTES + aoff[it][nk]);
-            }
+        // Software pipeline over the four 32-deep sub-steps (sub = tile(0/1) * 2 + k-half(0/1)): the A fragments AND the expanded
+        // variant fragments of sub-step k+1 are produced while the 8 MFMAs of sub-step k issue; sched_barrier(0) closes each
+        // sub-step so that hipcc cannot sink the LDS reads next to their consumers (it then waits lgkmcnt(0) before every MFMA).
+        auto expand = [&](int sub, v4i (&b)[2]) {
             const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
             uint4 e0, e1;
             if (ABL & 4) { e0 = make_uint4((uint32_t)wb[tl][0], ch, 1, 0); e1 = make_uint4((uint32_t)wb[tl][1], ch, 0, 1); }
@@ -261,20 +252,34 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
                 e0 = qf_expand16((uint32_t)(wb[tl][0] >> (16 * ch)) & 0xFFFFu);
                 e1 = qf_expand16((uint32_t)(wb[tl][1] >> (16 * ch)) & 0xFFFFu);
             }
-            v4i b[2];
             b[0] = (v4i){(int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w};
             b[1] = (v4i){(int)e1.x, (int)e1.y, (int)e1.z, (int)e1.w};
+        };
+        v4i a_cur[4], a_nxt[4], b_cur[2], b_nxt[2];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            a_cur[it] = (ABL & 2) ? (v4i){it, lane, s, 1} : *reinterpret_cast<const v4i *>(a_base + aoff[it][0]);
+        expand(0, b_cur);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub < 3) {
+                const int nt = (sub + 1) >> 1, nk = (sub + 1) & 1;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    a_nxt[it] = (ABL & 2) ? (v4i){it, lane, nt, nk}
+                                          : *reinterpret_cast<const v4i *>(a_base + nt * QF_TILE_BYTES + aoff[it][nk]);
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt)
-                    acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[it], b[jt], acc[it][jt], 0, 0, 0);
-            // pin the issue order: next fragments' LDS reads first, then the 8 MFMAs (hipcc otherwise sinks each ds_read to just
-            // before its consumer and waits lgkmcnt(0) in front of every MFMA pair)
-            if (sub < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[it], b_cur[jt], acc[it][jt], 0, 0, 0);
+            if (sub < 3) expand(sub + 1, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int it = 0; it < 4; ++it) a_cur[it] = a_nxt[it];
+            b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
         }
         if (++slot == QF_NST) slot = 0;
         if (++cst == cI + 1) {
