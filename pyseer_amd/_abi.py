@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseerhip.so")
+LIB_PATH = os.environ.get("SEERHIP_LIB") or os.path.join(_HERE, "libseerhip.so")      # SEERHIP_LIB: A/B builds (development)
 
 SH_OK, SH_EINVAL, SH_ENODEV, SH_ENOMEM, SH_EH2, SH_ESHAPE, SH_EHIP = 0, -1, -2, -3, -4, -5, -6
 

@@ -146,8 +146,11 @@ __device__ __forceinline__ uint4 qf_expand16(uint32_t bits16)
     return r;
 }
 
-#define QF_NST 4                     // LDS ring depth (stages)
-#define QF_AHEAD (QF_NST - 1)        // stages of DMA in flight
+#ifndef QF_G_AUX
+#define QF_G_AUX 0
+#endif
+#define QF_NST 5                     // LDS ring depth (stages): s (computing), s+1 (landed, prefetched from), s+2..s+4 in flight
+#define QF_AHEAD (QF_NST - 1)        // stages issued ahead of the compute cursor
 #define QF_STAGE_BYTES (2 * QF_TILE_BYTES + 2 * QF_BN * 8)      // 16 KB of G + 8 KB of packed bits = 24 KB
 
 // one stage HBM/L2 -> LDS by LDS-DMA, 3 wave-instructions of 1 KB per wave: two for the G tiles, one for the block's packed
@@ -158,7 +161,7 @@ __device__ __forceinline__ void qf_dma_stage(const int8_t *gsrc, const uint64_t 
     for (int j = 0; j < 2; ++j) {
         const int piece = wave * 2 + j;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void *)(slot + piece * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(slot + piece * 1024), 16, 0, QF_G_AUX);
     }
     // bits: row (wave>>2) of the stage's two sample blocks, variants [(wave&3)*128, +128) of the block, 2 words per lane
     const uint64_t *src = tsrc + (int64_t)(wave >> 2) * Vpad + (wave & 3) * 128 + lane * 2;
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
     auto fetch = [&]() {
         const int8_t *g = G + ((int64_t)(lgrp + pl * lsplit) * TL + (int64_t)pI * (pI + 1) + 2 * pst) * QF_TILE_BYTES;
         const uint64_t *t = T + (int64_t)(2 * pst) * Vpad + v0;
+        if (ABL & 8) { g = G; t = T + v0; }                          // ablation: every stage re-reads the same 24 KB (cache-resident)
         if (!(ABL & 1)) qf_dma_stage(g, t, Vpad, smem + pslot * QF_STAGE_BYTES, wave, lane);
         if (++pslot == QF_NST) pslot = 0;
         if (++pst == pI + 1) { pst = 0; if (++pl == nl) { pl = 0; ++pI; } }
@@ -212,21 +216,50 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
 #pragma unroll 1
     for (int s = 0; s < QF_AHEAD && s < total; ++s) fetch();
 
-    // barrier_s: every wave's pieces of stage s have landed and nobody reads stage s-1 any more, so its slot is refilled with
-    // stage s + QF_AHEAD.  (Tried and measured slower, +1.4 % / +3 %: taking the barrier half a stage apart on the two waves that
-    // share a SIMD -- w, w+4 or w, w^1 -- over a 5-slot ring; the stalls are not a phase-alignment effect.)
+    // barrier_s: every wave's pieces of stages <= s+1 have landed and nobody reads stage s-1 any more, so its slot is refilled
+    // with stage s + QF_AHEAD.  Landing one stage EARLY lets the last sub-step of stage s prefetch the first fragments and bit
+    // words of stage s+1, so no wave starts a stage by waiting on LDS.  (Tried and measured slower, +1.4 % / +3 %: taking the
+    // barrier half a stage apart on the two waves that share a SIMD; the stalls are not a phase-alignment effect.)
     auto sync_refill = [&](int s) {
-        const int newer = min(total - 1 - s, QF_AHEAD - 1);
+        const int newer = max(0, min(total - 2 - s, 2));           // stages allowed to be still in flight: s+2, s+3
         if (!(ABL & 1)) { if (newer >= 2) qf_wait_vm<6>(); else if (newer == 1) qf_wait_vm<3>(); else qf_wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + QF_AHEAD < total) fetch();
     };
+    auto read_bits = [&](const char *base, uint64_t (&w)[2][2]) {
+        w[0][0] = *reinterpret_cast<const uint64_t *>(base + boff);
+        w[0][1] = *reinterpret_cast<const uint64_t *>(base + boff + 256);
+        w[1][0] = *reinterpret_cast<const uint64_t *>(base + boff + QF_BN * 8);
+        w[1][1] = *reinterpret_cast<const uint64_t *>(base + boff + QF_BN * 8 + 256);
+    };
+    auto expand = [&](const uint64_t (&w)[2][2], int sub, v4i (&b)[2]) {
+        const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
+        uint4 e0, e1;
+        if (ABL & 4) { e0 = make_uint4((uint32_t)w[tl][0], ch, 1, 0); e1 = make_uint4((uint32_t)w[tl][1], ch, 0, 1); }
+        else {
+            e0 = qf_expand16((uint32_t)(w[tl][0] >> (16 * ch)) & 0xFFFFu);
+            e1 = qf_expand16((uint32_t)(w[tl][1] >> (16 * ch)) & 0xFFFFu);
+        }
+        b[0] = (v4i){(int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w};
+        b[1] = (v4i){(int)e1.x, (int)e1.y, (int)e1.z, (int)e1.w};
+    };
+
+    // Software pipeline over the 32-deep sub-steps (sub = tile(0/1) * 2 + k-half(0/1)), continuous ACROSS stages: the A fragments
+    // and the expanded variant fragments of the next sub-step are produced while the 8 MFMAs of the current one issue;
+    // sched_barrier(0) closes each sub-step so that hipcc cannot sink the LDS reads next to their consumers.
+    uint64_t wb[2][2], wbn[2][2];
+    v4i a_cur[4], a_nxt[4], b_cur[2], b_nxt[2];
+    sync_refill(0);
+    read_bits(smem, wb);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) a_cur[it] = (ABL & 2) ? (v4i){it, lane, 0, 1} : *reinterpret_cast<const v4i *>(smem + aoff[it][0]);
+    expand(wb, 0, b_cur);
 
     int slot = 0;
 #pragma unroll 1
     for (int s = 0; s < total; ++s) {
-        sync_refill(s);
+        if (s > 0) sync_refill(s);
         if (cst == 0) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
@@ -236,30 +269,7 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
                     for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0;
         }
         const char *a_base = smem + slot * QF_STAGE_BYTES;
-        uint64_t wb[2][2];
-        wb[0][0] = *reinterpret_cast<const uint64_t *>(a_base + boff);
-        wb[0][1] = *reinterpret_cast<const uint64_t *>(a_base + boff + 256);
-        wb[1][0] = *reinterpret_cast<const uint64_t *>(a_base + boff + QF_BN * 8);
-        wb[1][1] = *reinterpret_cast<const uint64_t *>(a_base + boff + QF_BN * 8 + 256);
-        // Software pipeline over the four 32-deep sub-steps (sub = tile(0/1) * 2 + k-half(0/1)): the A fragments AND the expanded
-        // variant fragments of sub-step k+1 are produced while the 8 MFMAs of sub-step k issue; sched_barrier(0) closes each
-        // sub-step so that hipcc cannot sink the LDS reads next to their consumers (it then waits lgkmcnt(0) before every MFMA).
-        auto expand = [&](int sub, v4i (&b)[2]) {
-            const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
-            uint4 e0, e1;
-            if (ABL & 4) { e0 = make_uint4((uint32_t)wb[tl][0], ch, 1, 0); e1 = make_uint4((uint32_t)wb[tl][1], ch, 0, 1); }
-            else {
-                e0 = qf_expand16((uint32_t)(wb[tl][0] >> (16 * ch)) & 0xFFFFu);
-                e1 = qf_expand16((uint32_t)(wb[tl][1] >> (16 * ch)) & 0xFFFFu);
-            }
-            b[0] = (v4i){(int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w};
-            b[1] = (v4i){(int)e1.x, (int)e1.y, (int)e1.z, (int)e1.w};
-        };
-        v4i a_cur[4], a_nxt[4], b_cur[2], b_nxt[2];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            a_cur[it] = (ABL & 2) ? (v4i){it, lane, s, 1} : *reinterpret_cast<const v4i *>(a_base + aoff[it][0]);
-        expand(0, b_cur);
+        const char *n_base = smem + (slot + 1 == QF_NST ? 0 : slot + 1) * QF_STAGE_BYTES;     // stage s+1 (landed as of barrier_s)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -269,13 +279,18 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
                 for (int it = 0; it < 4; ++it)
                     a_nxt[it] = (ABL & 2) ? (v4i){it, lane, nt, nk}
                                           : *reinterpret_cast<const v4i *>(a_base + nt * QF_TILE_BYTES + aoff[it][nk]);
+                if (sub == 2) read_bits(n_base, wbn);               // garbage (never used) behind the last stage
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    a_nxt[it] = (ABL & 2) ? (v4i){it, lane, s, 1} : *reinterpret_cast<const v4i *>(n_base + aoff[it][0]);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt)
                     acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[it], b_cur[jt], acc[it][jt], 0, 0, 0);
-            if (sub < 3) expand(sub + 1, b_nxt);
+            if (sub < 3) expand(wb, sub + 1, b_nxt); else expand(wbn, 0, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int it = 0; it < 4; ++it) a_cur[it] = a_nxt[it];
@@ -305,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
             cst = 0; scale_l *= step;
             if (++cl == nl) { cl = 0; scale_l = scale0; ++cI; }
         }
+        wb[0][0] = wbn[0][0]; wb[0][1] = wbn[0][1]; wb[1][0] = wbn[1][0]; wb[1][1] = wbn[1][1];
     }
     // lanes l and l^32 hold different rows of the same variant
 #pragma unroll
@@ -510,12 +526,14 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     switch (variant) {          // 30 + mask = timing ablations (results meaningless)
     case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    case 38: hipLaunchKernelGGL(k_lmm_quadform_i8<8>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     }
