@@ -549,6 +549,204 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
 
 
 // =====================================================================================================================
+// Firth as a device-resident state machine (the default; k_glm_firth above is the single-kernel form kept for A/B).
+//
+// fit_firth (model.py:414-504) alternates two sample passes: the penalised score at beta (hat diagonal through the factored
+// information) and the penalised likelihood at a candidate (a fresh information matrix, its determinant, the step-halving
+// test).  Each pass is its own kernel so that each is compiled to <= 256 VGPRs (two waves per SIMD instead of one 400-register
+// wave), and between passes the live variants are re-listed, so a wavefront never idles on lanes that have converged or are
+// in the other phase.  Per-variant state lives in HBM, SoA over the slot index: beta, cand, the LDL^T factor of I(beta),
+// F(beta), I11, the previous step norm, counters.
+// =====================================================================================================================
+struct FirthWork {
+    double *st;                 // [FW_ND(PC)][cap]
+    int *iter, *halv, *var;     // [cap] accepted steps (-1 = initial evaluation pending), halvings of the current step, variant index
+    int64_t cap;
+};
+template <int PC> __host__ __device__ constexpr int fw_beta() { return 0; }
+template <int PC> __host__ __device__ constexpr int fw_cand() { return PC; }
+template <int PC> __host__ __device__ constexpr int fw_fac() { return 2 * PC; }
+template <int PC> __host__ __device__ constexpr int fw_fcur() { return 2 * PC + PC * (PC + 1) / 2; }
+template <int PC> __host__ __device__ constexpr int fw_i11() { return fw_fcur<PC>() + 1; }
+template <int PC> __host__ __device__ constexpr int fw_snp() { return fw_fcur<PC>() + 2; }
+template <int PC> __host__ __device__ constexpr int fw_nd() { return fw_fcur<PC>() + 3; }
+
+template <int Q>
+__global__ __launch_bounds__(64) void k_firth_init(const int *__restrict__ firth_list, const int *__restrict__ firth_count, GlmParams P,
+                                                   FirthWork fw, int *__restrict__ eval_list, int *__restrict__ eval_count)
+{
+    constexpr int PC = Q + 2;
+    const int cnt = *firth_count;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s == 0) *eval_count = cnt;
+    if (s >= cnt) return;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) {
+        const double b0 = (a == 0) ? P.ymean_logit : 0.0;                    // start vector, model.py:323-324
+        fw.st[(int64_t)(fw_beta<PC>() + a) * fw.cap + s] = b0;
+        fw.st[(int64_t)(fw_cand<PC>() + a) * fw.cap + s] = b0;
+    }
+    fw.st[(int64_t)fw_snp<PC>() * fw.cap + s] = INFINITY;
+    fw.iter[s] = -1; fw.halv[s] = 0; fw.var[s] = firth_list[s];
+    eval_list[s] = s;
+}
+
+// penalised likelihood at cand; accept / halve / converge / fail (the state == 1 arm of k_glm_firth)
+template <int Q>
+__global__ __launch_bounds__(64, 2) void k_firth_eval(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                      const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                      FirthWork fw, const int *__restrict__ eval_list, const int *__restrict__ eval_count,
+                                                      int *__restrict__ next_eval, int *__restrict__ next_eval_count,
+                                                      int *__restrict__ step_list, int *__restrict__ step_count,
+                                                      double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                      int *__restrict__ pinv_list, int *__restrict__ pinv_count)
+{
+    constexpr int PC = Q + 2;
+    const double SING_TOL = 1e-12;
+    const int cnt = *eval_count;
+    if ((int64_t)blockIdx.x * 64 >= cnt) return;
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    const bool live = li < cnt;
+    const int s = eval_list[live ? li : 0];
+    const int64_t v = fw.var[s];
+    const int64_t cap = fw.cap;
+    double cand[PC], A[PC * (PC + 1) / 2], dummy[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) cand[a] = fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s];
+    double ll, maxdev, det;
+    info_pass<Q, false, true>(T, Vpad, v, P.N, P.NB64, y, W, cand, A, dummy, ll, maxdev);
+    if (!live) return;
+    const double i11c = A[sidx(1, 1)];
+    const bool singular = !ldl_factor<PC>(A, SING_TOL, &det);
+    if (singular) {                     // handled by k_glm_firth_pinv (numpy.linalg.pinv semantics, model.py:450)
+        const int s2 = atomicAdd(pinv_count, 1); pinv_list[s2] = (int)v;
+        return;
+    }
+    const double Fcand = -(ll + 0.5 * log(det));                     // firth_likelihood, model.py:410-411
+    int iter = fw.iter[s];
+    bool accept = true, failed = false, conv = false;
+    double sn = 0.0;
+    if (iter < 0) {                                                  // F(beta_0): nothing to compare with
+        iter = 0;
+    } else {
+        const double Fcur = fw.st[(int64_t)fw_fcur<PC>() * cap + s];
+        double stepmax = 0.0;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) {
+            const double d = cand[a] - fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
+            stepmax = fmax(stepmax, fabs(d)); sn = fma(d, d, sn);
+        }
+        // see k_glm_firth: steps below 1e-10 are accepted outright (F(new) > F(old) is rounding noise there)
+        if (Fcand > Fcur && !(stepmax < 1e-10)) {                    // step halving, model.py:467-474
+            accept = false;
+            const int h = fw.halv[s] + 1;
+            fw.halv[s] = h;
+            if (h > 1000) failed = true;
+            else {
+#pragma unroll
+                for (int a = 0; a < PC; ++a) {
+                    const double b = fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
+                    fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = b + 0.5 * (cand[a] - b);
+                }
+                next_eval[atomicAdd(next_eval_count, 1)] = s;
+            }
+        } else {
+            sn = sqrt(sn);
+            const double snp = fw.st[(int64_t)fw_snp<PC>() * cap + s];
+            conv = (iter > 0) && (snp < 1e-4);                       // tests the PREVIOUS step, model.py:477-479
+            fw.st[(int64_t)fw_snp<PC>() * cap + s] = sn;
+            ++iter;
+            if (!conv && iter >= 1000) failed = true;                // step_limit exhausted, model.py:482-484
+        }
+    }
+    if (accept && !failed && !conv) {                                // beta <- cand; keep the factor for the score pass
+#pragma unroll
+        for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s] = cand[a];
+#pragma unroll
+        for (int a = 0; a < PC * (PC + 1) / 2; ++a) fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s] = A[a];
+        fw.st[(int64_t)fw_fcur<PC>() * cap + s] = Fcand;
+        fw.iter[s] = iter; fw.halv[s] = 0;
+        step_list[atomicAdd(step_count, 1)] = s;
+        return;
+    }
+    if (!failed && !conv) return;                                    // halved: queued above
+    uint32_t fl = flags[v];
+    if (failed) {
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                           // model.py:357-362
+        out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
+    } else {
+        const double fitll = -Fcand;
+        const double lrstat = -2.0 * (P.null_firth - fitll);
+        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
+        out[V + v] = pval; out[2 * V + v] = cand[1]; out[3 * V + v] = sqrt(i11c); out[4 * V + v] = cand[0];   // bse = sqrt(I11), model.py:491
+#pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = cand[2 + j];
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(cand[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    }
+    flags[v] = fl;
+}
+
+// penalised score at beta through the stored factor, Newton step -> cand (the state == 0 arm of k_glm_firth)
+template <int Q>
+__global__ __launch_bounds__(64, 2) void k_firth_step(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
+                                                      const double *__restrict__ W, GlmParams P, FirthWork fw,
+                                                      const int *__restrict__ step_list, const int *__restrict__ step_count,
+                                                      int *__restrict__ next_eval, int *__restrict__ next_eval_count)
+{
+    constexpr int PC = Q + 2;
+    const int cnt = *step_count;
+    if ((int64_t)blockIdx.x * 64 >= cnt) return;
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    const bool live = li < cnt;
+    const int s = step_list[live ? li : 0];
+    const int64_t v = fw.var[s];
+    const int64_t cap = fw.cap;
+    const int N = P.N, NB64 = P.NB64;
+    double beta[PC], A[PC * (PC + 1) / 2], U[PC], dinv[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
+#pragma unroll
+    for (int a = 0; a < PC * (PC + 1) / 2; ++a) A[a] = fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) { U[a] = 0.0; dinv[a] = 1.0 / A[sidx(a, a)]; }
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double x[PC];
+            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+            double eta = 0.0;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+            const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+            double zt[PC]; double qf = 0.0;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) {
+                double t = x[a];
+#pragma unroll
+                for (int k = 0; k < a; ++k) t = fma(-A[sidx(a, k)], zt[k], t);
+                zt[a] = t;
+                qf = fma(t * t, dinv[a], qf);
+            }
+            const double h = wgt * qf;                               // diagonal of the hat matrix, model.py:455-462
+            const double res = y[i] - mu + h * (0.5 - mu);
+#pragma unroll
+            for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
+        }
+    }
+    if (!live) return;
+    ldl_solve<PC>(A, U);                                             // var_covar_mat . U, model.py:463
+#pragma unroll
+    for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = beta[a] + U[a];
+    next_eval[atomicAdd(next_eval_count, 1)] = s;
+}
+
+// =====================================================================================================================
 // Firth slow path: literal restatement of fit_firth with numpy.linalg.pinv semantics (model.py:450) for variants whose
 // information matrix is (near-)singular, e.g. a k-mer that duplicates a binary covariate.  Arrays live in scratch and
 // loops are not unrolled: this kernel is about semantics, not speed, and sees a handful of variants per batch.
@@ -951,6 +1149,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
     else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
+    else if (which >= 6) return hipErrorInvalidValue;
     else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags);
     return hipGetLastError();
 }
@@ -969,4 +1168,36 @@ extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uin
     default: return hipErrorInvalidValue;
     }
 #undef GLM_CASE
+}
+
+// ---- Firth state machine launchers: which = 0 init, 1 eval, 2 step; n = upper bound of the list length (grid size) ----
+template <int Q>
+static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
+                               const double *W, GlmParams P, FirthWork fw, const int *in_list, const int *in_count, int *next_eval,
+                               int *next_eval_count, int *step_list, int *step_count, double *out, uint32_t *flags, int *plist, int *pcount)
+{
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 63) / 64)), blk(64);
+    if (which == 0) hipLaunchKernelGGL(k_firth_init<Q>, grid, blk, 0, st, in_list, in_count, P, fw, next_eval, next_eval_count);
+    else if (which == 1) hipLaunchKernelGGL(k_firth_eval<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval, next_eval_count,
+                                            step_list, step_count, out, flags, plist, pcount);
+    else hipLaunchKernelGGL(k_firth_step<Q>, grid, blk, 0, st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    return hipGetLastError();
+}
+
+extern "C" int shk_firth_state_doubles(int Q) { const int PC = Q + 2; return 2 * PC + PC * (PC + 1) / 2 + 3; }
+
+extern "C" hipError_t shk_firth_launch(hipStream_t st, int Q, int which, int64_t n, const uint64_t *T, int64_t Vpad, int64_t V,
+                                       const double *y, const double *W, GlmParams P, double *fst, int *fiter, int *fhalv, int *fvar,
+                                       int64_t fcap, const int *in_list, const int *in_count, int *next_eval, int *next_eval_count,
+                                       int *step_list, int *step_count, double *out, uint32_t *flags, int *plist, int *pcount)
+{
+    FirthWork fw{fst, fiter, fhalv, fvar, fcap};
+#define FIRTH_CASE(q) case q: return launch_firth<q>(st, which, n, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval, next_eval_count, step_list, step_count, out, flags, plist, pcount);
+    switch (Q) {
+        FIRTH_CASE(0) FIRTH_CASE(1) FIRTH_CASE(2) FIRTH_CASE(3) FIRTH_CASE(4) FIRTH_CASE(5) FIRTH_CASE(6) FIRTH_CASE(7)
+        FIRTH_CASE(8) FIRTH_CASE(9) FIRTH_CASE(10) FIRTH_CASE(11) FIRTH_CASE(12) FIRTH_CASE(13) FIRTH_CASE(14)
+    default: return hipErrorInvalidValue;
+    }
+#undef FIRTH_CASE
 }

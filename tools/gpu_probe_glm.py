@@ -28,8 +28,11 @@ def run(N, q, V, force_firth, cont=False):
           % (N, q, V, force_firth, cont, dt * 1e3, ms, V / dt, 100 * np.mean((f & 0x7C) != 0), 100 * np.mean((f >> 16) & 1)))
     e.close()
 
-run(1000, 10, 1 << 18, False)
-run(5000, 10, 1 << 17, False)
-run(5000, 10, 1 << 15, True)
-run(1000, 10, 1 << 16, True)
-run(5000, 10, 1 << 18, False, cont=True)
+if os.environ.get("FIRTH_V"):
+    run(int(os.environ.get("N", 5000)), 10, int(os.environ["FIRTH_V"]), True)
+else:
+    run(1000, 10, 1 << 18, False)
+    run(5000, 10, 1 << 17, False)
+    run(5000, 10, 1 << 15, True)
+    run(1000, 10, 1 << 16, True)
+    run(5000, 10, 1 << 18, False, cont=True)
