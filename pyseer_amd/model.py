@@ -127,7 +127,30 @@ def fit_null(p, m, cov, continuous, firth=False):
             return None
         return r[2]
     try:
-        beta, llf = logit_newton(v, p, start)
+        try:
+            beta, llf = logit_newton(v, p, start)
+        except np.linalg.LinAlgError:
+            # model.py:134-137: "Null fit with default optimiser may fail, Powell optimizer might work".  statsmodels'
+            # _fit_powell = scipy fmin_powell on -loglike/nobs with xtol = ftol = 1e-4 and fit()'s maxiter = 35
+            # (SM:base/optimizer.py:631-665); the separation callback stays armed; the covariance is then taken from an
+            # eigendecomposition and silently dropped when the Hessian is not positive definite (SM:base/model.py:543-556).
+            from scipy import optimize
+            n = v.shape[0]
+
+            def callback(b):
+                if np.allclose(_cdf(v.dot(b)) - p, 0):
+                    raise PerfectSeparation()
+
+            beta = optimize.fmin_powell(lambda b: -_loglike(v, p, b) / n, start, xtol=1e-4, ftol=1e-4, maxiter=35,
+                                        full_output=1, disp=0, callback=callback)[0]
+            beta = np.atleast_1d(np.asarray(beta, dtype=float))
+            H = _info(v, beta)
+            bse = np.full(beta.shape[0], np.nan)
+            if np.all(np.isfinite(H)):
+                w, _ = np.linalg.eigh(H)
+                if np.min(w) > 0:
+                    bse = np.sqrt(np.diag(np.linalg.inv(H)))
+            return NullFit(_loglike(v, p, beta), beta, bse)
     except np.linalg.LinAlgError:
         sys.stderr.write('Matrix inversion error for null model\n')
         return None

@@ -1,6 +1,7 @@
 """Host-side null fits (pyseer_amd/model.py fit_null) against the reference's numbers (model_test.py:120-172 family)."""
 import os
 
+import pytest
 import numpy as np
 
 from pyseer_amd.model import fit_null, fit_firth_host, firth_likelihood
@@ -35,3 +36,19 @@ def test_synthetic_nulls():
         m = d["m"] if int(d["q"]) else np.zeros((0, 0))
         assert abs(fit_null(d["y"], m, np.zeros((0, 0)), False).llf - float(d["null_llf"])) < 1e-8
         assert abs(fit_null(d["y"], m, np.zeros((0, 0)), False, firth=True) - float(d["null_firth"])) < 1e-7
+
+
+def test_fit_null_degenerate_designs_match_reference():
+    """Null fits on rank-deficient designs (tests/golden/make_null_golden.py ran the reference): the ridge keeps Newton going
+    on a duplicated column; when the final un-ridged inverse fails here, the Powell fallback (model.py:134-137) lands on the
+    same log-likelihood."""
+    from pyseer_amd.model import fit_null
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "null_degenerate.npz"))
+    p, m = d["p"], d["m"]
+    n = p.shape[0]
+    e = np.zeros((n, 0))
+    for name, mm in (("dup", np.c_[m, m[:, 0]]), ("const", np.c_[m, np.ones(n)]), ("ok", m)):
+        r = fit_null(p, mm, e, False)
+        assert r is not None and abs(r.llf - float(d["llf_" + name])) < 1e-8, name
+    assert fit_null(p, m, e, False, firth=True) == pytest.approx(float(d["firth_ok"]), rel=1e-9)
+    assert fit_null(p, np.c_[m, np.ones(n)], e, False, firth=True) == -np.inf
