@@ -816,7 +816,7 @@ __device__ __noinline__ double slow_det(const double *Ain)
 
 // numpy.linalg.pinv of a symmetric matrix: cyclic Jacobi eigen-decomposition, eigenvalues <= 1e-15 * max dropped
 template <int PC>
-__device__ __noinline__ void slow_pinv(const double *Ain, double *Pm)
+__device__ __noinline__ void slow_pinv(const double *Ain, double *Pm, double rcond = 1e-15, int *rank = nullptr)
 {
     double A[PC * PC], Vv[PC * PC];
     for (int a = 0; a < PC * PC; ++a) { A[a] = Ain[a]; Vv[a] = 0.0; }
@@ -844,13 +844,14 @@ __device__ __noinline__ void slow_pinv(const double *Ain, double *Pm)
     }
     double smax = 0.0;
     for (int i = 0; i < PC; ++i) smax = fmax(smax, fabs(A[i * PC + i]));
+    if (rank) { int r = 0; for (int k = 0; k < PC; ++k) r += (fabs(A[k * PC + k]) > rcond * smax) ? 1 : 0; *rank = r; }
 #pragma unroll 1
     for (int i = 0; i < PC; ++i)
 #pragma unroll 1
         for (int j = 0; j < PC; ++j) {
             double s = 0.0;
 #pragma unroll 1
-            for (int k = 0; k < PC; ++k) { const double w = A[k * PC + k]; if (fabs(w) > 1e-15 * smax) s = fma(Vv[i * PC + k] / w, Vv[j * PC + k], s); }
+            for (int k = 0; k < PC; ++k) { const double w = A[k * PC + k]; if (fabs(w) > rcond * smax) s = fma(Vv[i * PC + k] / w, Vv[j * PC + k], s); }
             Pm[i * PC + j] = s;
         }
 }
@@ -950,7 +951,8 @@ __global__ __launch_bounds__(64) void k_glm_ols(const uint64_t *__restrict__ T, 
                                                 const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
                                                 const double *__restrict__ yc, const double *__restrict__ ZtZ,
                                                 const double *__restrict__ Zty, GlmParams P,
-                                                double *__restrict__ out, uint32_t *__restrict__ flags)
+                                                double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                int *__restrict__ pinv_list, int *__restrict__ pinv_count)
 {
     constexpr int PC = Q + 2;
     const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -1018,7 +1020,11 @@ __global__ __launch_bounds__(64) void k_glm_ols(const uint64_t *__restrict__ T, 
         kbse = sqrt(scale * e1[1]);
         kbeta = beta[1]; icpt = beta[0];
         pval = sh_t_sf2(kbeta / kbse, dfr);                                   // res.pvalues[1]
-        if (!ok) { pval = NAN; fl |= SH_NOTE_MATRIX_INV; }
+        if (!ok) {                          // rank-deficient design: statsmodels' OLS is pinv-based -> k_glm_ols_pinv finishes it
+            const int s2 = atomicAdd(pinv_count, 1); pinv_list[s2] = (int)v;
+            out[v] = prep; flags[v] = fl;
+            return;
+        }
         if (pval > P.lrtt || !isfinite(pval) || !isfinite(kbeta)) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
     }
     out[v] = prep; out[V + v] = pval; out[2 * V + v] = kbeta; out[3 * V + v] = kbse; out[4 * V + v] = icpt;
@@ -1027,6 +1033,74 @@ __global__ __launch_bounds__(64) void k_glm_ols(const uint64_t *__restrict__ T, 
     flags[v] = fl;
 }
 
+
+// OLS slow path for rank-deficient designs (a k-mer that duplicates, or complements, a binary covariate): statsmodels OLS.fit()
+// is pinv-based (SM:regression/linear_model.py, method='pinv'): beta = pinv(X) y, normalized_cov = pinv(X) pinv(X)^T = (X^T X)^+,
+// df_resid = N - rank(X).  Here (X^T X)^+ comes from a Jacobi eigendecomposition of X^T X; its eigenvalues resolve the singular
+// values of X only down to sqrt(eps) * s_max, so directions with lambda <= 1e-10 * lambda_max (s <= 1e-5 * s_max) are the null
+// space -- exact collinearity, which is what 0/1 columns against real covariates produce; numpy's own cut-off is s <= 1e-15 s_max.
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_ols_pinv(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                     const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                     const int *__restrict__ pinv_list, const int *__restrict__ pinv_count,
+                                                     double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    constexpr int PC = Q + 2;
+    const int cnt = *pinv_count;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= cnt) return;
+    const int64_t v = pinv_list[slot];
+    const int N = P.N, NB64 = P.NB64;
+    double A[PC * PC], Pm[PC * PC], rhs[PC], beta[PC];
+    for (int a = 0; a < PC * PC; ++a) A[a] = 0.0;
+    for (int a = 0; a < PC; ++a) rhs[a] = 0.0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double x[PC];
+            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll 1
+            for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+#pragma unroll 1
+            for (int a = 0; a < PC; ++a) {
+                rhs[a] = fma(x[a], y[i], rhs[a]);
+#pragma unroll 1
+                for (int c = 0; c < PC; ++c) A[a * PC + c] = fma(x[a], x[c], A[a * PC + c]);
+            }
+        }
+    }
+    int rank = PC;
+    slow_pinv<PC>(A, Pm, 1e-10, &rank);
+#pragma unroll 1
+    for (int a = 0; a < PC; ++a) { double s = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < PC; ++c) s = fma(Pm[a * PC + c], rhs[c], s);
+        beta[a] = s; }
+    double ssr = 0.0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double f = fma(beta[1], (double)(unsigned)((w64 >> b) & 1ull), beta[0]);
+#pragma unroll 1
+            for (int j = 0; j < Q; ++j) f = fma(beta[2 + j], W[(int64_t)i * Q + j], f);
+            const double r = y[i] - f;
+            ssr = fma(r, r, ssr);
+        }
+    }
+    const double dfr = (double)(N - rank);
+    const double kbse = sqrt(ssr / dfr * Pm[PC + 1]);
+    const double pval = sh_t_sf2(beta[1] / kbse, dfr);
+    uint32_t fl = flags[v];
+    if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = kbse; out[4 * V + v] = beta[0];
+#pragma unroll 1
+    for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+    flags[v] = fl;
+}
 
 // =====================================================================================================================
 // a6 fit_lineage_effect (model.py:151-199): logistic regression of the VARIANT on [1, lineages, covariates] (statsmodels
@@ -1149,8 +1223,9 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
     else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
-    else if (which >= 6) return hipErrorInvalidValue;
-    else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags);
+    else if (which == 6) hipLaunchKernelGGL(k_glm_ols_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
+    else if (which > 6) return hipErrorInvalidValue;
+    else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, plist, pcount);
     return hipGetLastError();
 }
 

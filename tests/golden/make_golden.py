@@ -455,6 +455,8 @@ if __name__ == "__main__":
         run_fixed_case("ols_N100_q3", 21, 100, 3, 48, continuous=True)
         run_fixed_case("ols_N300_q10", 22, 300, 10, 64, continuous=True)
         run_fixed_case("ols_N300_q0", 23, 300, 0, 48, continuous=True)
+    if "ols_rankdef" in what or "glm" in what:
+        run_fixed_case("ols_N300_q4_bincov", 24, 300, 4, 48, continuous=True, binary_cov=True)   # K[9] duplicates a covariate: pinv
     if "lmm" in what:
         run_lmm_case("lmm_N50_D1", 31, 50, 1, 32, [0.0, 0.25, 0.9])
         run_lmm_case("lmm_N300_D1", 32, 300, 1, 64, [0.0, 0.25, 0.5, 0.9])

@@ -160,3 +160,30 @@ def test_empty_and_single_variant_batches():
     r1 = e.glm_batch(pack_variants(d["K"][20:21]))
     close(r1["kbeta"], d["main"][20:21, 2], atol=FA); close(r1["pvalue"], d["main"][20:21, 1])
     e.close()
+
+
+def test_ols_rank_deficient_design_follows_pinv():
+    """Continuous phenotype, k-mer identical to (or the complement of) a binary covariate: statsmodels' OLS.fit() is pinv-based
+    (model.py:299-312), so the reference still reports the minimum-norm coefficients, their pinv standard errors and a t-test
+    with N - rank degrees of freedom."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(77)
+    N, q = 300, 4
+    W = rng.standard_normal((N, q)); W[:, 2] = (rng.random(N) < 0.4).astype(float)
+    y = 0.4 * W[:, 0] + 0.8 * W[:, 2] + rng.standard_normal(N)
+    K = (rng.random((6, N)) < 0.3).astype(np.uint8)
+    K[1] = W[:, 2].astype(np.uint8)                  # duplicates the covariate
+    K[3] = 1 - W[:, 2].astype(np.uint8)              # intercept minus the covariate
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, True).llf
+    want = orc.fixed_effects_batch(y, K.astype(float), W, True, 1.0, 1.0, nl, np.nan)
+    e = Engine(N)
+    e.glm_setup(y, W, True, nl, np.nan)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(r[f], want[f], atol=1e-9, what=f)
+    close(r["betas"], want["betas"], atol=1e-9, what="betas")
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
