@@ -112,9 +112,10 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
             const double r = yi - mu;
             maxdev = fmax(maxdev, fabs(r));
             if (LOGLIK && want_ll) {
-                // SM Logit.loglike: log(cdf(q*eta)), q = 2y-1.  For y = 0: cdf(-eta) = 1/(1+exp(eta)), exp(eta) = 1/exp(-eta)
-                const double cq = (yi == 1.0) ? mu : ((yi == 0.0) ? 1.0 / (1.0 + 1.0 / en) : logit_cdf((2.0 * yi - 1.0) * eta));
-                ll += log(cq);
+                // SM Logit.loglike: log(cdf(q*eta)), q = 2y-1.  y = 1: log(mu).  y = 0: cdf(-eta) = exp(-eta) * cdf(eta), so
+                // log(cdf(-eta)) = log(mu) - eta: one logarithm, no second reciprocal, and no cancellation when mu -> 1.
+                const double lm = log(mu);
+                ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
             }
             if (SCORE) {
                 g[0] += r; g[1] = fma(r, xd, g[1]);
