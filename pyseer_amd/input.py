@@ -347,6 +347,38 @@ class NativeKmerReader(object):
             self.last_blob, self.last_off = raw[:self._off[nv]], self._off[:nv + 1].copy()      # for the block sink
             yield names, bits[:nv], counts[:nv]
 
+    def blocks_with_names(self):
+        """(names, bits, counts, names_blob, name_off) per block: the blob/offsets travel with the block (prefetch-safe)."""
+        for names, bits, counts in self:
+            yield names, bits, counts, self.last_blob, self.last_off
+
+
+def prefetched(iterable, depth=2):
+    """Run `iterable` in a background thread, `depth` items ahead.  The native reader spends its time inside ctypes calls (GIL
+    released: inflate + OpenMP parse), so block k+1 is read and packed while block k is on the GPU / being formatted."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for item in iterable:
+                q.put((item, None))
+        except BaseException as ex:           # re-raised in the consumer
+            q.put((None, ex))
+        q.put((end, None))
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    while True:
+        item, ex = q.get()
+        if ex is not None:
+            raise ex
+        if item is end:
+            return
+        yield item
+
 
 def strains_from_bits(row, samples_sorted_idx, samples):
     """(kstrains, nkstrains), both lexicographically sorted like read_variant's (input.py:439-440), from one packed row."""
@@ -362,9 +394,9 @@ def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
     reader = NativeKmerReader(path, samples, block_size)
-    for names, bits, counts in reader:
+    for names, bits, counts, blob, off in prefetched(reader.blocks_with_names()):
         blk = PackedBlock(n, 0)
-        blk.names_blob, blk.name_off = reader.last_blob, reader.last_off
+        blk.names_blob, blk.name_off = blob, off
         afs = counts.astype(np.float64) / n
         keep = (afs >= min_af) & (afs <= max_af)
         blk.names = names
