@@ -20,7 +20,8 @@ hipError_t shk_sim_accumulate(hipStream_t st, const uint64_t *T, int64_t Vpad, i
 hipError_t shk_sim_finish(hipStream_t st, const unsigned long long *Kacc, int NS, int N, double *K);
 hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
-                          const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
+                          const double *, const double *, const uint64_t *, const uint64_t *, int, const double *, LmmLinOut);
+hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, int, int, double *);
 hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *);
 hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
@@ -47,7 +48,7 @@ struct sh_ctx {
     bool lmm_ready = false;
     int k = 0, D = 0, L = 5, DP = 0;
     LmmFinParams fin{};
-    double *d_vv = nullptr, *d_mdiag = nullptr, *d_yc = nullptr, *d_Qb = nullptr;
+    double *d_vv = nullptr, *d_mdiag = nullptr, *d_yc = nullptr, *d_Qb = nullptr, *d_tab = nullptr;   // d_tab: nibble tables of (vv, mdiag)
     uint64_t *d_y1 = nullptr, *d_y0 = nullptr;
     int8_t *d_G = nullptr;
     double quant_scale = 0.0;
@@ -62,6 +63,7 @@ struct sh_ctx {
     double *d_xky = nullptr, *d_dg = nullptr, *d_rss = nullptr, *d_s1 = nullptr, *d_q1 = nullptr, *d_q = nullptr;
     // ---- optional timing of the dominant kernel (sh_set_timing / sh_get_timing)
     int timing = 0;
+    int lin_tab = 1;                                  // SEERHIP_LIN=0: per-sample k_lmm_linear instead of the nibble tables
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
     // ---- pattern de-duplication (sh_set_dedup)
     int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
@@ -222,6 +224,7 @@ sh_ctx *sh_create(int device, int n_samples)
     c->device = device; c->N = n_samples;
     if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
     if (const char *qs = std::getenv("SEERHIP_QF_SPLIT")) c->qf_split = std::atoi(qs);
+    if (const char *ql = std::getenv("SEERHIP_LIN")) c->lin_tab = std::atoi(ql);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
     return c;
@@ -232,7 +235,7 @@ void sh_destroy(sh_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     free_ws(c);
-    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0);
+    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_tab);
     hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);
     for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -380,8 +383,8 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (DP) { Qbp.assign((size_t)N * DP, 0.0); for (int i = 0; i < N; ++i) for (int e = 0; e < r; ++e) Qbp[(size_t)i * DP + e] = Qb[(size_t)i * D + e]; }
 
     // 5. device side: M = W sgn W^T (fp64 MFMA), diagonal, limbs
-    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_G);
-    c->d_vv = c->d_mdiag = c->d_yc = c->d_Qb = nullptr; c->d_y1 = c->d_y0 = nullptr; c->d_G = nullptr;
+    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_G); hipFree(c->d_tab);
+    c->d_vv = c->d_mdiag = c->d_yc = c->d_Qb = c->d_tab = nullptr; c->d_y1 = c->d_y0 = nullptr; c->d_G = nullptr;
     const int NT = c->NT, L = n_limbs;
     const int NR = 2 * NT;                                   // 128-sample row tiles
     const size_t gbytes = (size_t)L * NR * (NR + 1) * 8192;
@@ -401,6 +404,8 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (DP) HIPCHK(hipMemcpyAsync(c->d_Qb, Qbp.data(), sizeof(double) * (size_t)N * DP, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_M, 0, sizeof(double) * (size_t)Np * Np, st));
     HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NR, L, d_M, c->d_mdiag, d_amax, c->d_G));
+    HIPCHK(dmalloc(&c->d_tab, (size_t)c->NB64 * 256 * 2));
+    HIPCHK(shk_lmm_build_tab(st, c->d_vv, c->d_mdiag, N, c->NB64, c->d_tab));
     unsigned long long amax_bits = 0;
     HIPCHK(hipMemcpyAsync(&amax_bits, d_amax, sizeof(amax_bits), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -449,7 +454,7 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     LmmLinOut lo{c->d_t11, c->d_t01, c->d_m, c->d_xky, c->d_dg, c->d_rss, c->d_s1, c->d_q1};
     HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
     HIPCHK(shk_lmm_linear(st, c->DP, c->d_T, Vpad, c->N, c->NB64, c->d_vv, c->d_mdiag, c->d_yc, c->d_Qb, c->d_y1, c->d_y0,
-                          c->fin.continuous, lo));
+                          c->fin.continuous, c->lin_tab ? c->d_tab : nullptr, lo));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const int lsplit = c->qf_split ? c->L : 1;

@@ -114,6 +114,52 @@ __global__ __launch_bounds__(256) void k_lmm_linear(const uint64_t *__restrict__
     o.xky[v] = xky; o.dg[v] = dg; o.rss[v] = rss; o.s1[v] = s1; o.q1[v] = q1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same O(N) terms for the common case (D = 1, binary phenotype) by table lookup: for every 4-sample nibble of a variant's
+// word, tab[sb][nib][value] = (sum of vv, sum of mdiag) over the set bits, built once per run (k_lmm_build_tab, 4 KB per
+// 64-sample block).  16 conflict-free ds_read_b128 + 32 fp64 adds per word instead of 64 x (extract, convert, 2 FMAs).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lmm_build_tab(const double *__restrict__ vv, const double *__restrict__ mdiag, int N, int NB64,
+                                                       double2 *__restrict__ tab)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;              // entry = (sb * 16 + nib) * 16 + value
+    if (e >= NB64 * 256) return;
+    const int value = e & 15, base = (e >> 4) * 4;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < 4; ++k)
+        if (((value >> k) & 1) && base + k < N) { a += vv[base + k]; b += mdiag[base + k]; }
+    tab[e] = make_double2(a, b);
+}
+
+__global__ __launch_bounds__(256) void k_lmm_linear_tab(const uint64_t *__restrict__ T, int64_t Vpad, int N, int NB64,
+                                                        const double2 *__restrict__ tab, const uint64_t *__restrict__ y1,
+                                                        const uint64_t *__restrict__ y0, LmmLinOut o)
+{
+    __shared__ double2 lt[2][256];
+    const int tid = threadIdx.x;
+    const int64_t v = (int64_t)blockIdx.x * 256 + tid;
+    double xky = 0, dg = 0;
+    int t11 = 0, t01 = 0, m = 0;
+    lt[0][tid] = tab[tid];
+    for (int sb = 0; sb < NB64; sb++) {
+        const double2 nxt = (sb + 1 < NB64) ? tab[(sb + 1) * 256 + tid] : make_double2(0.0, 0.0);
+        const uint64_t w = T[(int64_t)sb * Vpad + v];
+        __syncthreads();                                          // slice sb is in lt[sb & 1]; nobody reads lt[(sb+1) & 1] any more
+        m += __popcll(w); t11 += __popcll(w & y1[sb]); t01 += __popcll(w & y0[sb]);
+        const double2 *cur = lt[sb & 1];
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+#pragma unroll
+        for (int nib = 0; nib < 8; ++nib) {
+            const double2 e0 = cur[nib * 16 + ((lo >> (4 * nib)) & 15u)];
+            const double2 e1 = cur[(8 + nib) * 16 + ((hi >> (4 * nib)) & 15u)];
+            xky += e0.x; dg += e0.y; xky += e1.x; dg += e1.y;
+        }
+        lt[(sb + 1) & 1][tid] = nxt;
+    }
+    o.t11[v] = t11; o.t01[v] = t01; o.m[v] = m;
+    o.xky[v] = xky; o.dg[v] = dg; o.rss[v] = (double)m * (double)(N - m) / (double)N; o.s1[v] = 0.0; o.q1[v] = 0.0;
+}
+
 template __global__ void k_lmm_linear<0>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
 template __global__ void k_lmm_linear<4>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
 template __global__ void k_lmm_linear<8>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
@@ -516,11 +562,21 @@ hipError_t shk_repack_bits(hipStream_t st, const uint8_t *bits, int64_t row_byte
     return hipGetLastError();
 }
 
+hipError_t shk_lmm_build_tab(hipStream_t st, const double *vv, const double *mdiag, int N, int NB64, double *tab)
+{
+    hipLaunchKernelGGL(k_lmm_build_tab, dim3((unsigned)NB64), dim3(256), 0, st, vv, mdiag, N, NB64, reinterpret_cast<double2 *>(tab));
+    return hipGetLastError();
+}
+
 hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpad, int N, int NB64, const double *vv,
                           const double *mdiag, const double *yc, const double *Qb, const uint64_t *y1,
-                          const uint64_t *y0, int continuous, LmmLinOut o)
+                          const uint64_t *y0, int continuous, const double *tab, LmmLinOut o)
 {
     dim3 grid((unsigned)(Vpad / 256)), blk(256);
+    if (DP == 0 && !continuous && tab) {
+        hipLaunchKernelGGL(k_lmm_linear_tab, grid, blk, 0, st, T, Vpad, N, NB64, reinterpret_cast<const double2 *>(tab), y1, y0, o);
+        return hipGetLastError();
+    }
     switch (DP) {
     case 0: hipLaunchKernelGGL(k_lmm_linear<0>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
     case 4: hipLaunchKernelGGL(k_lmm_linear<4>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;
