@@ -209,7 +209,9 @@ __device__ __forceinline__ uint4 qf_expand16(uint32_t bits16)
 #ifndef QF_G_AUX
 #define QF_G_AUX 0
 #endif
-#define QF_NST 5                     // LDS ring depth (stages): s (computing), s+1 (landed, prefetched from), s+2..s+4 in flight
+#ifndef QF_NST
+#define QF_NST 5
+#endif                               // LDS ring depth (stages): s (computing), s+1 (landed, prefetched from), s+2..s+4 in flight
 #define QF_AHEAD (QF_NST - 1)        // stages issued ahead of the compute cursor
 #define QF_STAGE_BYTES (2 * QF_TILE_BYTES + 2 * QF_BN * 8)      // 16 KB of G + 8 KB of packed bits = 24 KB
 
@@ -281,8 +283,10 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
     // words of stage s+1, so no wave starts a stage by waiting on LDS.  (Tried and measured slower, +1.4 % / +3 %: taking the
     // barrier half a stage apart on the two waves that share a SIMD; the stalls are not a phase-alignment effect.)
     auto sync_refill = [&](int s) {
-        const int newer = max(0, min(total - 2 - s, 2));           // stages allowed to be still in flight: s+2, s+3
-        if (!(ABL & 1)) { if (newer >= 2) qf_wait_vm<6>(); else if (newer == 1) qf_wait_vm<3>(); else qf_wait_vm<0>(); }
+        const int newer = max(0, min(total - 2 - s, QF_AHEAD - 2));   // stages allowed to be still in flight: s+2 .. s+QF_AHEAD-1
+        if (!(ABL & 1)) {
+            if (newer >= 3) qf_wait_vm<9>(); else if (newer == 2) qf_wait_vm<6>(); else if (newer == 1) qf_wait_vm<3>(); else qf_wait_vm<0>();
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + QF_AHEAD < total) fetch();
