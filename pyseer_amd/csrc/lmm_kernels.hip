@@ -20,6 +20,25 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // bits (variant-major rows) -> T[sb][v] : one uint64 per (64-sample block, variant); coalesced for every consumer.
 // ---------------------------------------------------------------------------------------------
+// fallback for rows too long to stage 64 of them in 64 KB of LDS (more than 8192 samples): strided 8-byte gather per thread
+__global__ __launch_bounds__(256) void k_repack_bits_gather(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V,
+                                                            int64_t Vpad, int N, uint64_t *__restrict__ T)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int sb = blockIdx.y;
+    uint64_t w = 0;
+    if (v < V) {
+        const int64_t off = (int64_t)sb * 8;
+        const uint8_t *p = bits + v * row_bytes + off;
+        int64_t nbytes = row_bytes - off; if (nbytes > 8) nbytes = 8;
+        if (nbytes == 8 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) w = *reinterpret_cast<const uint64_t *>(p);
+        else for (int b = 0; b < nbytes; b++) w |= (uint64_t)p[b] << (8 * b);
+        const int valid = N - sb * 64;
+        if (valid <= 0) w = 0; else if (valid < 64) w &= ((1ull << valid) - 1ull);
+    }
+    T[(int64_t)sb * Vpad + v] = w;
+}
+
 __global__ __launch_bounds__(256) void k_repack_bits(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V,
                                                      int64_t Vpad, int N, int NB64p, uint64_t *__restrict__ T)
 {
@@ -559,9 +578,13 @@ hipError_t shk_repack_bits(hipStream_t st, const uint8_t *bits, int64_t row_byte
                            int NB64, uint64_t *T)
 {
     const size_t lds = (size_t)64 * row_bytes;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;                      // 20480 samples per row at most
+    if (lds > 64 * 1024) {                                                   // more than 8192 samples: per-thread gather (needs Vpad % 256 == 0)
+        if (Vpad & 255) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_repack_bits_gather, dim3((unsigned)(Vpad / 256), (unsigned)NB64), dim3(256), 0, st, bits, row_bytes, V, Vpad, N, T);
+        return hipGetLastError();
+    }
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_repack_bits), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_repack_bits), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_repack_bits, dim3((unsigned)(Vpad / 64)), dim3(256), lds, st, bits, row_bytes, V, Vpad, N, NB64, T);
     return hipGetLastError();
 }

@@ -241,3 +241,18 @@ def test_pattern_dedup_is_exact_and_transparent(engine_mod):
     for k in want:
         assert np.array_equal(got[k], want[k], equal_nan=True), k
     e.close()
+
+
+def test_long_rows_use_the_gather_repack(engine_mod):
+    """More than 8192 samples per row: the repack falls back to the per-thread gather; results must not depend on the path.
+    Checked on the similarity accumulator (exact integers; no O(N^3) setup needed at this N)."""
+    from pyseer_amd.engine import Engine, pack_variants
+    rng = np.random.default_rng(5)
+    n, V = 8300, 700
+    Kv = (rng.random((V, n)) < 0.3).astype(np.uint8)
+    e = Engine(n)
+    e.sim_begin(); e.sim_accumulate(pack_variants(Kv))
+    K = e.sim_finish()
+    e.close()
+    G = Kv.astype(np.float32)
+    assert np.array_equal(K, (G.T @ G).astype(np.float64))
