@@ -15,6 +15,9 @@
 #include "common.h"
 
 #define GLM_MAXQ 14
+#ifndef GLM_FAST_WAVES
+#define GLM_FAST_WAVES 2
+#endif
 
 __host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, i >= j
 
@@ -26,6 +29,7 @@ struct GlmParams {
     double null_llf, null_firth, pret, lrtt;
     double min_af, max_af; int af_on;
     int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
+    const float *zz;              // per-sample products table for fast_pass_mfma (FastCols<Q>::STRIDE floats per sample), or null
 };
 
 // ---- LDL^T of a packed symmetric P x P matrix, in place (no pivoting; tolerates indefinite matrices) ----------------
@@ -224,12 +228,125 @@ __device__ __forceinline__ void fast_pass(const uint64_t *__restrict__ T, int64_
     H[sidx(1, 1)] = H[sidx(1, 0)];
 }
 
+// ---- the same pass with the covariate block of the fp32 Hessian on the matrix pipe --------------------------------------
+// H = sum_i w_i x_i x_i^T with x_i = [1, k_i, z_i].  The Q(Q+1)/2 entries H(2+j,2+k) = sum_i w_i (z_ij z_ik) are a skinny GEMM
+//   [64 variants x samples](w, per lane)  x  [samples x Q(Q+1)/2](z_j z_k, wave-uniform: a per-run table)
+// and go to v_mfma_f32_32x32x2_f32, two samples per issue: A = 32 variants x 2 samples.  A lane's w for samples (i, i+1) sit in
+// two registers; one v_permlane32_swap turns them into the A operands of the two 32-variant halves.  The 2 + 2Q entries that
+// involve the intercept or the variant column stay on the VALU (fp32), as do eta, mu and the fp64 score.  At the end of the pass
+// the 32x32 C tiles go through LDS once so that every lane holds its own variant's packed H.
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int Q> struct FastCols {
+    static constexpr int NPROD = Q * (Q + 1) / 2;
+    static constexpr int NCB = (NPROD + 31) / 32 > 0 ? (NPROD + 31) / 32 : 1;      // 32-column blocks of the products table
+    static constexpr int STRIDE = NCB * 32;                                          // floats per sample in the table
+    static constexpr int LDS_FLOATS = 32 * (STRIDE + 1);
+};
+
+template <int Q>
+__device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
+                                               const double *__restrict__ y, const double *__restrict__ W,
+                                               const float *__restrict__ Wf, const float *__restrict__ ZZ,
+                                               const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2],
+                                               double &maxdev, float *tr)
+{
+    constexpr int P = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE;
+    const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
+    v16f acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][h][r] = 0.0f;
+    float h00 = 0.0f, h10 = 0.0f, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0[j] = 0.0f; hz1[j] = 0.0f; }
+#pragma unroll
+    for (int a = 0; a < P; ++a) g[a] = 0.0;
+    maxdev = 0.0;
+    auto sample = [&](int i, bool xb) -> float {
+        double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], W[(int64_t)i * Q + j], eta);
+        const double mu = 1.0 / (1.0 + exp(-eta));
+        const double r = y[i] - mu;
+        maxdev = fmax(maxdev, fabs(r));
+        g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, W[(int64_t)i * Q + j], g[2 + j]);
+        const float wf = (float)(mu * (1.0 - mu));
+        const float wx = xb ? wf : 0.0f;
+        h00 += wf; h10 += wx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0[j] = fmaf(wf, zj, hz0[j]); hz1[j] = fmaf(wx, zj, hz1[j]); }
+        return wf;
+    };
+    // (Fetching the next pair's wave-uniform rows a pair ahead was tried: 128 SGPR spills, 25 % slower.)
+    if (Q > 0) {
+        const int nfull = N >> 1;                                             // pairs (2p, 2p+1); a pair never straddles a 64-sample word
+        for (int pr = 0; pr < nfull; ++pr) {
+            const int i = 2 * pr, b = i & 63;
+            const float *zrow = ZZ + (int64_t)(i + lh) * STRIDE + l31;
+            float bz[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bz[cb] = zrow[cb * 32];
+            const uint64_t w = T[(int64_t)(i >> 6) * Vpad + v];
+            const float wf0 = sample(i, (w >> b) & 1ull);
+            const float wf1 = sample(i + 1, (w >> (b + 1)) & 1ull);
+            // A operands: lanes 0-31 = sample i, lanes 32-63 = sample i+1, for the variants of each 32-lane half
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(wf0), __float_as_uint(wf1), false, false);
+            const float a0 = __uint_as_float(sw[0]), a1 = __uint_as_float(sw[1]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bz[cb], acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bz[cb], acc[cb][1], 0, 0, 0);
+            }
+        }
+        if (N & 1) {                                                          // the odd sample: k = 1 rows of A are zero
+            const int i = N - 1;
+            const float *zrow = ZZ + (int64_t)i * STRIDE + l31;
+            const float wf0 = sample(i, (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(wf0), 0u, false, false);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[0]), zrow[cb * 32], acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[1]), zrow[cb * 32], acc[cb][1], 0, 0, 0);
+            }
+        }
+    } else {
+        for (int i = 0; i < N; ++i) sample(i, (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+    }
+    H[sidx(0, 0)] = h00; H[sidx(1, 0)] = h10; H[sidx(1, 1)] = h10;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0[j]; H[sidx(2 + j, 1)] = hz1[j]; }
+    // C layout of the 32x32 tile: row (variant) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = lane & 31
+    if (Q > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * (STRIDE + 1) + cb * 32 + l31] = acc[cb][h][r];
+            __syncthreads();
+            if (lh == h) {
+                const float *row = tr + l31 * (STRIDE + 1);
+#pragma unroll
+                for (int j = 0; j < Q; ++j)
+#pragma unroll
+                    for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
+            }
+        }
+    }
+}
+
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
 struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; };
 
 // ---- kernel 1: a1 prefilter + routing + phase A (fast Newton) ---------------------------------------------------------------
 template <int Q>
-__global__ __launch_bounds__(64, 2) void k_glm_fast(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+__global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                  const double *__restrict__ y, const double *__restrict__ W,
                                                  const float *__restrict__ Wf,
                                                  const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
@@ -264,11 +381,14 @@ __global__ __launch_bounds__(64, 2) void k_glm_fast(const uint64_t *__restrict__
     bool need_slow = want_fit && (P.newton_mode == 1);
     bool active = want_fit && !need_slow;
     int it = 0;
+    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
     while (__any(active)) {
+        float Hf[PC * (PC + 1) / 2];
+        double g[PC], maxdev;
+        // the matrix-pipe pass is wave-wide (permlane swap, MFMA): lanes that already stopped ride along with their frozen beta
+        if (P.zz) fast_pass_mfma<Q>(T, Vpad, vr, N, NB64, y, W, Wf, P.zz, beta, Hf, g, maxdev, tr);
         if (active) {
-            float Hf[PC * (PC + 1) / 2];
-            double g[PC], maxdev;
-            fast_pass<Q>(T, Vpad, vr, N, NB64, y, W, Wf, beta, Hf, g, maxdev);
+            if (!P.zz) fast_pass<Q>(T, Vpad, vr, N, NB64, y, W, Wf, beta, Hf, g, maxdev);
             if (it > 0 && maxdev <= 1e-8) { need_slow = true; active = false; }
             else {
                 double A[PC * (PC + 1) / 2];
