@@ -76,6 +76,8 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--cpu-eigh', action='store_true', default=False,
+                    help='Decompose the similarity matrix with numpy on the host instead of rocSOLVER on the GPU')
     ot.add_argument('--no-dedup', action='store_true', default=False,
                     help='Test every variant separately [Default: each distinct presence pattern of a block is tested once]')
     ot.add_argument('--python-reader', action='store_true', default=False,
@@ -215,7 +217,8 @@ def main(argv=None):
     from .engine import Engine
     if options.lmm:
         sys.stderr.write("Setting up LMM\n")
-        p, lmm, h2 = initialise_lmm(p, cov, options.similarity, options.load_lmm, options.save_lmm)
+        p, lmm, h2 = initialise_lmm(p, cov, options.similarity, options.load_lmm, options.save_lmm,
+                                    use_gpu=not options.cpu_eigh, device=options.gpu)
         sys.stderr.write("h^2 = " + '{0:.2f}'.format(h2) + "\n")
         eng = Engine(len(p), device=options.gpu)
         eng.lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)

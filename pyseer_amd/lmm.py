@@ -30,7 +30,7 @@ def mask_like_fit_lmm(r):
 # One-off LMM setup on the host (pyseer/lmm.py:26-122 initialise_lmm; pyseer/fastlmm/lmm_cov.py:88-104 setSU_fromK,
 # :427-478 findH2; pyseer/fastlmm/mingrid.py:13-103 minimize1D).  O(N^3) once per run, never per variant.
 # ---------------------------------------------------------------------------------------------------------------
-def spectral_decomposition(K, covar, use_gpu=False):
+def spectral_decomposition(K, covar, use_gpu=False, device=0):
     """setSU_fromK: K += I; K_ = P K P; eigh; U = U[:, D:], S = S[D:] - 1   (lmm_cov.py:88-104).
 
     covar: (N, D) covariates incl. the intercept (last column).  use_gpu=True runs the symmetric eigensolver through
@@ -45,7 +45,7 @@ def spectral_decomposition(K, covar, use_gpu=False):
     K_ = K_ - covar.dot(Xd.dot(K_))
     if use_gpu:
         import torch
-        S, U = torch.linalg.eigh(torch.from_numpy(K_).cuda())
+        S, U = torch.linalg.eigh(torch.from_numpy(K_).to("cuda:%d" % device))
         S = S.cpu().numpy(); U = U.cpu().numpy()
     else:
         S, U = np.linalg.eigh(K_)
@@ -125,7 +125,7 @@ class LmmState(object):
         self.U, self.S, self.Y, self.X = U, S, Y, X
 
 
-def initialise_lmm(p, cov, K_in, lmm_cache_in=None, lmm_cache_out=None, lineage_samples=None, use_gpu=False):
+def initialise_lmm(p, cov, K_in, lmm_cache_in=None, lmm_cache_out=None, lineage_samples=None, use_gpu=False, device=0):
     """pyseer/lmm.py:26-122: returns (p restricted to the samples of the similarity matrix, LmmState, h2).
     Reads / writes the reference's cache layout (np.savez: arr_0 = U, arr_1 = S, arr_2 = [h2])."""
     import os
@@ -168,7 +168,7 @@ def initialise_lmm(p, cov, K_in, lmm_cache_in=None, lmm_cache_out=None, lineage_
     Kv = K.values.astype(float)
     if abs(factor - 1.0) > 1e-15:
         Kv = Kv * factor
-    U, S = spectral_decomposition(Kv, covar, use_gpu=use_gpu)
+    U, S = spectral_decomposition(Kv, covar, use_gpu=use_gpu, device=device)
     h2, _ = find_h2(U, S, p.values.astype(float), covar)
     if lmm_cache_out is not None and not os.path.exists(lmm_cache_out):
         np.savez(lmm_cache_out, U, S, np.array([h2]))
