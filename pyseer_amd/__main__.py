@@ -22,7 +22,7 @@ import pandas as pd
 from . import __version__
 from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
 from .input import (load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
-                    iter_packed_blocks, iter_packed_blocks_native)
+                    iter_packed_blocks, iter_packed_blocks_native, iter_packed_blocks_cached, PackedCacheWriter)
 from .lmm import initialise_lmm, mask_like_fit_lmm
 from .model import fit_null, covariate_block
 from .utils import format_output
@@ -76,6 +76,10 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--save-packed', default=None,
+                    help='Also write the parsed k-mer file as packed bit rows (for --load-packed in later runs over the same samples)')
+    ot.add_argument('--load-packed', default=None,
+                    help='Read variants from a packed cache written by --save-packed instead of parsing --kmers again')
     ot.add_argument('--cpu-eigh', action='store_true', default=False,
                     help='Decompose the similarity matrix with numpy on the host instead of rocSOLVER on the GPU')
     ot.add_argument('--no-dedup', action='store_true', default=False,
@@ -279,9 +283,16 @@ def main(argv=None):
         printed += 1
         out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
 
-    if native:
-        blocks = iter_packed_blocks_native(p, var_file, options.min_af, options.max_af, options.block_size,
+    cache_out = None
+    if options.load_packed:
+        blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
+    elif native:
+        if options.save_packed:
+            cache_out = PackedCacheWriter(options.save_packed, [str(x) for x in p.index])
+        blocks = iter_packed_blocks_native(p, var_file, options.min_af, options.max_af, options.block_size,
+                                           want_patterns=bool(options.output_patterns), want_samples=options.print_samples,
+                                           save_to=cache_out)
     else:
         blocks = iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
                                     options.max_missing, options.uncompressed, options.block_size)
@@ -295,7 +306,7 @@ def main(argv=None):
 
     def sink_block(blk, r):
         nonlocal prefilter, tested, printed
-        nb = len(blk.names)
+        nb = len(blk)
         status = np.asarray(blk.status, dtype=np.int64)
         on = status == 0
         j = np.asarray(blk.row_of, dtype=np.int64)[on]
@@ -426,6 +437,8 @@ def main(argv=None):
 
     if patterns is not None:
         patterns.close()
+    if cache_out is not None:
+        cache_out.close()
     eng.close()
     sys.stderr.write('%d loaded variants\n' % (prefilter + tested))
     sys.stderr.write('%d pre-filtered variants\n' % prefilter)

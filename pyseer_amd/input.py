@@ -251,17 +251,32 @@ def iter_variants_lmm(variant_iter, lmm, h2, lineage, lineage_clusters, covariat
 # ---------------------------------------------------------------------------------------------------------------
 class PackedBlock(object):
     """One block of parsed variants: metadata lists + packed presence rows for those that reach the engine."""
-    __slots__ = ("names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks", "last_k",
+    __slots__ = ("_names", "patterns", "afs", "kstrains", "nkstrains", "status", "bits", "row_of", "ks", "last_k",
                  "names_blob", "name_off")
 
     def __init__(self, n_samples, capacity):
-        self.names, self.patterns, self.afs, self.kstrains, self.nkstrains = [], [], [], [], []
+        self._names, self.patterns, self.afs, self.kstrains, self.nkstrains = [], [], [], [], []
         self.status = []            # 0 = to engine, 1 = af/missing filtered, 2 = carries missing calls (NaN in k)
         self.ks = []                # the dense k only for status 2 (host-side handling of the error path)
         self.row_of = []            # row in self.bits, or -1
         self.names_blob = self.name_off = None     # concatenated names + offsets when the native reader supplied them
         self.last_k = None          # dense k of the LAST variant parsed into the block (see __main__: lmm.py:209-213)
         self.bits = np.zeros((capacity, row_bytes_for(n_samples)), dtype=np.uint8)
+
+    @property
+    def names(self):
+        """Variant names as a list of str; decoded from the name blob only when somebody asks (the block sink does not)."""
+        if self._names is None:
+            b, o = self.names_blob, self.name_off
+            self._names = [b[o[i]:o[i + 1]].decode() for i in range(len(o) - 1)]
+        return self._names
+
+    @names.setter
+    def names(self, v):
+        self._names = v
+
+    def __len__(self):
+        return len(self.status)
 
 
 def iter_packed_blocks(p, var_type, infile, all_strains, sample_order, min_af, max_af, max_missing, uncompressed,
@@ -330,7 +345,8 @@ class NativeKmerReader(object):
         except Exception:
             pass
 
-    def __iter__(self):
+    def raw_blocks(self):
+        """(bits, counts, names_blob, name_off) per block; names stay one bytes blob + offsets (what the block sink consumes)."""
         C, abi = self._C, self._abi
         while True:
             bits = np.zeros((self.block_size, self.row_bytes), dtype=np.uint8)
@@ -342,15 +358,12 @@ class NativeKmerReader(object):
                 raise IOError(self._lib.sh_reader_error().decode())
             if nv == 0:
                 return
-            raw = self._names.raw
-            names = [raw[self._off[v]:self._off[v + 1]].decode() for v in range(nv)]
-            self.last_blob, self.last_off = raw[:self._off[nv]], self._off[:nv + 1].copy()      # for the block sink
-            yield names, bits[:nv], counts[:nv]
+            yield bits[:nv], counts[:nv], self._names.raw[:self._off[nv]], self._off[:nv + 1].copy()
 
-    def blocks_with_names(self):
-        """(names, bits, counts, names_blob, name_off) per block: the blob/offsets travel with the block (prefetch-safe)."""
-        for names, bits, counts in self:
-            yield names, bits, counts, self.last_blob, self.last_off
+    def __iter__(self):
+        """(names, bits, counts) per block, names decoded to str."""
+        for bits, counts, blob, off in self.raw_blocks():
+            yield [blob[off[v]:off[v + 1]].decode() for v in range(counts.shape[0])], bits, counts
 
 
 def prefetched(iterable, depth=2):
@@ -388,36 +401,128 @@ def strains_from_bits(row, samples_sorted_idx, samples):
     return ks, nks
 
 
-def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False):
-    """Same PackedBlock stream as iter_packed_blocks for k-mer files, fed by the native reader."""
+_NO_STRAINS = ()           # shared placeholder when the sample lists are not wanted (read-only)
+
+
+def _block_from_raw(n, samples, order, names, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples):
+    """PackedBlock from one raw block of the native reader / the packed cache (all parsed variants, before the AF filter)."""
+    blk = PackedBlock(n, 0)
+    blk.names_blob, blk.name_off = blob, off
+    afs = counts.astype(np.float64) / n
+    keep = (afs >= min_af) & (afs <= max_af)
+    blk.names = names                                    # None = decode lazily from the blob
+    blk.afs = afs.tolist()
+    blk.status = np.where(keep, 0, 1).tolist()
+    blk.row_of = np.where(keep, np.cumsum(keep) - 1, -1).tolist()
+    nv = int(counts.shape[0])
+    blk.ks = [None] * nv
+    blk.bits = bits if keep.all() else np.ascontiguousarray(bits[keep])
+    if want_samples:
+        sp = [strains_from_bits(bits[i], order, samples) for i in range(nv)]
+        blk.kstrains = [a for a, _ in sp]; blk.nkstrains = [b for _, b in sp]
+    else:
+        blk.kstrains = [_NO_STRAINS] * nv; blk.nkstrains = [_NO_STRAINS] * nv
+    if want_patterns:
+        dense = np.unpackbits(bits, axis=1, bitorder="little")[:, :n].astype(np.int64)
+        blk.patterns = [hash_pattern(dense[i]) for i in range(nv)]
+    else:
+        blk.patterns = [b''] * nv
+    for i in np.nonzero(counts == 0)[0]:
+        sys.stderr.write("No observations of " + blob[off[i]:off[i + 1]].decode() + " in selected samples\n")
+    blk.last_k = np.unpackbits(bits[nv - 1], bitorder="little")[:n].astype(np.int64)
+    return blk
+
+
+def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, save_to=None):
+    """Same PackedBlock stream as iter_packed_blocks for k-mer files, fed by the native reader.  save_to: a PackedCacheWriter that
+    receives every raw block (all parsed variants, before the AF filter)."""
     samples = [str(x) for x in p.index]
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
     reader = NativeKmerReader(path, samples, block_size)
-    for names, bits, counts, blob, off in prefetched(reader.blocks_with_names()):
-        blk = PackedBlock(n, 0)
-        blk.names_blob, blk.name_off = blob, off
-        afs = counts.astype(np.float64) / n
-        keep = (afs >= min_af) & (afs <= max_af)
-        blk.names = names
-        blk.afs = afs.tolist()
-        blk.status = [0 if k_ else 1 for k_ in keep]
-        rows = np.cumsum(keep) - 1
-        blk.row_of = [int(rows[i]) if keep[i] else -1 for i in range(len(names))]
-        blk.ks = [None] * len(names)
-        blk.bits = np.ascontiguousarray(bits[keep])
-        if want_samples:
-            sp = [strains_from_bits(bits[i], order, samples) for i in range(len(names))]
-            blk.kstrains = [a for a, _ in sp]; blk.nkstrains = [b for _, b in sp]
+    for bits, counts, blob, off in prefetched(reader.raw_blocks()):
+        if save_to is not None:
+            save_to.write_block(blob, off, counts, bits)
+        yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Packed cache: the parsed k-mer file as bit rows, so that further runs over the same samples (another phenotype column,
+# other covariates, LMM after fixed effects) skip gzip and text parsing and stream at the engine's rate.
+#   header: b"SEERPK01", uint32 n_samples, uint32 row_bytes, uint64 len, sample names joined by "\n" (phenotype order)
+#   blocks: uint64 nv, uint64 name_bytes, int64 name_off[nv+1], int32 counts[nv], names, uint8 bits[nv*row_bytes]; nv = 0 ends
+# ---------------------------------------------------------------------------------------------------------------
+_PK_MAGIC = b"SEERPK01"
+
+
+class PackedCacheWriter(object):
+    def __init__(self, path, samples):
+        self._f = open(path, "wb")
+        names = "\n".join(samples).encode()
+        self._f.write(_PK_MAGIC + np.array([len(samples), row_bytes_for(len(samples))], dtype="<u4").tobytes()
+                      + np.array([len(names)], dtype="<u8").tobytes() + names)
+
+    def write_block(self, blob, off, counts, bits):
+        nv = int(counts.shape[0])
+        self._f.write(np.array([nv, len(blob)], dtype="<u8").tobytes())
+        self._f.write(np.ascontiguousarray(off, dtype="<i8").tobytes())
+        self._f.write(np.ascontiguousarray(counts, dtype="<i4").tobytes())
+        self._f.write(blob)
+        self._f.write(np.ascontiguousarray(bits, dtype=np.uint8).tobytes())
+
+    def close(self):
+        if self._f is not None:
+            self._f.write(np.array([0, 0], dtype="<u8").tobytes())
+            self._f.close()
+            self._f = None
+
+
+def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False):
+    """PackedBlock stream from a packed cache written by --save-packed; the samples (and their order) must be the run's own.
+    Stored blocks are re-cut to about `block_size` variants (stored blocks are never split, only merged)."""
+    samples = [str(x) for x in p.index]
+    order = sorted(range(len(samples)), key=lambda i: samples[i])
+    n = len(samples)
+
+    def raw_blocks():
+        with open(path, "rb") as f:
+            if f.read(8) != _PK_MAGIC:
+                raise IOError("%s is not a packed k-mer cache" % path)
+            ns, rb = np.frombuffer(f.read(8), dtype="<u4")
+            (ln,) = np.frombuffer(f.read(8), dtype="<u8")
+            stored = f.read(int(ln)).decode().split("\n")
+            if stored != samples:
+                raise ValueError("packed cache was written for a different sample list / order (%d vs %d samples)"
+                                 % (len(stored), n))
+            if int(rb) != row_bytes_for(n):
+                raise IOError("packed cache row width mismatch")
+            while True:
+                nv, nb = (int(x) for x in np.frombuffer(f.read(16), dtype="<u8"))
+                if nv == 0:
+                    return
+                off = np.frombuffer(f.read(8 * (nv + 1)), dtype="<i8")
+                counts = np.frombuffer(f.read(4 * nv), dtype="<i4")
+                blob = f.read(nb)
+                bits = np.frombuffer(f.read(nv * int(rb)), dtype=np.uint8).reshape(nv, int(rb))
+                yield blob, off, counts, bits
+
+    def merged():
+        acc, rows = [], 0
+        for blk in raw_blocks():
+            acc.append(blk); rows += blk[2].shape[0]
+            if rows >= block_size:
+                yield acc
+                acc, rows = [], 0
+        if acc:
+            yield acc
+
+    for group in prefetched(merged()):
+        if len(group) == 1:
+            blob, off, counts, bits = group[0]
         else:
-            blk.kstrains = [[] for _ in names]; blk.nkstrains = [[] for _ in names]
-        if want_patterns:
-            dense = np.unpackbits(bits, axis=1, bitorder="little")[:, :n].astype(np.int64)
-            blk.patterns = [hash_pattern(dense[i]) for i in range(len(names))]
-        else:
-            blk.patterns = [b''] * len(names)
-        for i in range(len(names)):
-            if counts[i] == 0:
-                sys.stderr.write("No observations of " + names[i] + " in selected samples\n")
-        blk.last_k = np.unpackbits(bits[len(names) - 1], bitorder="little")[:n].astype(np.int64)
-        yield blk
+            blob = b"".join(g[0] for g in group)
+            base = np.cumsum([0] + [len(g[0]) for g in group[:-1]])
+            off = np.concatenate([g[1][:-1] + b for g, b in zip(group, base)] + [np.array([len(blob)], dtype=np.int64)])
+            counts = np.concatenate([g[2] for g in group])
+            bits = np.concatenate([g[3] for g in group], axis=0)
+        yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)

@@ -58,3 +58,31 @@ def test_corner_cases(tmp_path):
             dense = np.unpackbits(bits[v], bitorder="little")[:len(samples)]
             assert var_name == names[v] and np.array_equal(dense, k) and abs(af - counts[v] / len(samples)) < 1e-15
             assert hash_pattern(dense.astype(np.int64)) == hash_pattern(np.asarray(k))
+
+
+def test_packed_cache_round_trip(tmp_path):
+    """--save-packed / --load-packed: the cache reproduces the native reader's blocks (names, AFs, kept rows, order), also when
+    stored blocks are merged into larger ones, and refuses another sample list."""
+    import pandas as pd
+    import pytest
+    from pyseer_amd.input import iter_packed_blocks_native, iter_packed_blocks_cached, PackedCacheWriter
+    cli = os.path.join(os.path.dirname(__file__), "golden", "cli")
+    p = pd.read_csv(os.path.join(cli, "subset.pheno"), index_col=0, sep="\t")
+    p.index = p.index.astype(str)
+    p = p[p.columns[-1]]
+    path = str(tmp_path / "k.pk")
+    w = PackedCacheWriter(path, [str(x) for x in p.index])
+    direct = list(iter_packed_blocks_native(p, os.path.join(cli, "kmers.gz"), 0.01, 0.99, 37, save_to=w))
+    w.close()
+    for bs in (37, 64, 100000):
+        cached = list(iter_packed_blocks_cached(p, path, 0.01, 0.99, bs))
+        names_d = [n for b in direct for n in b.names]
+        names_c = [n for b in cached for n in b.names]
+        assert names_d == names_c
+        assert [a for b in direct for a in b.afs] == [a for b in cached for a in b.afs]
+        assert [s for b in direct for s in b.status] == [s for b in cached for s in b.status]
+        assert np.array_equal(np.concatenate([b.bits for b in direct]), np.concatenate([b.bits for b in cached]))
+        for b in cached:                                   # the name blob/offsets handed to the sink agree with the list
+            assert [b.names_blob[b.name_off[i]:b.name_off[i + 1]].decode() for i in range(len(b.names))] == b.names
+    with pytest.raises(ValueError):
+        list(iter_packed_blocks_cached(p.iloc[::-1], path, 0.01, 0.99, 64))

@@ -27,10 +27,42 @@ with gzip.open(d + "/kmers.gz", "wt", compresslevel=4) as f:
         f.write("".join(rng.choice(list("ACGT"), 31)) + " | " + " ".join(names[i] + ":1" for i in idx) + "\n")
 print("inputs written in %.1f s (%.1f MB gz)" % (time.time() - t0, os.path.getsize(d + "/kmers.gz") / 1e6))
 env = dict(os.environ); env["PYTHONPATH"] = ROOT
-for extra in ([], ["--block_size", "65536"]):
+for extra in ([], ["--block_size", "65536", "--save-packed", d + "/kmers.pk"], ["--block_size", "65536", "--load-packed", d + "/kmers.pk"],
+              ["--save-lmm", d + "/lmm.npz", "--block_size", "65536", "--load-packed", d + "/kmers.pk"]):
     t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.gz", "--phenotypes", d + "/pheno.tsv", "--lmm",
                         "--similarity", d + "/sim.tsv"] + extra, env=env, stdout=open(d + "/out.tsv", "w"), stderr=subprocess.PIPE)
     dt = time.time() - t0
     print("CLI", extra, "rc", r.returncode, "%.1f s total -> %.0f k-mers/s end to end" % (dt, V / dt))
     print("   ", r.stderr.decode().strip().splitlines()[-4:])
+
+# ---- steady state from a packed cache: BIGV synthetic variants written straight into the cache format (no text involved)
+BIGV = int(os.environ.get("BIGV", 0))
+if BIGV:
+    sys.path.insert(0, ROOT)
+    from pyseer_amd.input import PackedCacheWriter
+    from pyseer_amd.packing import row_bytes_for
+    t0 = time.time()
+    w = PackedCacheWriter(d + "/big.pk", names)
+    rb = row_bytes_for(N)
+    blk = 1 << 17
+    mask = np.zeros(rb, dtype=np.uint8); mask[:N // 8] = 255
+    if N % 8: mask[N // 8] = (1 << (N % 8)) - 1
+    for s in range(0, BIGV, blk):
+        nv = min(blk, BIGV - s)
+        bits = rng.integers(0, 256, (nv, rb), dtype=np.uint8) & mask
+        counts = np.unpackbits(bits, axis=1).sum(axis=1).astype(np.int32)
+        nm = ("".join(rng.choice(list("ACGT"), 31 * nv))).encode()
+        off = np.arange(nv + 1, dtype=np.int64) * 31
+        w.write_block(nm, off, counts, bits)
+    w.close()
+    print("cache with %d variants written in %.1f s (%.2f GB)" % (BIGV, time.time() - t0, os.path.getsize(d + "/big.pk") / 1e9))
+    for extra in (["--block_size", "262144"], ["--block_size", "262144", "--no-dedup"]):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.gz", "--phenotypes", d + "/pheno.tsv", "--lmm",
+                            "--similarity", d + "/sim.tsv", "--load-packed", d + "/big.pk"] + extra, env=env,
+                           stdout=open(d + "/out_big.tsv", "w"), stderr=subprocess.PIPE)
+        dt = time.time() - t0
+        print("CLI from cache", extra, "rc", r.returncode, "%.1f s total -> %.0f k-mers/s end to end; output %.2f GB"
+              % (dt, BIGV / dt, os.path.getsize(d + "/out_big.tsv") / 1e9))
+        print("   ", r.stderr.decode().strip().splitlines()[-4:])
