@@ -226,8 +226,6 @@ def fixed_effects_regression(variant, p, k, m, c, af, pattern, lineage_effects, 
     if p is None:                                                         # model.py:255-260
         return Seer(variant, pattern, af, np.nan, np.nan, np.nan, np.nan, np.nan, np.array([]), None,
                     kstrains, nkstrains, {'af-filter'}, True, False)
-    if lineage_effects:
-        raise NotImplementedError("lineage effects (fit_lineage_effect, model.py:151) are not built in this round")
     key = (id(p), id(m), id(c), bool(continuous), float(pret), float(lrtt), id(null_res), repr(null_firth))
     fe = _cache.get(key)
     if fe is None:
@@ -239,5 +237,15 @@ def fixed_effects_regression(variant, p, k, m, c, af, pattern, lineage_effects, 
         prep = np.nan
         return Seer(variant, pattern, af, prep, np.nan, np.nan, np.nan, np.nan, np.array([]), None, kstrains, nkstrains,
                     {'missing-data-error'}, False, True)
-    r = fe.batch_from_dense(k.reshape(1, -1))
-    return seer_from_row(r, 0, variant, pattern, af, kstrains, nkstrains)
+    bits = pack_variants(k.reshape(1, -1))
+    r = fe.batch(bits)
+    s = seer_from_row(r, 0, variant, pattern, af, kstrains, nkstrains)
+    if lineage_effects and not s.prefilter and 'firth-fail' not in s.notes:           # model.py:379-382 -> fit_lineage_effect
+        lkey = (id(lin), id(c))
+        if getattr(fe, "_lineage_key", None) != lkey:
+            cv = np.asarray(getattr(c, "values", c), dtype=float)
+            fe.engine.lineage_setup(np.asarray(lin, dtype=float), cv if (cv.ndim == 2 and cv.shape[0] == fe.n and cv.shape[1] > 0) else None)
+            fe._lineage_key = lkey
+        ml = int(fe.engine.lineage_batch(bits)[0])
+        s = s._replace(max_lineage=None if ml < 0 else ml)
+    return s

@@ -187,3 +187,26 @@ def test_ols_rank_deficient_design_follows_pinv():
         close(r[f], want[f], atol=1e-9, what=f)
     close(r["betas"], want["betas"], atol=1e-9, what="betas")
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+
+
+def test_drop_in_signature_with_lineage():
+    """pyseer_amd.model.fixed_effects_regression keeps the reference's one-variant signature, lineage effects included
+    (model.py:202, :379-382); checked against the oracle's fit_lineage_effect and fixed-effects rows."""
+    from oracle import oracle as orc
+    from pyseer_amd.model import fixed_effects_regression, fit_null
+    d = np.load(os.path.join(G, "lineage_N200_l3.npz"))
+    lin, K = d["lin"].astype(float), d["K"].astype(float)
+    n = lin.shape[0]
+    rng = np.random.default_rng(3)
+    y = (rng.random(n) < 0.4).astype(float)
+    m = lin[:, :2].copy()
+    e0 = np.zeros((n, 0))
+    null = fit_null(y, m, e0, False)
+    nf = fit_null(y, m, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K[:12], m, False, 1.0, 1.0, null.llf, nf)
+    for v in range(12):
+        s = fixed_effects_regression("v%d" % v, y, K[v], m, e0, K[v].mean(), b"", True, lin, 1.0, 1.0, null, nf, [], [], False)
+        assert np.isclose(s.kbeta, want["kbeta"][v], rtol=1e-6, atol=1e-9, equal_nan=True)
+        if not s.prefilter and 'firth-fail' not in s.notes:
+            ref = orc.lineage_effect(lin, None, K[v])
+            assert (s.max_lineage is None) == (ref is None)        # the index itself: Wald ties, see test_lineage_effect_golden
