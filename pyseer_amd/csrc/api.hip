@@ -21,7 +21,7 @@ hipError_t shk_sim_finish(hipStream_t st, const unsigned long long *Kacc, int NS
 hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, const double *, LmmLinOut);
-hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, int, int, double *);
+hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, const double *, const double *, int, int, int, int, double *);
 hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *);
 hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
@@ -404,8 +404,8 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (DP) HIPCHK(hipMemcpyAsync(c->d_Qb, Qbp.data(), sizeof(double) * (size_t)N * DP, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_M, 0, sizeof(double) * (size_t)Np * Np, st));
     HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NR, L, d_M, c->d_mdiag, d_amax, c->d_G));
-    HIPCHK(dmalloc(&c->d_tab, (size_t)c->NB64 * 256 * 2));
-    HIPCHK(shk_lmm_build_tab(st, c->d_vv, c->d_mdiag, N, c->NB64, c->d_tab));
+    HIPCHK(dmalloc(&c->d_tab, (size_t)c->NB64 * 256 * (2 + 2 + 8)));          // up to 12 doubles per nibble entry
+    HIPCHK(shk_lmm_build_tab(st, c->d_vv, c->d_mdiag, c->d_yc, c->d_Qb, DP, continuous, N, c->NB64, c->d_tab));
     unsigned long long amax_bits = 0;
     HIPCHK(hipMemcpyAsync(&amax_bits, d_amax, sizeof(amax_bits), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

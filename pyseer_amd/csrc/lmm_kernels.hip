@@ -179,6 +179,95 @@ __global__ __launch_bounds__(256) void k_lmm_linear_tab(const uint64_t *__restri
     o.xky[v] = xky; o.dg[v] = dg; o.rss[v] = (double)m * (double)(N - m) / (double)N; o.s1[v] = 0.0; o.q1[v] = 0.0;
 }
 
+// The general form of the table kernel: NE doubles per entry = (vv, diag M) [+ (yc, yc^2) for the Welch prefilter of a
+// continuous phenotype] [+ the DP columns of the covariate basis Qb].  rss = ||x - Qb Qb^T x||^2 only feeds the "explained by the
+// covariates" test (std <= 1e-10, lmm_cov.py:179-181): it is m - sum_d c_d^2 in exact arithmetic, and only a wavefront that holds
+// a variant where that difference cancels (<= 1e-8 m) walks the samples again for the exact residual.
+template <int NE>
+__global__ __launch_bounds__(256) void k_lmm_build_tabn(const double *__restrict__ vv, const double *__restrict__ mdiag,
+                                                        const double *__restrict__ yc, const double *__restrict__ Qb, int DP, int cont,
+                                                        int N, int NB64, double *__restrict__ tab)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;              // entry = (sb * 16 + nib) * 16 + value
+    if (e >= NB64 * 256) return;
+    const int value = e & 15, base = (e >> 4) * 4;
+    for (int c = 0; c < NE; ++c) {
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k;
+            if (!((value >> k) & 1) || i >= N) continue;
+            double x;
+            if (c == 0) x = vv[i]; else if (c == 1) x = mdiag[i];
+            else if (cont && c == 2) x = yc[i]; else if (cont && c == 3) x = yc[i] * yc[i];
+            else x = Qb[(int64_t)i * DP + (c - 2 - 2 * cont)];
+            a += x;
+        }
+        tab[(int64_t)e * NE + c] = a;
+    }
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void k_lmm_linear_tabn(const uint64_t *__restrict__ T, int64_t Vpad, int N, int NB64,
+                                                         const double *__restrict__ tab, const uint64_t *__restrict__ y1,
+                                                         const uint64_t *__restrict__ y0, const double *__restrict__ Qb, int DP,
+                                                         int cont, LmmLinOut o)
+{
+    __shared__ __attribute__((aligned(16))) double lt[2][256 * NE];
+    const int tid = threadIdx.x;
+    const int64_t v = (int64_t)blockIdx.x * 256 + tid;
+    double acc[NE];
+#pragma unroll
+    for (int c = 0; c < NE; ++c) acc[c] = 0.0;
+    int t11 = 0, t01 = 0, m = 0;
+#pragma unroll
+    for (int c = 0; c < NE; ++c) lt[0][tid * NE + c] = tab[(int64_t)tid * NE + c];
+    for (int sb = 0; sb < NB64; sb++) {
+        double nxt[NE];
+        const bool more = sb + 1 < NB64;
+#pragma unroll
+        for (int c = 0; c < NE; ++c) nxt[c] = more ? tab[((int64_t)(sb + 1) * 256 + tid) * NE + c] : 0.0;
+        const uint64_t w = T[(int64_t)sb * Vpad + v];
+        __syncthreads();                                          // slice sb is in lt[sb & 1]; nobody reads lt[(sb+1) & 1] any more
+        m += __popcll(w); t11 += __popcll(w & y1[sb]); t01 += __popcll(w & y0[sb]);
+        const double *cur = lt[sb & 1];
+#pragma unroll 4
+        for (int nib = 0; nib < 16; ++nib) {
+            const double *e = cur + (nib * 16 + (int)((w >> (4 * nib)) & 15ull)) * NE;
+#pragma unroll
+            for (int c = 0; c < NE; ++c) acc[c] += e[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NE; ++c) lt[(sb + 1) & 1][tid * NE + c] = nxt[c];
+    }
+    const int c0 = 2 + 2 * cont;
+    double rss;
+    if (DP > 0) {
+        double sc = 0.0;
+        for (int d = 0; d < NE - c0; ++d) sc = fma(acc[c0 + d], acc[c0 + d], sc);
+        rss = (double)m - sc;
+        const bool susp = rss <= 1e-8 * fmax((double)m, 1.0);
+        if (__any(susp)) {
+            double ex = 0.0;
+            for (int sb = 0; sb < NB64; sb++) {
+                const uint64_t w = T[(int64_t)sb * Vpad + v];
+                const int nb = min(64, N - sb * 64);
+                for (int b = 0; b < nb; b++) {
+                    const int i = sb * 64 + b;
+                    double r = (double)(unsigned)((w >> b) & 1ull);
+                    for (int d = 0; d < NE - c0; ++d) r = fma(-Qb[(int64_t)i * DP + d], acc[c0 + d], r);
+                    ex = fma(r, r, ex);
+                }
+            }
+            if (susp) rss = ex;
+        }
+    } else {
+        rss = (double)m * (double)(N - m) / (double)N;           // ||x - mean(x)||^2, exact
+    }
+    o.t11[v] = t11; o.t01[v] = t01; o.m[v] = m;
+    o.xky[v] = acc[0]; o.dg[v] = acc[1]; o.rss[v] = rss;
+    o.s1[v] = cont ? acc[2] : 0.0; o.q1[v] = cont ? acc[3] : 0.0;
+}
+
 template __global__ void k_lmm_linear<0>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
 template __global__ void k_lmm_linear<4>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
 template __global__ void k_lmm_linear<8>(const uint64_t *, int64_t, int, int, const double *, const double *, const double *, const double *, const uint64_t *, const uint64_t *, int, LmmLinOut);
@@ -589,9 +678,23 @@ hipError_t shk_repack_bits(hipStream_t st, const uint8_t *bits, int64_t row_byte
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_build_tab(hipStream_t st, const double *vv, const double *mdiag, int N, int NB64, double *tab)
+// number of doubles per table entry for (continuous, DP), or 0 when the table kernels do not cover the configuration
+static int lin_tab_ne(int DP, int continuous) { return (DP == 0 || DP == 4 || DP == 8) ? 2 + 2 * (continuous ? 1 : 0) + DP : 0; }
+
+hipError_t shk_lmm_build_tab(hipStream_t st, const double *vv, const double *mdiag, const double *yc, const double *Qb, int DP,
+                             int continuous, int N, int NB64, double *tab)
 {
-    hipLaunchKernelGGL(k_lmm_build_tab, dim3((unsigned)NB64), dim3(256), 0, st, vv, mdiag, N, NB64, reinterpret_cast<double2 *>(tab));
+    const dim3 g((unsigned)NB64), b(256);
+    const int cont = continuous ? 1 : 0;
+    switch (lin_tab_ne(DP, continuous)) {
+    case 2: hipLaunchKernelGGL(k_lmm_build_tab, g, b, 0, st, vv, mdiag, N, NB64, reinterpret_cast<double2 *>(tab)); break;
+    case 4: hipLaunchKernelGGL(k_lmm_build_tabn<4>, g, b, 0, st, vv, mdiag, yc, Qb, DP, cont, N, NB64, tab); break;
+    case 6: hipLaunchKernelGGL(k_lmm_build_tabn<6>, g, b, 0, st, vv, mdiag, yc, Qb, DP, cont, N, NB64, tab); break;
+    case 8: hipLaunchKernelGGL(k_lmm_build_tabn<8>, g, b, 0, st, vv, mdiag, yc, Qb, DP, cont, N, NB64, tab); break;
+    case 10: hipLaunchKernelGGL(k_lmm_build_tabn<10>, g, b, 0, st, vv, mdiag, yc, Qb, DP, cont, N, NB64, tab); break;
+    case 12: hipLaunchKernelGGL(k_lmm_build_tabn<12>, g, b, 0, st, vv, mdiag, yc, Qb, DP, cont, N, NB64, tab); break;
+    default: return hipSuccess;                                // no table for this configuration
+    }
     return hipGetLastError();
 }
 
@@ -600,9 +703,17 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
                           const uint64_t *y0, int continuous, const double *tab, LmmLinOut o)
 {
     dim3 grid((unsigned)(Vpad / 256)), blk(256);
-    if (DP == 0 && !continuous && tab) {
-        hipLaunchKernelGGL(k_lmm_linear_tab, grid, blk, 0, st, T, Vpad, N, NB64, reinterpret_cast<const double2 *>(tab), y1, y0, o);
-        return hipGetLastError();
+    const int cont = continuous ? 1 : 0;
+    if (tab) {
+        switch (lin_tab_ne(DP, continuous)) {
+        case 2: hipLaunchKernelGGL(k_lmm_linear_tab, grid, blk, 0, st, T, Vpad, N, NB64, reinterpret_cast<const double2 *>(tab), y1, y0, o); return hipGetLastError();
+        case 4: hipLaunchKernelGGL(k_lmm_linear_tabn<4>, grid, blk, 0, st, T, Vpad, N, NB64, tab, y1, y0, Qb, DP, cont, o); return hipGetLastError();
+        case 6: hipLaunchKernelGGL(k_lmm_linear_tabn<6>, grid, blk, 0, st, T, Vpad, N, NB64, tab, y1, y0, Qb, DP, cont, o); return hipGetLastError();
+        case 8: hipLaunchKernelGGL(k_lmm_linear_tabn<8>, grid, blk, 0, st, T, Vpad, N, NB64, tab, y1, y0, Qb, DP, cont, o); return hipGetLastError();
+        case 10: hipLaunchKernelGGL(k_lmm_linear_tabn<10>, grid, blk, 0, st, T, Vpad, N, NB64, tab, y1, y0, Qb, DP, cont, o); return hipGetLastError();
+        case 12: hipLaunchKernelGGL(k_lmm_linear_tabn<12>, grid, blk, 0, st, T, Vpad, N, NB64, tab, y1, y0, Qb, DP, cont, o); return hipGetLastError();
+        default: break;
+        }
     }
     switch (DP) {
     case 0: hipLaunchKernelGGL(k_lmm_linear<0>, grid, blk, 0, st, T, Vpad, N, NB64, vv, mdiag, yc, Qb, y1, y0, continuous, o); break;

@@ -256,3 +256,28 @@ def test_long_rows_use_the_gather_repack(engine_mod):
     e.close()
     G = Kv.astype(np.float32)
     assert np.array_equal(K, (G.T @ G).astype(np.float64))
+
+
+@pytest.mark.parametrize("D", [3, 6])
+def test_lmm_variant_in_the_covariate_span_is_zeroed(engine_mod, D):
+    """rotate() zeroes a column that the covariates explain (std <= 1e-10 after regressing them out, lmm_cov.py:179-181): a k-mer
+    equal to a binary covariate, or to its complement.  The table kernel sees m - sum c^2 cancel and must take the exact path."""
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    N = 200
+    U, S, covar, y, Kv = _random_lmm(N, D, 7 + D, 40)
+    covar = covar.copy()
+    covar[:, 0] = (np.random.default_rng(D).random(N) < 0.35).astype(float)       # a binary covariate (the intercept is last)
+    Kv = Kv.copy()
+    Kv[5] = covar[:, 0].astype(np.uint8)
+    Kv[11] = 1 - covar[:, 0].astype(np.uint8)
+    L = orc.LmmOracle(U, S, y, covar)
+    wb, ws, wf, wp = L.block(0.4, Kv.astype(float))
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.4)
+    r = e.lmm_batch(pack(Kv))
+    e.close()
+    close(r["beta"], wb, atol=1e-12, what="beta"); close(r["bse"], ws, what="bse")
+    close(r["frac_h2"], wf, atol=1e-9, what="frac_h2"); close(r["pvalue"], wp, atol=1e-300, what="pvalue")
+    # whatever the reference makes of a zeroed column, both sides make the same of it
+    assert np.array_equal(np.isnan(r["bse"][[5, 11]]), np.isnan(ws[[5, 11]]))

@@ -9,9 +9,11 @@ g = torch.Generator(device="cuda"); g.manual_seed(5)
 U = (torch.randn((N, N - 1), generator=g, device="cuda", dtype=torch.float64) / np.sqrt(N)).cpu().numpy()
 rng = np.random.default_rng(9)
 S = np.sort(rng.gamma(0.5, 2.0, N - 1))[::-1].copy()
-y = (rng.random(N) < 0.4).astype(float); covar = np.ones((N, 1))
+D = int(os.environ.get("D", 1)); CONT = int(os.environ.get("CONT", 0))
+y = rng.standard_normal(N) if CONT else (rng.random(N) < 0.4).astype(float)
+covar = np.ones((N, 1)) if D == 1 else np.c_[rng.standard_normal((N, D - 1)), np.ones((N, 1))]
 e = Engine(N)
-t0 = time.time(); e.lmm_setup(U, S, y, covar, 0.3, n_limbs=L); print("setup s", time.time() - t0, e.lmm_info())
+t0 = time.time(); e.lmm_setup(U, S, y, covar, 0.3, continuous=bool(CONT), n_limbs=L); print("setup s", time.time() - t0, e.lmm_info())
 rb = row_bytes_for(N)
 bits = torch.randint(0, 256, (V, rb), dtype=torch.uint8, device="cuda", generator=g)
 e.use_torch_stream(); e.set_timing(True)
