@@ -281,3 +281,31 @@ def test_lmm_variant_in_the_covariate_span_is_zeroed(engine_mod, D):
     close(r["frac_h2"], wf, atol=1e-9, what="frac_h2"); close(r["pvalue"], wp, atol=1e-300, what="pvalue")
     # whatever the reference makes of a zeroed column, both sides make the same of it
     assert np.array_equal(np.isnan(r["bse"][[5, 11]]), np.isnan(ws[[5, 11]]))
+
+
+def test_host_batches_longer_than_one_pipeline_chunk(engine_mod):
+    """sh_lmm_batch / sh_glm_batch cut host batches into 2^18-variant chunks on two staging sets; several chunks plus a ragged
+    tail must give exactly what single small calls give."""
+    Engine, pack = engine_mod
+    N, D = 130, 1
+    V = (1 << 18) * 2 + 1234
+    U, S, covar, y, _ = _random_lmm(N, D, 5, 8)
+    rng = np.random.default_rng(11)
+    bits = rng.integers(0, 256, (V, (N + 63) // 64 * 8), dtype=np.uint8)
+    bits[:, N // 8] &= (1 << (N % 8)) - 1
+    bits[:, N // 8 + 1:] = 0
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.3)
+    big = e.lmm_batch(bits)
+    for lo in (0, (1 << 18) - 7, (1 << 19) - 3, V - 500):
+        part = e.lmm_batch(bits[lo:lo + 500])
+        for f in ("prep", "pvalue", "beta", "bse", "frac_h2", "flags"):
+            assert np.array_equal(big[f][lo:lo + 500], part[f], equal_nan=True), (f, lo)
+    W = rng.standard_normal((N, 2))
+    e.glm_setup(y, W, False, -80.0, -75.0)
+    bigg = e.glm_batch(bits)
+    for lo in (0, (1 << 18) - 7, V - 500):
+        part = e.glm_batch(bits[lo:lo + 500])
+        for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas", "flags"):
+            assert np.array_equal(bigg[f][lo:lo + 500], part[f], equal_nan=True), (f, lo)
+    e.close()
