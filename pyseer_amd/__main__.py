@@ -241,6 +241,11 @@ def main(argv=None):
     all_strains = set(p.index)
     var_type, var_file = ("kmers", options.kmers) if options.kmers else ("Rtab", options.pres)
     native = (var_type == "kmers") and not options.python_reader
+    if native and not options.uncompressed and not options.load_packed:
+        with open(var_file, "rb") as fh:                   # the reference's gzip.open raises on plain text (input.py:271-276)
+            if fh.read(2) != b"\x1f\x8b":
+                sys.stderr.write("Not a gzipped file (%s): use --uncompressed for plain-text k-mers\n" % var_file)
+                sys.exit(1)
     if not native:
         infile, sample_order = open_variant_file(var_type, var_file, None, None, options.uncompressed)
     patterns = open(options.output_patterns, 'wb') if options.output_patterns else None
