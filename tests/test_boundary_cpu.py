@@ -96,3 +96,16 @@ def test_load_var_block_blocks():
                 assert (None if lm.pattern is None else lm.pattern.decode()) == wv["pattern"]
                 assert (lm.prefilter, lm.filter, sorted(lm.notes)) == (wv["prefilter"], wv["filter"], wv["notes"])
                 assert int(np.nansum(k)) == wv["n_k"]
+
+
+def test_cmdscale_matches_the_references_own_vectors():
+    """pyseer/cmdscale.py: the reference pins classical MDS on tests/distances_smaller.tsv.gz against two data files it ships
+    (tests/cmdscale_test.py); the same files, copied as fixtures, pin the CLI's cmdscale here (axes are defined up to sign)."""
+    from pyseer_amd.input import cmdscale
+    F = os.path.join(G, "ref_fixtures")
+    D = pd.read_csv(os.path.join(F, "distances_smaller.tsv.gz"), index_col=0, sep="\t")
+    Y0 = np.loadtxt(os.path.join(F, "cmdscale.Y.txt.gz"))[:, :10]
+    e0 = np.loadtxt(os.path.join(F, "cmdscale.e.txt.gz"))[:10]
+    Y, e = cmdscale(D.values if hasattr(D, "values") else D)
+    assert np.abs(np.abs(Y0) - np.abs(Y[:, :10])).max() < 1e-10
+    assert np.abs(e0 - e[:10]).max() < 1e-10
