@@ -210,3 +210,35 @@ def test_drop_in_signature_with_lineage():
         if not s.prefilter and 'firth-fail' not in s.notes:
             ref = orc.lineage_effect(lin, None, K[v])
             assert (s.max_lineage is None) == (ref is None)        # the index itself: Wald ties, see test_lineage_effect_golden
+
+
+@pytest.mark.parametrize("tag", ["bin", "bin_pre", "bin_lrt", "bin_cov", "bin_bad", "cont", "cont_pre", "cont_lrt",
+                                 "cont_cov", "bin_nodist", "cont_nodist"])
+def test_reference_unit_scenarios_through_the_drop_in(tag):
+    """The scenarios of the reference's tests/model_test.py (TestFixedEffectsRegression*, its own N = 100 unit-test data), called the
+    way that file calls them -- fixed_effects_regression(variant, p, k, m, c, af, pattern, lineage_effects, lin, pret, lrtt,
+    null_res, null_firth, kstrains, nkstrains, continuous) -- and compared like its eq_seer (abs tol 1e-7) with the values the
+    reference produced (tests/golden/make_golden.py run_model_unit)."""
+    from pyseer_amd.model import fixed_effects_regression, NullFit
+    from pyseer_amd.classes import NOTE_ORDER
+    d = np.load(os.path.join(G, "model_unit.npz"))
+    cont = tag.startswith("cont")
+    p = d["p_continuous"] if cont else d["p_binary"]
+    k = np.array([1.0] * 5 + [0.0] * 95) if tag == "bin_bad" else d["k"]
+    m = np.zeros((100, 0)) if "nodist" in tag else d["m"]
+    c = d["cov"] if "cov" in tag else np.zeros((100, 0))
+    pret = 0.05 if tag.endswith("_pre") else 1.0
+    lrtt = 0.05 if tag.endswith("_lrt") else 1.0
+    nl, nf = d["s_%s_null" % tag]
+    s = fixed_effects_regression("variant", p, k, m, c, 0.2, b"pattern", False, None, pret, lrtt, NullFit(float(nl), None),
+                                 None if cont else float(nf), ["k1"], ["nk1"], cont)
+    want = d["s_%s_main" % tag]
+    got = np.array([s.prep, s.pvalue, s.kbeta, s.bse, s.intercept])
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.nanmax(np.abs(got - want), initial=0.0) < 1e-7
+    wb = d["s_%s_betas" % tag]
+    if wb.shape[0] and np.isfinite(wb).all():
+        assert np.abs(np.asarray(s.betas) - wb).max() < 1e-7
+    nm, pf, fl, _ = d["s_%s_flags" % tag]
+    assert set(n for i, n in enumerate(NOTE_ORDER) if (int(nm) >> i) & 1) == s.notes
+    assert (s.prefilter, s.filter) == (bool(pf), bool(fl))
+    assert (s.kmer, s.pattern, s.af, s.kstrains, s.nkstrains, s.max_lineage) == ("variant", b"pattern", 0.2, ["k1"], ["nk1"], None)
