@@ -100,19 +100,7 @@ def _die(msg):
     sys.exit(1)
 
 
-def _host_prefilter(p, k, continuous):
-    """pre_filtering (model.py:31-70) for the rare variants that carry missing calls and therefore never reach the GPU."""
-    from scipy import stats
-    if continuous:
-        return stats.ttest_ind(p[k == 1], p[k == 0], equal_var=False)[1], False
-    table = np.array([[np.sum((p == 1) & (k == 1)), np.sum((p == 1) & (k == 0))],
-                      [np.sum((p == 0) & (k == 1)), np.sum((p == 0) & (k == 0))]])
-    bad = bool((table <= 1).sum() > 0 or (table <= 5).sum() > 1)
-    try:
-        prep = stats.chi2_contingency(table, correction=False)[1]
-    except ValueError:
-        prep = np.nan
-    return prep, bad
+from .model import host_pre_filtering as _host_prefilter
 
 
 def main(argv=None):

@@ -173,3 +173,95 @@ def initialise_lmm(p, cov, K_in, lmm_cache_in=None, lmm_cache_out=None, lineage_
     if lmm_cache_out is not None and not os.path.exists(lmm_cache_out):
         np.savez(lmm_cache_out, U, S, np.array([h2]))
     return p, LmmState(U, S, p.values.astype(float), covar), h2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Drop-ins with the reference's signatures (pyseer/lmm.py:125-260).  The batched driver in pyseer_amd/__main__.py does not go
+# through them (it keeps results as arrays); they exist so that code written against pyseer.lmm keeps working unchanged.
+# ---------------------------------------------------------------------------------------------------------------
+_engines = {}
+
+
+def _engine_for(lmm, h2, continuous, filter_pvalue, lrt_pvalue):
+    from .engine import Engine
+    Y = np.asarray(lmm.Y, dtype=float).reshape(-1)
+    key = (id(lmm), float(h2), bool(continuous), float(filter_pvalue), float(lrt_pvalue))
+    eng = _engines.get(key)
+    if eng is None:
+        for old in list(_engines.values()):
+            old.close()
+        _engines.clear()
+        eng = Engine(Y.shape[0])
+        eng.lmm_setup(np.asarray(lmm.U, dtype=float), np.asarray(lmm.S, dtype=float), Y, np.asarray(lmm.X, dtype=float), h2,
+                      continuous, filter_pvalue, lrt_pvalue)          # raises KeyError('beta') for h2 outside [0, 1)
+        _engines[key] = eng
+    return eng
+
+
+def fit_lmm_block(lmm, h2, variant_block):
+    """pyseer/lmm.py:228-260: variant_block (n, B) of 0/1 -> {'p_values', 'beta', 'bse', 'frac_h2'}, arrays of length B.
+    KeyError('beta') for h2 outside [0, 1), AssertionError on a sample-count mismatch (tests/lmm_test.py:416-420)."""
+    from .packing import pack_variants
+    variant_block = np.asarray(variant_block, dtype=float)
+    n = np.asarray(lmm.Y).reshape(-1).shape[0]
+    eng = _engine_for(lmm, h2, False, np.inf, np.inf)
+    assert variant_block.ndim == 2 and variant_block.shape[0] == n, "shape missmatch between snps and Y"
+    if np.isnan(variant_block).any():
+        raise ValueError("missing calls cannot be packed; the reference propagates NaN here")
+    r = eng.lmm_batch(pack_variants(variant_block.T))
+    return {'p_values': r["pvalue"], 'beta': r["beta"], 'bse': r["bse"], 'frac_h2': r["frac_h2"]}
+
+
+def fit_lmm(lmm, h2, variants, variant_mat, lineage_effects, lineage_clusters, covariates, continuous, filter_pvalue,
+            lrt_pvalue):
+    """pyseer/lmm.py:125-226: LMM tuples for one block, af/pre-filtered variants first, then the tested ones, each in input
+    order; filtered columns of variant_mat are zeroed in place as the reference does."""
+    from .packing import pack_variants
+    from .model import host_pre_filtering
+    eng = _engine_for(lmm, h2, continuous, filter_pvalue, lrt_pvalue)
+    first, pending = [], []                                  # (input index, tuple): the reference's first and second loop
+    rows, where = [], []
+    for var_idx, (var, p, k) in enumerate(variants):
+        if var.pattern is None or k is None:
+            first.append((var_idx, var._replace(notes={'af-filter'}, prefilter=True, filter=False)))
+            variant_mat[:, var_idx] = 0.0
+            continue
+        kf = np.asarray(k, dtype=float)
+        if np.isnan(kf).any():                               # missing calls: pre_filtering on the host, NaN through the block fit
+            prep, bad = host_pre_filtering(np.asarray(p, dtype=float), kf, continuous)
+            notes = {'bad-chisq'} if bad else set()
+            if prep >= filter_pvalue or not np.isfinite(prep):
+                notes.add('pre-filtering-failed')
+                first.append((var_idx, var._replace(notes=notes, prep=prep, prefilter=True, filter=False)))
+                variant_mat[:, var_idx] = 0.0
+            else:
+                notes.add('lrt-filtering-failed')
+                pending.append((var_idx, var._replace(prep=prep, notes=notes, prefilter=False, pvalue=np.nan, filter=True)))
+            continue
+        rows.append(kf); where.append(var_idx)
+    if rows:
+        r = mask_like_fit_lmm(eng.lmm_batch(pack_variants(np.asarray(rows))))
+        stale_k = variants[-1][2]                            # lmm.py:209-213 reads the loop variable of the first loop
+        ml = None
+        if lineage_effects:
+            eng.lineage_setup(np.asarray(lineage_clusters, dtype=float),
+                              covariates if (covariates is not None and np.size(covariates)) else None)
+            if stale_k is not None and not np.isnan(np.asarray(stale_k, dtype=float)).any():
+                v = int(eng.lineage_batch(pack_variants(np.asarray(stale_k, dtype=float).reshape(1, -1)))[0])
+                ml = None if v < 0 else v
+        for j, var_idx in enumerate(where):
+            var = variants[var_idx][0]
+            fl = int(r["flags"][j])
+            notes = notes_from_flags(fl)
+            if fl & FLAG_PREFILTER:
+                first.append((var_idx, var._replace(notes=notes, prep=float(r["prep"][j]), prefilter=True, filter=False)))
+                variant_mat[:, var_idx] = 0.0
+            elif fl & FLAG_FILTER:
+                pending.append((var_idx, var._replace(prep=float(r["prep"][j]), notes=notes, prefilter=False,
+                                                      pvalue=float(r["pvalue"][j]), filter=True)))
+            else:
+                pending.append((var_idx, var._replace(prep=float(r["prep"][j]), pvalue=float(r["pvalue"][j]),
+                                                      kbeta=float(r["beta"][j]), bse=float(r["bse"][j]),
+                                                      frac_h2=float(r["frac_h2"][j]), notes=notes, prefilter=False, filter=False,
+                                                      max_lineage=ml)))
+    return [v for _, v in sorted(first, key=lambda t: t[0])] + [v for _, v in sorted(pending, key=lambda t: t[0])]

@@ -309,3 +309,55 @@ def test_host_batches_longer_than_one_pipeline_chunk(engine_mod):
         for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas", "flags"):
             assert np.array_equal(bigg[f][lo:lo + 500], part[f], equal_nan=True), (f, lo)
     e.close()
+
+
+def test_fit_lmm_block_drop_in_reads_like_the_reference_test(engine_mod):
+    """tests/lmm_test.py:395-420 (TestFitLmmBlock) with pyseer_amd.lmm.fit_lmm_block in place of pyseer.lmm.fit_lmm_block."""
+    from pyseer_amd.lmm import fit_lmm_block, LmmState
+    d = np.load(os.path.join(G, "lmm_unit.npz"))
+    y = LmmState(d["nocov_U"], d["nocov_S"], d["nocov_y"], d["nocov_covar"])
+    z = float(d["nocov_h2"])
+    variant_mat = d["nocov_k"].astype(float).reshape(-1, 1)
+    result = fit_lmm_block(y, z, variant_mat)
+    assert abs(result['beta'][0] - 0.15136876) < 5e-8
+    assert abs(result['bse'][0] - 0.14208536) < 5e-8
+    assert abs(result['frac_h2'][0] - 0.15198184) < 5e-8
+    assert abs(result['p_values'][0] - 0.29205322) < 5e-8
+    with pytest.raises(KeyError):                       # impossibly high h2
+        fit_lmm_block(y, 1, variant_mat)
+    with pytest.raises(AssertionError):                 # shape mismatch
+        fit_lmm_block(y, z, variant_mat[:10])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "lmm_N*.npz"))))
+def test_fit_lmm_drop_in_matches_golden_orchestration(engine_mod, path):
+    """pyseer_amd.lmm.fit_lmm with the reference's signature: tuple stream in, LMM tuples out, filtered variants first
+    (goldens: fit_lmm itself, tests/golden/make_golden.py run_lmm_case orchestrate)."""
+    from pyseer_amd.lmm import fit_lmm, LmmState
+    from pyseer_amd.classes import LMM, NOTE_ORDER
+    d = np.load(path)
+    Kv = d["Kv"].astype(float); y = d["y"]; cont = bool(d["continuous"])
+    noise = _perfect_fit(Kv, y) if not cont else np.zeros(Kv.shape[0], bool)
+    st = LmmState(d["U"], d["S"], y, d["covar"])
+    af = Kv.mean(axis=1)
+    keep = (af >= 0.01) & (af <= 0.99)
+    for o, (fp, lp) in (("o1", (1.0, 1.0)), ("o2", (0.05, 0.01))):
+        variants = [(LMM("v%d" % i, b"x" if keep[i] else None, af[i], np.nan, np.nan, np.nan, np.nan, np.nan, np.nan, [], [],
+                         set(), True, True), y, Kv[i] if keep[i] else None) for i in range(Kv.shape[0])]
+        mat = np.where(keep[None, :], Kv.T, 0.0).copy()
+        got = fit_lmm(st, float(d["h2"]), variants, mat, False, None, d["covar"], cont, fp, lp)
+        order = [str(s) for s in d[o + "_order"]]
+        assert [g.kmer for g in got] == order
+        rows = d[o + "_rows"]
+        for j, g in enumerate(got):
+            i = int(g.kmer[1:])
+            assert g.prefilter == bool(d[o + "_prefilter"][j])
+            if noise[i]:
+                continue
+            vals = np.array([g.prep, g.pvalue, g.kbeta, g.bse, g.frac_h2], dtype=float)
+            w = rows[j]
+            ok = (np.isnan(vals) & np.isnan(w)) | (np.abs(vals - w) <= 1e-6 * np.abs(w) + 1e-300)
+            assert ok.all(), (g.kmer, vals, w)
+            assert set(n for b, n in enumerate(NOTE_ORDER) if (int(d[o + "_notes"][j]) >> b) & 1) == g.notes
+            assert g.filter == bool(d[o + "_filter"][j])
+        assert (mat[:, ~keep] == 0).all()
