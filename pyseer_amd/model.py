@@ -264,3 +264,34 @@ def fixed_effects_regression(variant, p, k, m, c, af, pattern, lineage_effects, 
         ml = int(fe.engine.lineage_batch(bits)[0])
         s = s._replace(max_lineage=None if ml < 0 else ml)
     return s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The remaining names of pyseer/model.py's per-variant surface, with the reference's signatures
+# ---------------------------------------------------------------------------------------------------------------
+def pre_filtering(p, k, continuous):
+    """pyseer/model.py:31-70 -> (prep, bad_chisq), on the host (the kernels compute it from packed bits for whole batches)."""
+    return host_pre_filtering(np.asarray(p, dtype=float), np.asarray(k, dtype=float), continuous)
+
+
+_lineage_engine = {}
+
+
+def fit_lineage_effect(lin, c, k):
+    """pyseer/model.py:151-199: index of the lineage most associated with the variant (largest |beta|/bse in the logistic fit of
+    k on [1, lin, c]), or None when that fit fails.  Runs k_glm_lineage for the one variant."""
+    from .engine import Engine
+    lin = np.asarray(lin, dtype=float)
+    n = lin.shape[0]
+    cv = np.asarray(getattr(c, "values", c), dtype=float) if c is not None else np.zeros((n, 0))
+    key = (id(lin), id(c), n)
+    eng = _lineage_engine.get(key)
+    if eng is None:
+        for old in list(_lineage_engine.values()):
+            old.close()
+        _lineage_engine.clear()
+        eng = Engine(n)
+        eng.lineage_setup(lin, cv if (cv.ndim == 2 and cv.shape[0] == n and cv.shape[1] > 0) else None)
+        _lineage_engine[key] = eng
+    ml = int(eng.lineage_batch(pack_variants(np.asarray(k, dtype=float).reshape(1, -1)))[0])
+    return None if ml < 0 else ml

@@ -242,3 +242,23 @@ def test_reference_unit_scenarios_through_the_drop_in(tag):
     assert set(n for i, n in enumerate(NOTE_ORDER) if (int(nm) >> i) & 1) == s.notes
     assert (s.prefilter, s.filter) == (bool(pf), bool(fl))
     assert (s.kmer, s.pattern, s.af, s.kstrains, s.nkstrains, s.max_lineage) == ("variant", b"pattern", 0.2, ["k1"], ["nk1"], None)
+
+
+def test_pre_filtering_and_fit_lineage_effect_by_name():
+    """pyseer.model.pre_filtering / fit_lineage_effect under their own names: the literals of tests/model_test.py:89-115 and the
+    lineage goldens."""
+    from pyseer_amd.model import pre_filtering, fit_lineage_effect
+    d = np.load(os.path.join(G, "model_unit.npz"))
+    prep, bad = pre_filtering(d["p_binary"], d["k"], False)
+    assert abs(prep - 0.5365065578449575) < 1e-12 and not bad
+    prep, bad = pre_filtering(d["p_continuous"], d["k"], True)
+    assert abs(prep - 0.29623810011571716) < 1e-12 and not bad
+    p2 = np.concatenate((np.ones(50), np.zeros(50))); k2 = np.concatenate((np.ones(45), np.zeros(55)))
+    prep, bad = pre_filtering(p2, k2, False)
+    assert abs(prep / 1.4919966396986922e-19 - 1) < 1e-9 and bad
+    g = np.load(os.path.join(G, "lineage_N300_l10_j2.npz"))
+    lin, cov, K, want = g["lin"].astype(float), g["cov"].astype(float), g["K"], g["max_lineage"]
+    from test_oracle_golden import _same_or_tied
+    idx = list(range(0, K.shape[0], 5))
+    got = [fit_lineage_effect(lin, cov, K[v]) for v in idx]
+    _same_or_tied(got, [None if want[v] < 0 else int(want[v]) for v in idx], lin, cov, K[idx])
