@@ -389,13 +389,15 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
     // barrier_s: every wave's pieces of stages <= s+1 have landed and nobody reads stage s-1 any more, so its slot is refilled
     // with stage s + QF_AHEAD.  Landing one stage EARLY lets the last sub-step of stage s prefetch the first fragments and bit
     // words of stage s+1, so no wave starts a stage by waiting on LDS.  (Tried and measured slower, +1.4 % / +3 %: taking the
-    // barrier half a stage apart on the two waves that share a SIMD; the stalls are not a phase-alignment effect.)
+    // barrier half a stage apart on the two waves that share a SIMD; the stalls are not a phase-alignment effect.  The barrier
+    // itself: a timing build without it (SEERHIP_QF=46) runs 4.7 % faster, but one barrier per TWO stages over a 6-slot ring gains
+    // only 0.25 %: what costs is the waves waiting for each other, not the instruction.)
     auto sync_refill = [&](int s) {
         const int newer = max(0, min(total - 2 - s, QF_AHEAD - 2));   // stages allowed to be still in flight: s+2 .. s+QF_AHEAD-1
         if (!(ABL & 1)) {
             if (newer >= 3) qf_wait_vm<9>(); else if (newer == 2) qf_wait_vm<6>(); else if (newer == 1) qf_wait_vm<3>(); else qf_wait_vm<0>();
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 16)) __builtin_amdgcn_s_barrier();            // ABL 16: timing ablation without the barrier (results garbage)
         __builtin_amdgcn_sched_barrier(0);
         if (s + QF_AHEAD < total) fetch();
     };
@@ -738,12 +740,16 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     switch (variant) {          // 30 + mask = timing ablations (results meaningless)
     case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    case 53: hipLaunchKernelGGL(k_lmm_quadform_i8<23>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    case 46: hipLaunchKernelGGL(k_lmm_quadform_i8<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 38: hipLaunchKernelGGL(k_lmm_quadform_i8<8>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
     default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
