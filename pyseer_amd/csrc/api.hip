@@ -3,6 +3,8 @@
 #include "common.h"
 #include <string>
 #include <vector>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -75,6 +77,7 @@ struct sh_ctx {
     hipStream_t copy_stream = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     uint8_t *hb_bits[2] = {nullptr, nullptr}; double *hb_out[2] = {nullptr, nullptr}; uint32_t *hb_flags[2] = {nullptr, nullptr};
     int64_t hb_cap_bits = 0, hb_cap_out = 0;
+    uint8_t *hp_bits[2] = {nullptr, nullptr}; int64_t hp_cap = 0;     // pinned host staging (pageable user rows are copied in by several threads)
     // ---- staging for the host-pointer entry points
     int64_t cap_bits = 0, cap_out = 0;
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
@@ -111,6 +114,21 @@ static int ensure_staging(sh_ctx *c, int64_t bits_bytes, int64_t out_doubles, in
     return SH_OK;
 }
 
+// user rows -> pinned staging with several host threads: a single-threaded pageable hipMemcpy caps the whole path at ~10 GB/s
+static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nt = (int)std::min<size_t>(std::min(16u, hw), n / ((size_t)4 << 20) + 1);
+    if (nt <= 1) { std::memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n / nt + 63) & ~(size_t)63;
+    for (int t = 0; t < nt; ++t) {
+        const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back([=] { std::memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto &x : th) x.join();
+}
+
 // Host-pointer batches, pipelined: the packed rows of chunk i+1 cross PCIe on a copy stream while chunk i runs its kernels
 // on the compute stream (two device staging sets; the results of chunk i-1 are copied back after chunk i has been queued).
 // outs[a] receives row a of the (nrow x V) SoA result; rows >= 5 of the GLM result are delivered row-major through `betas`.
@@ -133,11 +151,19 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
         }
         c->hb_cap_bits = cap * row_bytes; c->hb_cap_out = cap * nrow;
     }
+    if (cap * row_bytes > c->hp_cap) {
+        for (int b = 0; b < 2; ++b) { if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]); c->hp_bits[b] = nullptr; HIPCHK(hipHostMalloc((void **)&c->hp_bits[b], cap * row_bytes, hipHostMallocDefault)); }
+        c->hp_cap = cap * row_bytes;
+    }
     std::vector<double> tmp;
-    const int64_t nchunk = (V + CH - 1) / CH;
+    // chunk boundaries: a shorter first chunk (2^17) so that the kernels start after 83 MB of upload instead of 166 MB; 2^17 and
+    // 2^18 variants are whole numbers of block rounds for the LMM kernel (tiles x 5 limbs on 256 CUs)
+    std::vector<int64_t> cut{0};
+    for (int64_t step = 1 << 17; cut.back() < V; step = CH) cut.push_back(std::min(V, cut.back() + step));
+    const int64_t nchunk = (int64_t)cut.size() - 1;
     auto drain = [&](int64_t i) -> int {                 // chunk i's results: copy stream, after its kernels (not behind chunk i+1's)
         const int b = (int)(i & 1);
-        const int64_t s = i * CH, n = std::min(CH, V - s);
+        const int64_t s = cut[i], n = cut[i + 1] - s;
         HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
         for (int a = 0; a < 5; ++a)
             HIPCHK(hipMemcpyAsync(outs[a] + s, c->hb_out[b] + (size_t)a * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
@@ -147,16 +173,24 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
         for (int j = 0; j < q; ++j) for (int64_t v = 0; v < n; ++v) betas[(size_t)(s + v) * q + j] = tmp[(size_t)j * n + v];
         return SH_OK;
     };
+    const bool dbg = std::getenv("SEERHIP_HOST_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t00 = now();
     for (int64_t i = 0; i < nchunk; ++i) {
         const int b = (int)(i & 1);
-        const int64_t s = i * CH, n = std::min(CH, V - s);
-        // staging set b is free: chunk i-2 was drained (copy stream synchronised) before this point
-        HIPCHK(hipMemcpyAsync(c->hb_bits[b], bits + s * row_bytes, n * row_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        const int64_t s = cut[i], n = cut[i + 1] - s;
+        const double t0 = now();
+        // staging set b (pinned host + device) is free: chunk i-2 was drained (copy stream synchronised) before this point
+        parallel_copy(c->hp_bits[b], bits + s * row_bytes, (size_t)(n * row_bytes));
+        const double t1 = now();
+        HIPCHK(hipMemcpyAsync(c->hb_bits[b], c->hp_bits[b], n * row_bytes, hipMemcpyHostToDevice, c->copy_stream));
         HIPCHK(hipEventRecord(c->ev_h2d[b], c->copy_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
         int rc = inner_dev(c->hb_bits[b], n, c->hb_out[b], c->hb_flags[b]); if (rc) return rc;
         HIPCHK(hipEventRecord(c->ev_done[b], c->stream));
+        const double t2 = now();
         if (i >= 1) { rc = drain(i - 1); if (rc) return rc; }
+        if (dbg) fprintf(stderr, "[host_batch] chunk %lld n=%lld: stage %.2f ms, queue %.2f ms, drain(prev) %.2f ms, t=%.2f\n", (long long)i, (long long)n, t1 - t0, t2 - t1, now() - t2, now() - t00);
     }
     return drain(nchunk - 1);
 }
@@ -239,6 +273,7 @@ void sh_destroy(sh_ctx *c)
     hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);
     for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    for (int b = 0; b < 2; ++b) if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]);
     hipFree(c->dd_h); hipFree(c->dd_keys); hipFree(c->dd_idx); hipFree(c->dd_rep); hipFree(c->dd_slot); hipFree(c->dd_n); hipFree(c->dd_bits); hipFree(c->dd_out); hipFree(c->dd_flags);
     hipFree(c->sim_K); hipFree(c->sim_S); hipFree(c->sim_keep); hipFree(c->sim_out);
     glm_free(&c->glm);

@@ -101,7 +101,7 @@ class Engine(object):
         """bits: (V, row_bytes) uint8 host array -> dict of host arrays (raw statistics + flags)."""
         bits = self._bits(bits)
         V = bits.shape[0]
-        o = np.full((5, V), np.nan); fl = np.zeros(V, dtype=np.uint32)
+        o = np.empty((5, V)); fl = np.empty(V, dtype=np.uint32)           # every element is written by the call
         if V:
             _abi.check(self._lib.sh_lmm_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
                                               _dp(o[2]), _dp(o[3]), _dp(o[4]), fl.ctypes.data_as(_abi.c_u32p)))
@@ -134,7 +134,9 @@ class Engine(object):
     def glm_batch(self, bits):
         bits = self._bits(bits)
         V = bits.shape[0]; q = self.q
-        o = np.full((5, V), np.nan); betas = np.full((V, max(q, 1)), np.nan); fl = np.zeros(V, dtype=np.uint32)
+        o = np.empty((5, V)); betas = np.empty((V, max(q, 1))); fl = np.empty(V, dtype=np.uint32)   # all written by the call
+        if q == 0:
+            betas[:] = np.nan
         if V:
             _abi.check(self._lib.sh_glm_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
                                               _dp(o[2]), _dp(o[3]), _dp(o[4]), _dp(betas), fl.ctypes.data_as(_abi.c_u32p)))
