@@ -1,0 +1,44 @@
+// glm_common.h -- pieces shared by the register-resident fixed-effects kernels (glm_kernels.hip, q <= 14) and the wide-design
+// kernels (glm_wide.hip, q <= 32)
+#pragma once
+#include "common.h"
+
+__host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, i >= j
+
+struct GlmParams {
+    int N, NB64, continuous, force_firth;
+    int n1, n0;                   // #(y==1), #(y==0)
+    double ymean_logit;           // log(mean(y)/(1-mean(y)))   model.py:323-324
+    double yc_sum, yc_sq;         // centred-phenotype sums (Welch prefilter)
+    double null_llf, null_firth, pret, lrtt;
+    double min_af, max_af; int af_on;
+    int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
+    const float *zz;              // per-sample products table for fast_pass_mfma (FastCols<Q>::STRIDE floats per sample), or null
+};
+
+__device__ __forceinline__ double logit_cdf(double x) { return 1.0 / (1.0 + exp(-x)); }    // SM Logit.cdf
+
+// ---- a1 prefilter from the packed bits ------------------------------------------------------------------------------
+__device__ __forceinline__ double glm_prefilter(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int NB64, int N,
+                                                const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                const double *__restrict__ yc, const GlmParams &P, bool *bad, int *mcount)
+{
+    int t11 = 0, t01 = 0, m = 0;
+    double s1 = 0, q1 = 0;
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w = T[(int64_t)sb * Vpad + v];
+        m += __popcll(w); t11 += __popcll(w & y1[sb]); t01 += __popcll(w & y0[sb]);
+        if (P.continuous) {
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; ++b) {
+                const double xd = (double)(unsigned)((w >> b) & 1ull), t = yc[sb * 64 + b];
+                s1 = fma(xd, t, s1); q1 = fma(xd, t * t, q1);
+            }
+        }
+    }
+    *mcount = m;
+    *bad = false;
+    if (P.continuous) return sh_prefilter_welch((double)m, s1, q1, (double)(N - m), P.yc_sum - s1, P.yc_sq - q1);
+    return sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, bad);
+}
+

@@ -1,0 +1,426 @@
+// glm_wide.hip -- fixed-effects regression for WIDE designs (15 <= q <= 32 covariate columns), one variant per lane.
+//
+// glm_kernels.hip keeps the p x p matrices of a variant in registers, fully unrolled, which stops at q = 14 (p = 16: 136 fp64
+// accumulators).  The reference has no such limit (pyseer/model.py:274-297 concatenates any number of MDS components and
+// covariate columns; a categorical covariate alone contributes one column per level).  These kernels restate the same
+// algorithms with a run-time p <= 34 on per-lane scratch arrays and rolled loops: statsmodels' Newton (start vector, ridge,
+// 35 iterations, separation callback, final un-ridged inverse), fit_firth with numpy's pinv, OLS through pinv.  Same notes,
+// same filters, same outputs; throughput is that of scratch memory, not of registers (they exist so that a wide design runs
+// at all: the reference manages ~100 variants/s/core on them).
+#include "glm_common.h"
+
+#define WIDE_PM 34
+
+// ---- dense helpers, row-major pc x pc inside arrays of capacity WIDE_PM^2 ------------------------------------------------
+// LU with partial pivoting in place; returns the determinant (0 when a pivot is exactly zero: numpy's LinAlgError / det 0)
+__device__ __noinline__ double w_lu(double *A, int *piv, int pc)
+{
+    double det = 1.0;
+#pragma unroll 1
+    for (int c = 0; c < pc; ++c) {
+        int p = c; double best = fabs(A[c * pc + c]);
+#pragma unroll 1
+        for (int r = c + 1; r < pc; ++r) { const double t = fabs(A[r * pc + c]); if (t > best) { best = t; p = r; } }
+        piv[c] = p;
+        if (p != c) {
+#pragma unroll 1
+            for (int j = 0; j < pc; ++j) { const double t = A[c * pc + j]; A[c * pc + j] = A[p * pc + j]; A[p * pc + j] = t; }
+            det = -det;
+        }
+        const double d = A[c * pc + c];
+        det *= d;
+        if (d == 0.0) return 0.0;
+#pragma unroll 1
+        for (int r = c + 1; r < pc; ++r) {
+            const double f = A[r * pc + c] / d;
+            A[r * pc + c] = f;
+#pragma unroll 1
+            for (int j = c + 1; j < pc; ++j) A[r * pc + j] = fma(-f, A[c * pc + j], A[r * pc + j]);
+        }
+    }
+    return det;
+}
+
+__device__ __noinline__ void w_lu_solve(const double *LU, const int *piv, int pc, double *b)
+{
+#pragma unroll 1
+    for (int c = 0; c < pc; ++c) { const int p = piv[c]; if (p != c) { const double t = b[c]; b[c] = b[p]; b[p] = t; }
+#pragma unroll 1
+        for (int r = c + 1; r < pc; ++r) b[r] = fma(-LU[r * pc + c], b[c], b[r]); }
+#pragma unroll 1
+    for (int c = pc - 1; c >= 0; --c) {
+#pragma unroll 1
+        for (int j = c + 1; j < pc; ++j) b[c] = fma(-LU[c * pc + j], b[j], b[c]);
+        b[c] /= LU[c * pc + c];
+    }
+}
+
+// numpy.linalg.pinv of a symmetric matrix: cyclic Jacobi eigen-decomposition, eigenvalues <= rcond * max dropped
+__device__ __noinline__ void w_pinv(const double *Ain, double *Pm, int pc, double rcond, int *rank)
+{
+    double A[WIDE_PM * WIDE_PM], Vv[WIDE_PM * WIDE_PM];
+#pragma unroll 1
+    for (int a = 0; a < pc * pc; ++a) { A[a] = Ain[a]; Vv[a] = 0.0; }
+#pragma unroll 1
+    for (int a = 0; a < pc; ++a) Vv[a * pc + a] = 1.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < pc; ++i) { dg = fma(A[i * pc + i], A[i * pc + i], dg);
+#pragma unroll 1
+            for (int j = i + 1; j < pc; ++j) off = fma(A[i * pc + j], A[i * pc + j], off); }
+        if (off <= 1e-34 * (dg + off) || off == 0.0) break;
+#pragma unroll 1
+        for (int p = 0; p < pc; ++p)
+#pragma unroll 1
+            for (int q = p + 1; q < pc; ++q) {
+                const double apq = A[p * pc + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * pc + q] - A[p * pc + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll 1
+                for (int k = 0; k < pc; ++k) { const double akp = A[k * pc + p], akq = A[k * pc + q]; A[k * pc + p] = c * akp - s * akq; A[k * pc + q] = s * akp + c * akq; }
+#pragma unroll 1
+                for (int k = 0; k < pc; ++k) { const double apk = A[p * pc + k], aqk = A[q * pc + k]; A[p * pc + k] = c * apk - s * aqk; A[q * pc + k] = s * apk + c * aqk; }
+#pragma unroll 1
+                for (int k = 0; k < pc; ++k) { const double vkp = Vv[k * pc + p], vkq = Vv[k * pc + q]; Vv[k * pc + p] = c * vkp - s * vkq; Vv[k * pc + q] = s * vkp + c * vkq; }
+            }
+    }
+    double smax = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < pc; ++i) smax = fmax(smax, fabs(A[i * pc + i]));
+    if (rank) { int r = 0;
+#pragma unroll 1
+        for (int k = 0; k < pc; ++k) r += (fabs(A[k * pc + k]) > rcond * smax) ? 1 : 0;
+        *rank = r; }
+#pragma unroll 1
+    for (int i = 0; i < pc; ++i)
+#pragma unroll 1
+        for (int j = 0; j < pc; ++j) {
+            double s = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < pc; ++k) { const double w = A[k * pc + k]; if (fabs(w) > rcond * smax) s = fma(Vv[i * pc + k] / w, Vv[j * pc + k], s); }
+            Pm[i * pc + j] = s;
+        }
+}
+
+// one pass over the samples at beta: I = X^T W X (full, row-major), optional score g, log-likelihood, max |y - mu|
+__device__ __noinline__ void w_info(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64, int q,
+                                    const double *__restrict__ y, const double *__restrict__ W, const double *beta, double *I,
+                                    double *g, double *ll_out, double *maxdev_out)
+{
+    const int pc = q + 2;
+#pragma unroll 1
+    for (int a = 0; a < pc * pc; ++a) I[a] = 0.0;
+    if (g) {
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) g[a] = 0.0; }
+    double ll = 0.0, maxdev = 0.0;
+#pragma unroll 1
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double x[WIDE_PM];
+            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll 1
+            for (int j = 0; j < q; ++j) x[2 + j] = W[(int64_t)i * q + j];
+            double eta = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) eta = fma(beta[a], x[a], eta);
+            const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu), yi = y[i], r = yi - mu;
+            maxdev = fmax(maxdev, fabs(r));
+            const double lm = log(mu);
+            ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) {
+                if (g) g[a] = fma(r, x[a], g[a]);
+                const double wa = wgt * x[a];
+#pragma unroll 1
+                for (int c = 0; c <= a; ++c) I[a * pc + c] = fma(wa, x[c], I[a * pc + c]);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int a = 0; a < pc; ++a)
+#pragma unroll 1
+        for (int c = a + 1; c < pc; ++c) I[a * pc + c] = I[c * pc + a];
+    *ll_out = ll; *maxdev_out = maxdev;
+}
+
+// ---- kernel 1: prefilter + routing (+ logistic Newton and its decisions for a binary phenotype) -------------------------
+__global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
+                                                 const double *__restrict__ y, const double *__restrict__ W,
+                                                 const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                 const double *__restrict__ yc, GlmParams P, double *__restrict__ out,
+                                                 uint32_t *__restrict__ flags, int *__restrict__ firth_list,
+                                                 int *__restrict__ firth_count, int *__restrict__ ols_list, int *__restrict__ ols_count)
+{
+    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    const int pc = q + 2, N = P.N, NB64 = P.NB64;
+    const double nobs = (double)N;
+    uint32_t fl = 0;
+    bool want_fit = true, to_firth = false, bad = false;
+    int m = 0;
+    double prep = glm_prefilter(T, Vpad, v, NB64, N, y1, y0, yc, P, &bad, &m);
+    if (P.af_on) {
+        const double af = (double)m / (double)N;
+        if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; want_fit = false; prep = NAN; }
+    }
+    if (want_fit) {
+        if (bad) fl |= SH_NOTE_BAD_CHISQ;
+        if (prep > P.pret || !isfinite(prep)) { fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER; want_fit = false; }   // model.py:266 (>)
+    }
+    out[v] = prep; out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+#pragma unroll 1
+    for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = NAN;
+    if (P.continuous) {
+        flags[v] = fl;
+        if (want_fit) { const int s = atomicAdd(ols_count, 1); ols_list[s] = (int)v; }
+        return;
+    }
+    if (want_fit && (bad || P.force_firth)) { to_firth = true; want_fit = false; }
+    if (want_fit) {
+        double beta[WIDE_PM], g[WIDE_PM], I[WIDE_PM * WIDE_PM];
+        int piv[WIDE_PM];
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) beta[a] = 0.0;
+        beta[0] = P.ymean_logit;                                                       // model.py:323-324
+        int status = 0, it = 0;
+        double ll, maxdev;
+#pragma unroll 1
+        for (;;) {
+            w_info(T, Vpad, v, N, NB64, q, y, W, beta, I, g, &ll, &maxdev);
+            if (it > 0 && maxdev <= 1e-8) { status = 1; break; }                       // _check_perfect_pred
+            // newparams = oldparams - inv(H/n + 1e-10 I) . score/n   with H = -X^T W X   (optimizer.py:415-423)
+#pragma unroll 1
+            for (int a = 0; a < pc * pc; ++a) I[a] = I[a] / nobs;
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) { I[a * pc + a] -= 1e-10; g[a] = g[a] / nobs; }
+            if (w_lu(I, piv, pc) == 0.0) { status = 2; break; }
+            w_lu_solve(I, piv, pc, g);
+            bool moving = false;
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
+            ++it;
+            if (!moving || it >= 35) break;
+        }
+        double llf = NAN, bse1 = NAN;
+        if (status == 0) {                                                             // results at the final beta
+            w_info(T, Vpad, v, N, NB64, q, y, W, beta, I, nullptr, &ll, &maxdev);
+            if (maxdev <= 1e-8) status = 1;                                            // callback after the last update
+            else {
+                llf = ll;
+                // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534); only bse[1] is used (model.py:332)
+                double amax = 0.0;
+#pragma unroll 1
+                for (int a = 0; a < pc * pc; ++a) { I[a] = I[a] / nobs; amax = fmax(amax, fabs(I[a])); }
+                const double det = w_lu(I, piv, pc);
+                bool tiny = det == 0.0;
+#pragma unroll 1
+                for (int a = 0; a < pc && !tiny; ++a) tiny = fabs(I[a * pc + a]) <= 4.0e-16 * amax;
+                if (tiny) status = 2;
+                else {
+#pragma unroll 1
+                    for (int a = 0; a < pc; ++a) g[a] = (a == 1) ? 1.0 : 0.0;
+                    w_lu_solve(I, piv, pc, g);
+                    bse1 = sqrt(g[1] / nobs);
+                }
+            }
+        }
+        if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }               // model.py:345-352
+        else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
+        else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }              // model.py:332-334
+        else {
+            const double lrstat = -2.0 * (P.null_llf - llf);
+            double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);           // model.py:336-339
+            out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = bse1; out[4 * V + v] = beta[0];
+#pragma unroll 1
+            for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+            if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
+        }
+    }
+    flags[v] = fl;
+    if (to_firth) { const int s = atomicAdd(firth_count, 1); firth_list[s] = (int)v; }
+}
+
+// ---- kernel 2: fit_firth (model.py:414-504) with numpy's pinv, for the listed variants ------------------------------------
+__global__ __launch_bounds__(64) void k_glm_wide_firth(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
+                                                       const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                       const int *__restrict__ list, const int *__restrict__ count,
+                                                       double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    const int cnt = *count;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= cnt) return;
+    const int64_t v = list[slot];
+    const int pc = q + 2, N = P.N, NB64 = P.NB64;
+    double beta[WIDE_PM], cand[WIDE_PM], U[WIDE_PM], I[WIDE_PM * WIDE_PM], Vm[WIDE_PM * WIDE_PM], L[WIDE_PM * WIDE_PM];
+    int piv[WIDE_PM];
+#pragma unroll 1
+    for (int a = 0; a < pc; ++a) beta[a] = 0.0;
+    beta[0] = P.ymean_logit;
+    double ll, md;
+    w_info(T, Vpad, v, N, NB64, q, y, W, beta, I, nullptr, &ll, &md);
+    auto logdet = [&]() { for (int a = 0; a < pc * pc; ++a) L[a] = I[a]; return log(w_lu(L, piv, pc)); };
+    double Fcur = -(ll + 0.5 * logdet());                                              // firth_likelihood, model.py:410-411
+    double i11 = I[pc + 1], sn_prev = INFINITY;
+    bool failed = false, conv = false;
+#pragma unroll 1
+    for (int iter = 0; iter < 1000 && !failed && !conv; ++iter) {
+        w_pinv(I, Vm, pc, 1e-15, nullptr);                                             // model.py:450
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) U[a] = 0.0;
+#pragma unroll 1
+        for (int sb = 0; sb < NB64; ++sb) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+#pragma unroll 1
+            for (int b = 0; b < nb; ++b) {
+                const int i = sb * 64 + b;
+                double x[WIDE_PM];
+                x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll 1
+                for (int j = 0; j < q; ++j) x[2 + j] = W[(int64_t)i * q + j];
+                double eta = 0.0, qf = 0.0;
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) eta = fma(beta[a], x[a], eta);
+                const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) { double s = 0.0;
+#pragma unroll 1
+                    for (int c = 0; c < pc; ++c) s = fma(Vm[a * pc + c], x[c], s);
+                    qf = fma(x[a], s, qf); }
+                const double res = y[i] - mu + wgt * qf * (0.5 - mu);                  // hat diagonal, model.py:455-462
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) U[a] = fma(x[a], res, U[a]);
+            }
+        }
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) { double s = 0.0;
+#pragma unroll 1
+            for (int c = 0; c < pc; ++c) s = fma(Vm[a * pc + c], U[c], s);
+            cand[a] = beta[a] + s; }
+        int halvings = 0; double Fcand;
+#pragma unroll 1
+        for (;;) {
+            w_info(T, Vpad, v, N, NB64, q, y, W, cand, I, nullptr, &ll, &md);
+            Fcand = -(ll + 0.5 * logdet());
+            double stepmax = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) stepmax = fmax(stepmax, fabs(cand[a] - beta[a]));
+            // steps below 1e-10 are accepted outright: F(new) > F(old) is rounding noise there (see k_glm_firth)
+            if (!(Fcand > Fcur) || stepmax < 1e-10) break;                             // step halving, model.py:467-474
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
+            if (++halvings > 1000) { failed = true; break; }
+        }
+        if (failed) break;
+        double sn = 0.0;
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) { const double d = cand[a] - beta[a]; sn = fma(d, d, sn); beta[a] = cand[a]; }
+        sn = sqrt(sn); Fcur = Fcand; i11 = I[pc + 1];
+        if (iter > 0 && sn_prev < 1e-4) conv = true;                                   // tests the PREVIOUS step, model.py:477-479
+        sn_prev = sn;
+    }
+    if (!conv) failed = true;
+    uint32_t fl = flags[v];
+    if (failed) {
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                                     // model.py:357-362
+        out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+#pragma unroll 1
+        for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = NAN;
+    } else {
+        const double lrstat = -2.0 * (P.null_firth - (-Fcur));
+        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);               // model.py:366-369
+        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0];   // bse = sqrt(I11), model.py:491
+#pragma unroll 1
+        for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    }
+    flags[v] = fl;
+}
+
+// ---- kernel 3: OLS through pinv (statsmodels OLS.fit(), model.py:299-312) for the listed variants ---------------------------
+__global__ __launch_bounds__(64) void k_glm_wide_ols(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
+                                                     const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                     const int *__restrict__ list, const int *__restrict__ count,
+                                                     double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    const int cnt = *count;
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= cnt) return;
+    const int64_t v = list[slot];
+    const int pc = q + 2, N = P.N, NB64 = P.NB64;
+    double A[WIDE_PM * WIDE_PM], Pm[WIDE_PM * WIDE_PM], rhs[WIDE_PM], beta[WIDE_PM];
+#pragma unroll 1
+    for (int a = 0; a < pc * pc; ++a) A[a] = 0.0;
+#pragma unroll 1
+    for (int a = 0; a < pc; ++a) rhs[a] = 0.0;
+#pragma unroll 1
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double x[WIDE_PM];
+            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+#pragma unroll 1
+            for (int j = 0; j < q; ++j) x[2 + j] = W[(int64_t)i * q + j];
+#pragma unroll 1
+            for (int a = 0; a < pc; ++a) {
+                rhs[a] = fma(x[a], y[i], rhs[a]);
+#pragma unroll 1
+                for (int c = 0; c < pc; ++c) A[a * pc + c] = fma(x[a], x[c], A[a * pc + c]);
+            }
+        }
+    }
+    int rank = pc;
+    w_pinv(A, Pm, pc, 1e-10, &rank);                       // see k_glm_ols_pinv for the cut-off
+#pragma unroll 1
+    for (int a = 0; a < pc; ++a) { double s = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < pc; ++c) s = fma(Pm[a * pc + c], rhs[c], s);
+        beta[a] = s; }
+    double ssr = 0.0;
+#pragma unroll 1
+    for (int sb = 0; sb < NB64; ++sb) {
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            const int i = sb * 64 + b;
+            double f = fma(beta[1], (double)(unsigned)((w64 >> b) & 1ull), beta[0]);
+#pragma unroll 1
+            for (int j = 0; j < q; ++j) f = fma(beta[2 + j], W[(int64_t)i * q + j], f);
+            const double r = y[i] - f;
+            ssr = fma(r, r, ssr);
+        }
+    }
+    const double dfr = (double)(N - rank);
+    const double kbse = sqrt(ssr / dfr * Pm[pc + 1]);
+    const double pval = sh_t_sf2(beta[1] / kbse, dfr);
+    uint32_t fl = flags[v];
+    if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+    out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = kbse; out[4 * V + v] = beta[0];
+#pragma unroll 1
+    for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+    flags[v] = fl;
+}
+
+extern "C" hipError_t shk_glm_wide(hipStream_t st, int which, int q, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
+                                   const double *W, const uint64_t *y1, const uint64_t *y0, const double *yc, GlmParams P,
+                                   double *out, uint32_t *flags, int *flist, int *fcount, int *olist, int *ocount)
+{
+    const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
+    if (which == 0) hipLaunchKernelGGL(k_glm_wide, grid, blk, 0, st, T, Vpad, V, q, y, W, y1, y0, yc, P, out, flags, flist, fcount, olist, ocount);
+    else if (which == 1) hipLaunchKernelGGL(k_glm_wide_firth, grid, blk, 0, st, T, Vpad, V, q, y, W, P, flist, fcount, out, flags);
+    else hipLaunchKernelGGL(k_glm_wide_ols, grid, blk, 0, st, T, Vpad, V, q, y, W, P, olist, ocount, out, flags);
+    return hipGetLastError();
+}

@@ -262,3 +262,36 @@ def test_pre_filtering_and_fit_lineage_effect_by_name():
     idx = list(range(0, K.shape[0], 5))
     got = [fit_lineage_effect(lin, cov, K[v]) for v in idx]
     _same_or_tied(got, [None if want[v] < 0 else int(want[v]) for v in idx], lin, cov, K[idx])
+
+
+@pytest.mark.parametrize("N,q,cont", [(400, 15, False), (600, 22, False), (500, 32, False), (400, 18, True)])
+def test_wide_designs_vs_oracle(N, q, cont):
+    """More than 14 covariate columns (the reference has no limit: pyseer/model.py:274-297): run-time-width kernels on scratch
+    arrays (glm_wide.hip), same statistics, notes and filters as the oracle, Firth-routed variants included."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(31 + N + q)
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.3 + 1.2 * W[:, 0] - 0.8 * W[:, 1]
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    V = 96
+    af = np.concatenate([rng.uniform(0.05, 0.95, V - 12), rng.uniform(0.004, 0.02, 12)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    keep = (K.mean(axis=1) >= 0.01) & (K.mean(axis=1) <= 0.99)
+    K = K[keep]
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, cont).llf
+    nf = np.nan if cont else fit_null(y, W, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W, cont, 1.0, 1.0, nl, nf)
+    e = Engine(N)
+    e.glm_setup(y, W, cont, nl, nf)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    firth = (want["notes"] & 0x7C) != 0
+    assert cont or firth.any()
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(r[f][~firth], want[f][~firth], atol=1e-12, what=f)
+        close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
+    close(r["betas"][~firth], want["betas"][~firth], atol=1e-12, what="betas")
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
