@@ -414,6 +414,92 @@ __global__ __launch_bounds__(64) void k_glm_wide_ols(const uint64_t *__restrict_
     flags[v] = fl;
 }
 
+// ---- kernel 4: fit_lineage_effect (model.py:151-199) for 17 <= 1 + lineages + covariates <= WIDE_LIN_PM ------------------------
+// (k_glm_lineage in glm_kernels.hip, with a run-time width.)  X: N x pc row-major, intercept in column 0, lineages next.
+#define WIDE_LIN_PM 50
+__global__ __launch_bounds__(64) void k_glm_wide_lineage(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int N, int NB64,
+                                                         const double *__restrict__ X, int pc, int nlin, int *__restrict__ out)
+{
+    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (v >= V) return;
+    double beta[WIDE_LIN_PM], g[WIDE_LIN_PM], H[WIDE_LIN_PM * WIDE_LIN_PM];
+    int piv[WIDE_LIN_PM];
+#pragma unroll 1
+    for (int a = 0; a < pc; ++a) beta[a] = 0.0;
+    int it = 0, status = 0, best = -1;
+    bool fin = false;
+    const double nobs = (double)N;
+#pragma unroll 1
+    for (;;) {
+        double maxdev = 0.0;
+#pragma unroll 1
+        for (int a = 0; a < pc * pc; ++a) H[a] = 0.0;
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) g[a] = 0.0;
+#pragma unroll 1
+        for (int sb = 0; sb < NB64; ++sb) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+#pragma unroll 1
+            for (int b = 0; b < nb; ++b) {
+                const double *x = X + (int64_t)(sb * 64 + b) * pc;
+                double eta = 0.0;
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) eta = fma(beta[a], x[a], eta);
+                const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+                const double r = (double)(unsigned)((w64 >> b) & 1ull) - mu;
+                maxdev = fmax(maxdev, fabs(r));
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) {
+                    g[a] = fma(r, x[a], g[a]);
+                    const double wa = wgt * x[a];
+#pragma unroll 1
+                    for (int c = 0; c <= a; ++c) H[a * pc + c] = fma(wa, x[c], H[a * pc + c]);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a)
+#pragma unroll 1
+            for (int c = 0; c <= a; ++c) { H[a * pc + c] /= nobs; H[c * pc + a] = H[a * pc + c]; }
+        if (it > 0 && maxdev <= 1e-8) { status = 1; break; }                           // PerfectSeparationError -> None
+        if (fin) {
+            // numpy.linalg.inv only fails on an EXACT zero pivot; huge/NaN standard errors go through np.argmax (first NaN wins)
+            if (w_lu(H, piv, pc) == 0.0) { status = 2; break; }
+            double bestw = -1.0; int first_nan = -1;
+#pragma unroll 1
+            for (int a = 1; a <= nlin; ++a) {
+#pragma unroll 1
+                for (int c = 0; c < pc; ++c) g[c] = (c == a) ? 1.0 : 0.0;
+                w_lu_solve(H, piv, pc, g);
+                const double wald = fabs(beta[a]) / sqrt(g[a] / nobs);
+                if (isnan(wald)) { if (first_nan < 0) first_nan = a - 1; }
+                else if (wald > bestw) { bestw = wald; best = a - 1; }
+            }
+            if (first_nan >= 0) best = first_nan;
+            break;
+        }
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) { H[a * pc + a] -= 1e-10; g[a] = g[a] / nobs; }
+        if (w_lu(H, piv, pc) == 0.0) { status = 2; break; }                            // LinAlgError -> None
+        w_lu_solve(H, piv, pc, g);
+        bool moving = false;
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
+        ++it;
+        if (!moving || it >= 35) fin = true;
+    }
+    out[v] = (status == 0) ? best : -1;
+}
+
+extern "C" hipError_t shk_glm_wide_lineage(hipStream_t st, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64, const double *X,
+                                           int pc, int nlin, int *out)
+{
+    if (pc > WIDE_LIN_PM) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_glm_wide_lineage, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, T, Vpad, V, N, NB64, X, pc, nlin, out);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t shk_glm_wide(hipStream_t st, int which, int q, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
                                    const double *W, const uint64_t *y1, const uint64_t *y0, const double *yc, GlmParams P,
                                    double *out, uint32_t *flags, int *flist, int *fcount, int *olist, int *ocount)

@@ -295,3 +295,30 @@ def test_wide_designs_vs_oracle(N, q, cont):
         close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
     close(r["betas"][~firth], want["betas"][~firth], atol=1e-12, what="betas")
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+
+
+@pytest.mark.parametrize("nl,j", [(20, 0), (30, 3), (16, 0)])
+def test_wide_lineage_vs_oracle(nl, j):
+    """fit_lineage_effect with more than 15 lineage/covariate columns (e.g. --lineage-clusters with many clusters)."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from test_oracle_golden import _same_or_tied
+    rng = np.random.default_rng(nl + j)
+    N, V = 900, 40
+    cl = rng.integers(0, nl + 1, N)
+    lin = np.zeros((N, nl)); lin[np.arange(N)[cl > 0], cl[cl > 0] - 1] = 1.0          # cluster indicators, one reference class
+    cov = rng.standard_normal((N, j)) if j else None
+    base = rng.uniform(0.3, 0.7, (V, nl + 1))
+    K = (rng.random((V, N)) < base[:, cl]).astype(np.uint8)
+    e = Engine(N)
+    e.lineage_setup(lin, cov)
+    got = e.lineage_batch(pack_variants(K))
+    e.close()
+    want = [orc.lineage_effect(lin, cov, K[v].astype(float)) for v in range(V)]
+    # A cluster whose members all carry (or all lack) the k-mer is quasi-separated: its coefficient diverges, and whether the
+    # weights underflow to an exactly singular Hessian (LinAlgError -> None) within the 35 iterations is decided by the rounding
+    # of the linear solves (numpy inverts, these kernels solve).  Not a parity target; everything else must agree.
+    sep = np.array([any(K[v][cl == c].sum() in (0, (cl == c).sum()) for c in range(nl + 1)) for v in range(V)])
+    assert (~sep).sum() >= V // 2
+    g = [None if x < 0 else int(x) for x in got]
+    _same_or_tied([g[v] for v in range(V) if not sep[v]], [want[v] for v in range(V) if not sep[v]], lin, cov, K[~sep])
