@@ -1,0 +1,100 @@
+"""Seeded random sweep of small configurations through both engines against the oracle: sample counts around word and tile
+edges, few and many covariates, binary and continuous phenotypes, rare and near-fixed variants, random thresholds."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-6, atol=0.0):
+    a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+    return (np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))) | \
+        (np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def _variants(rng, N, V):
+    af = np.concatenate([rng.uniform(0.03, 0.97, V - 8), [1.5 / N, 2.5 / N, 1 - 1.5 / N, 0.5, 0.5, 0.02, 0.98, 0.5]])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K[-1] = 0; K[-1, :max(1, N // 50)] = 1                      # a handful of carriers at the front
+    return K
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
+def test_lmm_random_configurations(seed):
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.lmm import mask_like_fit_lmm
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([31, 63, 64, 65, 127, 128, 129, 200, 257, 383]))
+    D = int(rng.integers(1, 6))
+    cont = bool(rng.integers(0, 2))
+    V = 72
+    k = N - D
+    U = rng.standard_normal((N, k)) / np.sqrt(N)
+    S = np.sort(rng.gamma(0.5, 2.0, k))[::-1].copy()
+    covar = np.ones((N, 1)) if D == 1 else np.c_[rng.standard_normal((N, D - 1)), np.ones((N, 1))]
+    y = rng.standard_normal(N) if cont else (rng.random(N) < 0.4).astype(float)
+    h2 = float(rng.uniform(0.0, 0.95))
+    fp, lp = (1.0, 1.0) if seed % 3 == 0 else (float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.2, 0.9)))
+    Kv = _variants(rng, N, V)
+    af = Kv.mean(axis=1)
+    afm = (~((af >= 0.01) & (af <= 0.99))).astype(np.uint8)      # 1 = af-filtered (load_var_block leaves pattern None)
+    want = orc.LmmOracle(U, S, y, covar).fit_lmm(h2, Kv.astype(float), afm, cont, fp, lp)
+    e = Engine(N)
+    e.set_af_filter(0.01, 0.99)
+    e.lmm_setup(U, S, y, covar, h2, continuous=cont, filter_pvalue=fp, lrt_pvalue=lp)
+    r = mask_like_fit_lmm(e.lmm_batch(pack_variants(Kv)))
+    e.close()
+    noise = np.zeros(V, bool) if cont else ((Kv == y).all(axis=1) | (Kv == 1 - y).all(axis=1))
+    for f, g in (("prep", "prep"), ("pvalue", "pvalue"), ("beta", "kbeta"), ("bse", "bse"), ("frac_h2", "frac_h2")):
+        ok = _close(r[f], want[g], atol=1e-12 if f in ("beta", "frac_h2") else 1e-300) | noise
+        assert ok.all(), (f, N, D, cont, np.argwhere(~ok)[:4].tolist(), r[f][~ok][:4], want[g][~ok][:4])
+    assert (((r["flags"] & 0x1FF) == want["notes"]) | noise).all()
+    assert ((((r["flags"] >> 16) & 1) == want["prefilter"])).all()
+    assert (((((r["flags"] >> 17) & 1) == want["filter"])) | noise).all()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
+def test_fixed_effects_random_configurations(seed):
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(2000 + seed)
+    N = int(rng.choice([40, 63, 64, 65, 100, 128, 129, 250, 300]))
+    q = int(rng.choice([0, 1, 2, 3, 5, 8, 11, 14, 16]))
+    cont = bool(rng.integers(0, 2))
+    V = 72
+    W = rng.standard_normal((N, q))
+    if q:
+        W /= np.abs(W).max(axis=0)
+    eta = -0.2 + (1.0 * W[:, 0] if q else 0.0)
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    pret, lrtt = (1.0, 1.0) if seed % 3 == 0 else (float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9)))
+    K = _variants(rng, N, V)
+    af = K.mean(axis=1)
+    K = K[(af >= 0.01) & (af <= 0.99)]
+    e0 = np.zeros((0, 0))
+    null = fit_null(y, W, e0, cont)
+    if null is None:
+        pytest.skip("null model not estimable for this draw")
+    nf = np.nan if cont else fit_null(y, W, e0, False, firth=True)
+    if nf is None:
+        pytest.skip("Firth null model did not converge for this draw")
+    want = orc.fixed_effects_batch(y, K.astype(float), W if q else None, cont, pret, lrtt, null.llf, nf)
+    e = Engine(N)
+    e.glm_setup(y, W, cont, null.llf, nf, pret, lrtt)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    firth = (want["notes"] & 0x7C) != 0
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        ok = _close(r[f], want[f], rtol=np.where(firth, 2e-6, 1e-6), atol=np.where(firth, 1e-6 if f != "pvalue" else 1e-300, 1e-12))
+        assert ok.all(), (f, N, q, cont, np.argwhere(~ok)[:4].tolist(), r[f][~ok][:4], want[f][~ok][:4])
+    tested = np.isfinite(want["kbeta"])
+    if q:
+        assert _close(r["betas"][tested], want["betas"][tested], rtol=2e-6, atol=1e-6).all()
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+    assert (((r["flags"] >> 16) & 1) == want["prefilter"]).all() and (((r["flags"] >> 17) & 1) == want["filter"]).all()
