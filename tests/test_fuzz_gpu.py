@@ -98,3 +98,42 @@ def test_fixed_effects_random_configurations(seed):
         assert _close(r["betas"][tested], want["betas"][tested], rtol=2e-6, atol=1e-6).all()
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
     assert (((r["flags"] >> 16) & 1) == want["prefilter"]).all() and (((r["flags"] >> 17) & 1) == want["filter"]).all()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
+def test_forced_firth_random_configurations(seed):
+    """Every variant through fit_firth (BASELINE config C4 shape, small): state-machine kernels, and the run-time-width kernel for
+    q > 14, against the oracle's fit_firth."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(3000 + seed)
+    N = int(rng.choice([60, 64, 100, 129, 200, 320]))
+    q = int(rng.choice([0, 1, 3, 6, 10, 14, 15]))
+    V = 40
+    W = rng.standard_normal((N, q))
+    if q:
+        W /= np.abs(W).max(axis=0)
+    eta = -0.2 + (1.0 * W[:, 0] if q else 0.0)
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    K = _variants(rng, N, V)
+    af = K.mean(axis=1)
+    K = K[(af >= 0.01) & (af <= 0.99)]
+    e0 = np.zeros((0, 0))
+    null = fit_null(y, W, e0, False)
+    nf = fit_null(y, W, e0, False, firth=True)
+    if null is None or nf is None:
+        pytest.skip("null model not estimable for this draw")
+    want = orc.firth_batch(y, K.astype(float), W if q else None)
+    e = Engine(N)
+    e.glm_setup(y, W, False, null.llf, nf, force_firth=True)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    ok = (want["status"] == 0) & np.isfinite(want["fitll"])
+    failed = ((r["flags"] >> 6) & 1) == 1
+    assert (failed[want["status"] != 0]).all() and not failed[ok].any()
+    for f in ("intercept", "kbeta", "bse"):
+        assert _close(r[f][ok], want[f][ok], rtol=2e-6, atol=1e-6).all(), (f, N, q)
+    lr = -2 * (nf - want["fitll"][ok])
+    want_p = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
+    assert _close(r["pvalue"][ok], want_p, rtol=5e-6, atol=1e-300).all()
