@@ -317,6 +317,13 @@ __device__ __forceinline__ uint4 qf_expand16(uint32_t bits16)
 #ifndef QF_G_AUX
 #define QF_G_AUX 0
 #endif
+#ifndef QF_JT
+#define QF_JT 2                      // 32-variant sub-tiles per wave: 2 (8 waves, two per SIMD) or 4 (4 waves, one per SIMD:
+                                     // 256 accumulators in AGPRs halve the LDS fragment reads per MFMA, but hipcc then spills 187
+                                     // VGPRs inside the MFMA loop -- correct, 5x slower; kept as a build option, not used)
+#endif
+#define QF_WAVES (16 / QF_JT)
+#define QF_DMA_PER_WAVE (24 / QF_WAVES)  // LDS-DMA wave-instructions per stage per wave: 16 pieces of G + 8 of packed bits
 #ifndef QF_NST
 #define QF_NST 5
 #endif                               // LDS ring depth (stages): s (computing), s+1 (landed, prefetched from), s+2..s+4 in flight
@@ -328,22 +335,26 @@ __device__ __forceinline__ uint4 qf_expand16(uint32_t bits16)
 __device__ __forceinline__ void qf_dma_stage(const int8_t *gsrc, const uint64_t *tsrc, int64_t Vpad, char *slot, int wave, int lane)
 {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int piece = wave * 2 + j;
+    for (int j = 0; j < 16 / QF_WAVES; ++j) {
+        const int piece = wave * (16 / QF_WAVES) + j;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void *)(slot + piece * 1024), 16, 0, QF_G_AUX);
     }
-    // bits: row (wave>>2) of the stage's two sample blocks, variants [(wave&3)*128, +128) of the block, 2 words per lane
-    const uint64_t *src = tsrc + (int64_t)(wave >> 2) * Vpad + (wave & 3) * 128 + lane * 2;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)(slot + 2 * QF_TILE_BYTES + wave * 1024), 16, 0, 0);
+    // bits: 8 pieces of 1 KB = (row of the stage's two sample blocks) x (128 variants of the block), 2 words per lane
+#pragma unroll
+    for (int j = 0; j < 8 / QF_WAVES; ++j) {
+        const int pb = wave * (8 / QF_WAVES) + j;
+        const uint64_t *src = tsrc + (int64_t)(pb >> 2) * Vpad + (pb & 3) * 128 + lane * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(slot + 2 * QF_TILE_BYTES + pb * 1024), 16, 0, 0);
+    }
 }
 
 template <int N> __device__ __forceinline__ void qf_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ABL: timing ablations (results meaningless): 1 = no DMA, 2 = no LDS fragment reads, 4 = no bit expansion
 template <int ABL>
-__global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
+__global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
                                                             int64_t Vpad, int NR, int L, int lsplit, double *__restrict__ qout)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // QF_NST slots x 24 KB (the ONLY LDS object)
@@ -363,10 +374,12 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
     int aoff[4][2];
 #pragma unroll
     for (int it = 0; it < 4; ++it) { aoff[it][0] = qf_off(it * 32 + l31, lh); aoff[it][1] = qf_off(it * 32 + l31, 2 + lh); }
-    const int boff = 2 * QF_TILE_BYTES + (wave * 64 + l31) * 8;        // this lane's first variant column in the bits area
+    const int boff = 2 * QF_TILE_BYTES + (wave * (32 * QF_JT) + l31) * 8;   // this lane's first variant column in the bits area
 
-    double tot[2] = {0.0, 0.0};
-    v16i acc[4][2];
+    double tot[QF_JT];
+#pragma unroll
+    for (int jt = 0; jt < QF_JT; ++jt) tot[jt] = 0.0;
+    v16i acc[4][QF_JT];
     int pI = 0, pl = 0, pst = 0, pslot = 0;                              // DMA cursor (QF_NST-1 stages ahead)
     int cI = 0, cl = 0, cst = 0;                                        // compute cursor
     double scale0 = 1.0, step = 1.0;
@@ -395,35 +408,36 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
     auto sync_refill = [&](int s) {
         const int newer = max(0, min(total - 2 - s, QF_AHEAD - 2));   // stages allowed to be still in flight: s+2 .. s+QF_AHEAD-1
         if (!(ABL & 1)) {
-            if (newer >= 3) qf_wait_vm<9>(); else if (newer == 2) qf_wait_vm<6>(); else if (newer == 1) qf_wait_vm<3>(); else qf_wait_vm<0>();
+            if (newer >= 3) qf_wait_vm<3 * QF_DMA_PER_WAVE>(); else if (newer == 2) qf_wait_vm<2 * QF_DMA_PER_WAVE>();
+            else if (newer == 1) qf_wait_vm<QF_DMA_PER_WAVE>(); else qf_wait_vm<0>();
         }
         if (!(ABL & 16)) __builtin_amdgcn_s_barrier();            // ABL 16: timing ablation without the barrier (results garbage)
         __builtin_amdgcn_sched_barrier(0);
         if (s + QF_AHEAD < total) fetch();
     };
-    auto read_bits = [&](const char *base, uint64_t (&w)[2][2]) {
-        w[0][0] = *reinterpret_cast<const uint64_t *>(base + boff);
-        w[0][1] = *reinterpret_cast<const uint64_t *>(base + boff + 256);
-        w[1][0] = *reinterpret_cast<const uint64_t *>(base + boff + QF_BN * 8);
-        w[1][1] = *reinterpret_cast<const uint64_t *>(base + boff + QF_BN * 8 + 256);
-    };
-    auto expand = [&](const uint64_t (&w)[2][2], int sub, v4i (&b)[2]) {
-        const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
-        uint4 e0, e1;
-        if (ABL & 4) { e0 = make_uint4((uint32_t)w[tl][0], ch, 1, 0); e1 = make_uint4((uint32_t)w[tl][1], ch, 0, 1); }
-        else {
-            e0 = qf_expand16((uint32_t)(w[tl][0] >> (16 * ch)) & 0xFFFFu);
-            e1 = qf_expand16((uint32_t)(w[tl][1] >> (16 * ch)) & 0xFFFFu);
+    auto read_bits = [&](const char *base, uint64_t (&w)[2][QF_JT]) {
+#pragma unroll
+        for (int jt = 0; jt < QF_JT; ++jt) {
+            w[0][jt] = *reinterpret_cast<const uint64_t *>(base + boff + 256 * jt);
+            w[1][jt] = *reinterpret_cast<const uint64_t *>(base + boff + QF_BN * 8 + 256 * jt);
         }
-        b[0] = (v4i){(int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w};
-        b[1] = (v4i){(int)e1.x, (int)e1.y, (int)e1.z, (int)e1.w};
+    };
+    auto expand = [&](const uint64_t (&w)[2][QF_JT], int sub, v4i (&b)[QF_JT]) {
+        const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
+#pragma unroll
+        for (int jt = 0; jt < QF_JT; ++jt) {
+            uint4 e;
+            if (ABL & 4) e = make_uint4((uint32_t)w[tl][jt], ch, jt, 1);
+            else e = qf_expand16((uint32_t)(w[tl][jt] >> (16 * ch)) & 0xFFFFu);
+            b[jt] = (v4i){(int)e.x, (int)e.y, (int)e.z, (int)e.w};
+        }
     };
 
     // Software pipeline over the 32-deep sub-steps (sub = tile(0/1) * 2 + k-half(0/1)), continuous ACROSS stages: the A fragments
     // and the expanded variant fragments of the next sub-step are produced while the 8 MFMAs of the current one issue;
     // sched_barrier(0) closes each sub-step so that hipcc cannot sink the LDS reads next to their consumers.
-    uint64_t wb[2][2], wbn[2][2];
-    v4i a_cur[4], a_nxt[4], b_cur[2], b_nxt[2];
+    uint64_t wb[2][QF_JT], wbn[2][QF_JT];
+    v4i a_cur[4], a_nxt[4], b_cur[QF_JT], b_nxt[QF_JT];
     sync_refill(0);
     read_bits(smem, wb);
 #pragma unroll
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt)
+                for (int jt = 0; jt < QF_JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0;
         }
@@ -462,13 +476,14 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt)
+                for (int jt = 0; jt < QF_JT; ++jt)
                     acc[it][jt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[it], b_cur[jt], acc[it][jt], 0, 0, 0);
             if (sub < 3) expand(wb, sub + 1, b_nxt); else expand(wbn, 0, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int it = 0; it < 4; ++it) a_cur[it] = a_nxt[it];
-            b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+#pragma unroll
+            for (int jt = 0; jt < QF_JT; ++jt) b_cur[jt] = b_nxt[jt];
         }
         if (++slot == QF_NST) slot = 0;
         if (++cst == cI + 1) {
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
             // segment spans exactly the row tile's own samples, so its bit words ARE the epilogue mask.  |acc| <= 127 * N < 2^23,
             // so the masked sum is a chain of 24-bit multiply-adds by the 0/1 bit (v_bfe_u32 + v_mad_i32_i24 per register).
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
+            for (int jt = 0; jt < QF_JT; ++jt) {
                 int part[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -494,12 +509,17 @@ __global__ __launch_bounds__(512, 2) void k_lmm_quadform_i8(const int8_t *__rest
             cst = 0; scale_l *= step;
             if (++cl == nl) { cl = 0; scale_l = scale0; ++cI; }
         }
-        wb[0][0] = wbn[0][0]; wb[0][1] = wbn[0][1]; wb[1][0] = wbn[1][0]; wb[1][1] = wbn[1][1];
+#pragma unroll
+        for (int jt = 0; jt < QF_JT; ++jt) { wb[0][jt] = wbn[0][jt]; wb[1][jt] = wbn[1][jt]; }
     }
     // lanes l and l^32 hold different rows of the same variant
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) tot[jt] += __shfl_xor(tot[jt], 32, 64);
-    if (lh == 0) { double *qo = qout + (int64_t)lgrp * Vpad; qo[v0 + wave * 64 + l31] = tot[0]; qo[v0 + wave * 64 + 32 + l31] = tot[1]; }
+    for (int jt = 0; jt < QF_JT; ++jt) tot[jt] += __shfl_xor(tot[jt], 32, 64);
+    if (lh == 0) {
+        double *qo = qout + (int64_t)lgrp * Vpad + v0 + wave * (32 * QF_JT) + l31;
+#pragma unroll
+        for (int jt = 0; jt < QF_JT; ++jt) qo[32 * jt] = tot[jt];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -730,7 +750,7 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
 
 hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q)
 {
-    const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(512);
+    const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(64 * QF_WAVES);
     const size_t lds = QF_NST * QF_STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
