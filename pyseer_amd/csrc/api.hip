@@ -274,6 +274,7 @@ void sh_destroy(sh_ctx *c)
     for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     for (int b = 0; b < 2; ++b) if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]);
+    for (auto &p : c->tev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     hipFree(c->dd_h); hipFree(c->dd_keys); hipFree(c->dd_idx); hipFree(c->dd_rep); hipFree(c->dd_slot); hipFree(c->dd_n); hipFree(c->dd_bits); hipFree(c->dd_out); hipFree(c->dd_flags);
     hipFree(c->sim_K); hipFree(c->sim_S); hipFree(c->sim_keep); hipFree(c->sim_out);
     glm_free(&c->glm);
