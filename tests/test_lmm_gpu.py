@@ -361,3 +361,31 @@ def test_fit_lmm_drop_in_matches_golden_orchestration(engine_mod, path):
             assert set(n for b, n in enumerate(NOTE_ORDER) if (int(d[o + "_notes"][j]) >> b) & 1) == g.notes
             assert g.filter == bool(d[o + "_filter"][j])
         assert (mat[:, ~keep] == 0).all()
+
+
+def test_contexts_release_their_memory(engine_mod):
+    """sh_destroy gives back every allocation (workspace, staging, tables, Firth state, similarity accumulator)."""
+    import torch
+    Engine, pack = engine_mod
+    rng = np.random.default_rng(3)
+    N = 300
+    U, S, covar, y, Kv = _random_lmm(N, 2, 9, 400)
+    W = rng.standard_normal((N, 3))
+
+    def cycle():
+        e = Engine(N)
+        e.lmm_setup(U, S, y, covar, 0.3)
+        e.set_dedup(True)
+        e.lmm_batch(pack(Kv))
+        e.glm_setup(y, W, False, -150.0, -140.0, force_firth=True)
+        e.glm_batch(pack(Kv))
+        e.sim_begin(); e.sim_accumulate(pack(Kv)); e.sim_finish()
+        e.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)
