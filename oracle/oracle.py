@@ -35,6 +35,7 @@ def lib():
         L.orc_f_sf_1.restype = C.c_double; L.orc_f_sf_1.argtypes = [C.c_double, C.c_double]
         L.orc_t_sf2.restype = C.c_double; L.orc_t_sf2.argtypes = [C.c_double, C.c_double]
         L.orc_firth_likelihood.restype = C.c_double
+        L.orc_set_firth_tie.restype = None; L.orc_set_firth_tie.argtypes = [C.c_double]
         L.orc_lmm_create.restype = C.c_void_p
         L.orc_lmm_nll.restype = C.c_double
         L.orc_lmm_nll.argtypes = [C.c_void_p, C.c_double]
@@ -91,6 +92,12 @@ def logit_newton(X, y, start, check_separation=True):
 def firth_likelihood(X, y, beta):
     X = _d(X); y = _d(y); beta = _d(beta)
     return lib().orc_firth_likelihood(_p(X), _p(y), X.shape[0], X.shape[1], _p(beta))
+
+
+def set_firth_tie(tie=0.0):
+    """Test-only: bias the first step-halving comparison of each fit_firth iteration by tie*|F| (0 = the reference exactly). Used to recognise
+    halvings that the reference decides on rounding noise (case 1)."""
+    lib().orc_set_firth_tie(C.c_double(tie))
 
 
 def fit_firth(X, y, start, step_limit=1000, convergence_limit=1e-4):

@@ -392,6 +392,12 @@ ORC_API double orc_firth_likelihood(const double *X, const double *y, int n, int
     return firth_like(X, y, n, pc, beta);
 }
 
+/* Test-only knob (default 0 = the reference's comparison exactly): the step-halving test becomes
+ * F(new) > F(old) + tie*|F(old)| for the FIRST comparison of each outer iteration.  With tie = +-2e-13 the parity tests can tell a rounding-decided halving (the reference's own
+ * result is then a coin flip, DESIGN.md section 6 case 1) from a real disagreement. */
+static double g_firth_tie = 0.0;
+ORC_API void orc_set_firth_tie(double tie) { g_firth_tie = tie; }
+
 ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const double *start,
                           int step_limit, double convergence_limit,
                           double *beta_out, double *bse1, double *fitll)
@@ -420,7 +426,7 @@ ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const
         /* step halving, model.py:465-474 (NaN comparison is False -> accept) */
         int j = 0;
         double fcur = firth_like(X, y, n, pc, cur);
-        while (firth_like(X, y, n, pc, nb) > fcur) {
+        while (firth_like(X, y, n, pc, nb) > fcur + (j == 0 ? g_firth_tie * fabs(fcur) : 0.0)) {
             for (int a = 0; a < pc; a++) nb[a] = cur[a] + 0.5 * (nb[a] - cur[a]);
             j++;
             if (j > step_limit) { free(cur); free(prev); free(nb); free(pi); return 1; }
