@@ -23,6 +23,40 @@ def _variants(rng, N, V):
     return K
 
 
+def _fixed_case(seed):
+    rng = np.random.default_rng(2000 + seed)
+    N = int(rng.choice([40, 63, 64, 65, 100, 128, 129, 250, 300]))
+    q = int(rng.choice([0, 1, 2, 3, 5, 8, 11, 14, 16]))
+    cont = bool(rng.integers(0, 2))
+    V = 72
+    W = rng.standard_normal((N, q))
+    if q:
+        W /= np.abs(W).max(axis=0)
+    eta = -0.2 + (1.0 * W[:, 0] if q else 0.0)
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    pret, lrtt = (1.0, 1.0) if seed % 3 == 0 else (float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9)))
+    K = _variants(rng, N, V)
+    af = K.mean(axis=1)
+    K = K[(af >= 0.01) & (af <= 0.99)]
+    return N, q, cont, W, y, pret, lrtt, K
+
+
+def _firth_case(seed):
+    rng = np.random.default_rng(3000 + seed)
+    N = int(rng.choice([60, 64, 100, 129, 200, 320]))
+    q = int(rng.choice([0, 1, 3, 6, 10, 14, 15]))
+    V = 40
+    W = rng.standard_normal((N, q))
+    if q:
+        W /= np.abs(W).max(axis=0)
+    eta = -0.2 + (1.0 * W[:, 0] if q else 0.0)
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    K = _variants(rng, N, V)
+    af = K.mean(axis=1)
+    K = K[(af >= 0.01) & (af <= 0.99)]
+    return N, q, W, y, K
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
 def test_lmm_random_configurations(seed):
     from oracle import oracle as orc
@@ -63,20 +97,7 @@ def test_fixed_effects_random_configurations(seed):
     from oracle import oracle as orc
     from pyseer_amd.engine import Engine, pack_variants
     from pyseer_amd.model import fit_null
-    rng = np.random.default_rng(2000 + seed)
-    N = int(rng.choice([40, 63, 64, 65, 100, 128, 129, 250, 300]))
-    q = int(rng.choice([0, 1, 2, 3, 5, 8, 11, 14, 16]))
-    cont = bool(rng.integers(0, 2))
-    V = 72
-    W = rng.standard_normal((N, q))
-    if q:
-        W /= np.abs(W).max(axis=0)
-    eta = -0.2 + (1.0 * W[:, 0] if q else 0.0)
-    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
-    pret, lrtt = (1.0, 1.0) if seed % 3 == 0 else (float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9)))
-    K = _variants(rng, N, V)
-    af = K.mean(axis=1)
-    K = K[(af >= 0.01) & (af <= 0.99)]
+    N, q, cont, W, y, pret, lrtt, K = _fixed_case(seed)
     e0 = np.zeros((0, 0))
     null = fit_null(y, W, e0, cont)
     if null is None:
@@ -124,18 +145,7 @@ def test_forced_firth_random_configurations(seed):
     from oracle import oracle as orc
     from pyseer_amd.engine import Engine, pack_variants
     from pyseer_amd.model import fit_null
-    rng = np.random.default_rng(3000 + seed)
-    N = int(rng.choice([60, 64, 100, 129, 200, 320]))
-    q = int(rng.choice([0, 1, 3, 6, 10, 14, 15]))
-    V = 40
-    W = rng.standard_normal((N, q))
-    if q:
-        W /= np.abs(W).max(axis=0)
-    eta = -0.2 + (1.0 * W[:, 0] if q else 0.0)
-    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
-    K = _variants(rng, N, V)
-    af = K.mean(axis=1)
-    K = K[(af >= 0.01) & (af <= 0.99)]
+    N, q, W, y, K = _firth_case(seed)
     e0 = np.zeros((0, 0))
     null = fit_null(y, W, e0, False)
     nf = fit_null(y, W, e0, False, firth=True)
