@@ -36,6 +36,7 @@ def lib():
         L.orc_t_sf2.restype = C.c_double; L.orc_t_sf2.argtypes = [C.c_double, C.c_double]
         L.orc_firth_likelihood.restype = C.c_double
         L.orc_set_firth_tie.restype = None; L.orc_set_firth_tie.argtypes = [C.c_double]
+        L.orc_set_firth_accept_below.restype = None; L.orc_set_firth_accept_below.argtypes = [C.c_double]
         L.orc_lmm_create.restype = C.c_void_p
         L.orc_lmm_nll.restype = C.c_double
         L.orc_lmm_nll.argtypes = [C.c_void_p, C.c_double]
@@ -98,6 +99,28 @@ def set_firth_tie(tie=0.0):
     """Test-only: bias the first step-halving comparison of each fit_firth iteration by tie*|F| (0 = the reference exactly). Used to recognise
     halvings that the reference decides on rounding noise (case 1)."""
     lib().orc_set_firth_tie(C.c_double(tie))
+
+
+def set_firth_accept_below(eps=0.0):
+    """Test-only: accept a Firth candidate outright when no coordinate moves by eps or more (0 = off = the reference). The HIP
+    kernels use 1e-10; the reference either lands on the same beta to 1e-10 or reports a spurious firth-fail."""
+    lib().orc_set_firth_accept_below(C.c_double(eps))
+
+
+FIRTH_NOISE_VARIANTS = [(0.0, 0.0), (2e-13, 0.0), (-2e-13, 0.0), (0.0, 1e-10), (2e-13, 1e-10), (-2e-13, 1e-10)]
+
+
+def firth_noise_variants(fn):
+    """[fn() under each (tie, accept_below) setting]: the answers the reference can legitimately give for a Firth fit whose
+    step-halving comparisons sit on last-bit ties. The first entry is the reference's behaviour exactly."""
+    out = []
+    for tie, eps in FIRTH_NOISE_VARIANTS:
+        set_firth_tie(tie); set_firth_accept_below(eps)
+        try:
+            out.append(fn())
+        finally:
+            set_firth_tie(0.0); set_firth_accept_below(0.0)
+    return out
 
 
 def fit_firth(X, y, start, step_limit=1000, convergence_limit=1e-4):

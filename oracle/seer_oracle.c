@@ -395,8 +395,18 @@ ORC_API double orc_firth_likelihood(const double *X, const double *y, int n, int
 /* Test-only knob (default 0 = the reference's comparison exactly): the step-halving test becomes
  * F(new) > F(old) + tie*|F(old)| for the FIRST comparison of each outer iteration.  With tie = +-2e-13 the parity tests can tell a rounding-decided halving (the reference's own
  * result is then a coin flip, DESIGN.md section 6 case 1) from a real disagreement. */
-static double g_firth_tie = 0.0;
+static double g_firth_tie = 0.0, g_firth_accept = 0.0;
 ORC_API void orc_set_firth_tie(double tie) { g_firth_tie = tie; }
+/* Second test-only knob (default 0 = off): a candidate whose largest coordinate change is below `eps` is accepted without the
+ * F comparison.  The HIP kernels use eps = 1e-10 (DESIGN.md section 6 case 1): the reference halves such a step until the
+ * comparison lands by rounding, or gets stuck one ulp away from beta (cur + 0.5 ulp rounds back up) and reports a spurious
+ * firth-fail after step_limit halvings. */
+ORC_API void orc_set_firth_accept_below(double eps) { g_firth_accept = eps; }
+static int firth_tiny_step(const double *nb, const double *cur, int pc)
+{
+    double m = 0; for (int a = 0; a < pc; a++) { double d = fabs(nb[a] - cur[a]); if (d > m) m = d; }
+    return m < g_firth_accept;
+}
 
 ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const double *start,
                           int step_limit, double convergence_limit,
@@ -426,7 +436,7 @@ ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const
         /* step halving, model.py:465-474 (NaN comparison is False -> accept) */
         int j = 0;
         double fcur = firth_like(X, y, n, pc, cur);
-        while (firth_like(X, y, n, pc, nb) > fcur + (j == 0 ? g_firth_tie * fabs(fcur) : 0.0)) {
+        while (!firth_tiny_step(nb, cur, pc) && firth_like(X, y, n, pc, nb) > fcur + (j == 0 ? g_firth_tie * fabs(fcur) : 0.0)) {
             for (int a = 0; a < pc; a++) nb[a] = cur[a] + 0.5 * (nb[a] - cur[a]);
             j++;
             if (j > step_limit) { free(cur); free(prev); free(nb); free(pi); return 1; }

@@ -43,10 +43,14 @@ __device__ __noinline__ double w_lu(double *A, int *piv, int pc)
 
 __device__ __noinline__ void w_lu_solve(const double *LU, const int *piv, int pc, double *b)
 {
+    // w_lu swaps whole rows (multipliers of earlier columns included), so the row interchanges are applied to b first
 #pragma unroll 1
-    for (int c = 0; c < pc; ++c) { const int p = piv[c]; if (p != c) { const double t = b[c]; b[c] = b[p]; b[p] = t; }
+    for (int c = 0; c < pc; ++c) { const int p = piv[c]; if (p != c) { const double t = b[c]; b[c] = b[p]; b[p] = t; } }
 #pragma unroll 1
-        for (int r = c + 1; r < pc; ++r) b[r] = fma(-LU[r * pc + c], b[c], b[r]); }
+    for (int c = 0; c < pc; ++c) {
+#pragma unroll 1
+        for (int r = c + 1; r < pc; ++r) b[r] = fma(-LU[r * pc + c], b[c], b[r]);
+    }
 #pragma unroll 1
     for (int c = pc - 1; c >= 0; --c) {
 #pragma unroll 1

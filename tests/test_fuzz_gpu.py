@@ -111,31 +111,25 @@ def test_fixed_effects_random_configurations(seed):
     r = e.glm_batch(pack_variants(K))
     e.close()
     firth = (want["notes"] & 0x7C) != 0
-    # A Firth fit whose step halving the reference decides on a last-bit tie of F (case 1) has two
-    # legitimate answers; the oracle is re-run with the comparison biased by +-2e-13*|F| and either answer is accepted.
-    alts = [want]
-    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
-        def close_to(w):
-            return _close(r[f], w[f], rtol=np.where(firth, 2e-6, 1e-6), atol=np.where(firth, 1e-6 if f != "pvalue" else 1e-300, 1e-12))
-        ok = close_to(want)
-        if not ok.all() and firth[~ok].all():
-            if len(alts) == 1:
-                for tie in (2e-13, -2e-13):
-                    orc.set_firth_tie(tie)
-                    try:
-                        alts.append(orc.fixed_effects_batch(y, K.astype(float), W if q else None, cont, pret, lrtt, null.llf, nf))
-                    finally:
-                        orc.set_firth_tie(0.0)
-            ok = ok | close_to(alts[1]) | close_to(alts[2])
-        assert ok.all(), (f, N, q, cont, np.argwhere(~ok)[:4].tolist(), r[f][~ok][:4], want[f][~ok][:4])
-    tested = np.isfinite(want["kbeta"])
-    if q:
-        okb = np.zeros(r["betas"][tested].shape, bool)
-        for w in alts:
-            okb |= _close(r["betas"][tested], w["betas"][tested], rtol=2e-6, atol=1e-6)
-        assert okb.all()
-    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
-    assert (((r["flags"] >> 16) & 1) == want["prefilter"]).all() and (((r["flags"] >> 17) & 1) == want["filter"]).all()
+
+    def rows_matching(w):
+        m = ((r["flags"] & 0x1FF) == w["notes"]) & (((r["flags"] >> 16) & 1) == w["prefilter"]) & (((r["flags"] >> 17) & 1) == w["filter"])
+        for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+            m &= _close(r[f], w[f], rtol=np.where(firth, 2e-6, 1e-6), atol=np.where(firth, 1e-6 if f != "pvalue" else 1e-300, 1e-12))
+        if q:
+            both_nan = ~np.isfinite(w["kbeta"])
+            m &= both_nan | _close(r["betas"], w["betas"], rtol=2e-6, atol=1e-6).all(axis=1)
+        return m
+    good = rows_matching(want)
+    if not good.all() and firth[~good].all():
+        # Firth fits whose step-halving comparisons the reference decides on last-bit ties of F have more than one legitimate
+        # answer (case 1): such a row must equal the oracle under one of its documented tie settings.
+        for w in orc.firth_noise_variants(lambda: orc.fixed_effects_batch(y, K.astype(float), W if q else None, cont, pret, lrtt,
+                                                                          null.llf, nf))[1:]:
+            good |= rows_matching(w) & firth
+    bad = np.flatnonzero(~good)
+    assert bad.size == 0, (N, q, cont, bad[:4].tolist(), [(f, r[f][bad[:4]], want[f][bad[:4]]) for f in ("pvalue", "kbeta", "bse")],
+                           r["flags"][bad[:4]], want["notes"][bad[:4]])
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
@@ -156,23 +150,19 @@ def test_forced_firth_random_configurations(seed):
     e.glm_setup(y, W, False, null.llf, nf, force_firth=True)
     r = e.glm_batch(pack_variants(K))
     e.close()
-    ok = (want["status"] == 0) & np.isfinite(want["fitll"])
     failed = ((r["flags"] >> 6) & 1) == 1
-    assert (failed[want["status"] != 0]).all() and not failed[ok].any()
-    def pvals(w):
-        return np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in -2 * (nf - w["fitll"][ok])])
 
-    def matches(w):
-        m = np.ones(int(ok.sum()), bool)
+    def rows_matching(w):
+        ok = (w["status"] == 0) & np.isfinite(w["fitll"])
+        m = failed == (w["status"] != 0)
         for f in ("intercept", "kbeta", "bse"):
-            m &= _close(r[f][ok], w[f][ok], rtol=2e-6, atol=1e-6)
-        return m & _close(r["pvalue"][ok], pvals(w), rtol=5e-6, atol=1e-300)
-    good = matches(want)
+            m &= ~ok | _close(r[f], w[f], rtol=2e-6, atol=1e-6)
+        with np.errstate(invalid="ignore"):
+            lr = -2 * (nf - w["fitll"])
+        want_p = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
+        return m & (~ok | _close(r["pvalue"], want_p, rtol=5e-6, atol=1e-300))
+    good = rows_matching(want)
     if not good.all():                                            # last-bit ties of the halving test: see the test above
-        for tie in (2e-13, -2e-13):
-            orc.set_firth_tie(tie)
-            try:
-                good |= matches(orc.firth_batch(y, K.astype(float), W if q else None))
-            finally:
-                orc.set_firth_tie(0.0)
+        for w in orc.firth_noise_variants(lambda: orc.firth_batch(y, K.astype(float), W if q else None))[1:]:
+            good |= rows_matching(w)
     assert good.all(), (N, q, np.argwhere(~good)[:4].tolist())

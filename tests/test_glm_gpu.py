@@ -297,6 +297,41 @@ def test_wide_designs_vs_oracle(N, q, cont):
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
 
 
+@pytest.mark.parametrize("N,q,cont", [(400, 17, False), (400, 17, True), (300, 6, False), (600, 24, False)])
+def test_unscaled_covariates_vs_oracle(N, q, cont):
+    """Covariates on very different scales and far from zero mean (age in years next to a 0/1 flag next to a 1e-2-sized principal
+    component): the information matrix is badly scaled, so the pivoted LU of the run-time-width kernels really interchanges rows
+    (a solve that applied the interchanges in the wrong order passed every test with unit-scale columns)."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(977 + N + q + cont)
+    Z = rng.standard_normal((N, q))
+    scale = 10.0 ** rng.uniform(-2.0, 1.7, q); shift = rng.uniform(-2, 2, q) * scale
+    W = Z * scale + shift
+    W[:, q - 1] = (rng.random(N) < 0.3).astype(float)                                  # a 0/1 covariate
+    eta = -0.3 + 1.0 * Z[:, 0] - 0.7 * Z[:, 1]
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    V = 80
+    af = np.concatenate([rng.uniform(0.05, 0.95, V - 8), rng.uniform(0.006, 0.02, 8)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K = K[(K.mean(axis=1) >= 0.01) & (K.mean(axis=1) <= 0.99)]
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, cont).llf
+    nf = np.nan if cont else fit_null(y, W, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W, cont, 1.0, 1.0, nl, nf)
+    e = Engine(N)
+    e.glm_setup(y, W, cont, nl, nf)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    firth = (want["notes"] & 0x7C) != 0
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(r[f][~firth], want[f][~firth], rtol=1e-6, atol=1e-12, what=f)
+        close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
+    close(r["betas"][~firth], want["betas"][~firth], rtol=1e-6, atol=1e-12, what="betas")
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+
+
 @pytest.mark.parametrize("nl,j", [(20, 0), (30, 3), (16, 0)])
 def test_wide_lineage_vs_oracle(nl, j):
     """fit_lineage_effect with more than 15 lineage/covariate columns (e.g. --lineage-clusters with many clusters)."""

@@ -24,9 +24,7 @@ else:
     e = Engine(N); e.glm_setup(y, W, False, null.llf, nf, force_firth=True)
     fields = ("kbeta", "bse", "intercept")
 r = e.glm_batch(pack_variants(K)); e.close()
-alts = []
-for tie in (0.0, 2e-13, -2e-13):
-    orc.set_firth_tie(tie); alts.append(run()); orc.set_firth_tie(0.0)
+alts = orc.firth_noise_variants(run)          # [reference, tie+, tie-, accept<1e-10, tie+ & accept, tie- & accept]
 want = alts[0]
 print("N", N, "q", q, "cont", cont, "V", len(K))
 bad = np.zeros(len(K), bool)
@@ -40,7 +38,7 @@ else:
 for i in np.flatnonzero(bad):
     print("row", i, "carriers", int(K[i].sum()), "carriers with y=1" if not cont else "", int((K[i] * (y > 0)).sum()), "gpu flags", hex(int(r["flags"][i])))
     for f in fields:
-        print("   %-9s gpu %.12g | oracle %.12g | tie+ %.12g | tie- %.12g" % (f, r[f][i], *[a[f][i] for a in alts]))
+        print("   %-9s gpu %.12g | oracle variants " % (f, r[f][i]) + " ".join("%.12g" % a[f][i] for a in alts))
     if kind == "fixed":
         print("   notes oracle", [hex(int(a["notes"][i])) for a in alts])
     else:
