@@ -16,6 +16,10 @@ def _close(a, b, rtol=1e-6, atol=0.0):
         (np.abs(a - b) <= atol + rtol * np.abs(b))
 
 
+# FUZZ_SEEDS=n widens the sweep, FUZZ_OFFSET=k starts it at seed k (defaults: 12 seeds from 0)
+_SEEDS = range(int(os.environ.get("FUZZ_OFFSET", 0)), int(os.environ.get("FUZZ_OFFSET", 0)) + int(os.environ.get("FUZZ_SEEDS", 12)))
+
+
 def _variants(rng, N, V):
     af = np.concatenate([rng.uniform(0.03, 0.97, V - 8), [1.5 / N, 2.5 / N, 1 - 1.5 / N, 0.5, 0.5, 0.02, 0.98, 0.5]])
     K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
@@ -57,7 +61,7 @@ def _firth_case(seed):
     return N, q, W, y, K
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_lmm_random_configurations(seed):
     from oracle import oracle as orc
     from pyseer_amd.engine import Engine, pack_variants
@@ -92,7 +96,7 @@ def test_lmm_random_configurations(seed):
     assert (((((r["flags"] >> 17) & 1) == want["filter"])) | noise).all()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_fixed_effects_random_configurations(seed):
     from oracle import oracle as orc
     from pyseer_amd.engine import Engine, pack_variants
@@ -132,7 +136,7 @@ def test_fixed_effects_random_configurations(seed):
                            r["flags"][bad[:4]], want["notes"][bad[:4]])
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", 12))))
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_forced_firth_random_configurations(seed):
     """Every variant through fit_firth (BASELINE config C4 shape, small): state-machine kernels, and the run-time-width kernel for
     q > 14, against the oracle's fit_firth."""
