@@ -27,6 +27,15 @@ def _variants(rng, N, V):
     return K
 
 
+def _rescale(W, seed):
+    """One seed in three: covariates on their natural, badly matched scales (shifted, 1e-2 .. 30x), as users supply them."""
+    if W.shape[1] == 0 or seed % 3 != 1:
+        return W
+    rng = np.random.default_rng(5000 + seed)
+    scale = 10.0 ** rng.uniform(-2.0, 1.5, W.shape[1])
+    return W * scale + rng.uniform(-2, 2, W.shape[1]) * scale
+
+
 def _fixed_case(seed):
     rng = np.random.default_rng(2000 + seed)
     N = int(rng.choice([40, 63, 64, 65, 100, 128, 129, 250, 300]))
@@ -42,7 +51,7 @@ def _fixed_case(seed):
     K = _variants(rng, N, V)
     af = K.mean(axis=1)
     K = K[(af >= 0.01) & (af <= 0.99)]
-    return N, q, cont, W, y, pret, lrtt, K
+    return N, q, cont, _rescale(W, seed), y, pret, lrtt, K
 
 
 def _firth_case(seed):
@@ -58,7 +67,7 @@ def _firth_case(seed):
     K = _variants(rng, N, V)
     af = K.mean(axis=1)
     K = K[(af >= 0.01) & (af <= 0.99)]
-    return N, q, W, y, K
+    return N, q, _rescale(W, seed), y, K
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
@@ -74,7 +83,7 @@ def test_lmm_random_configurations(seed):
     k = N - D
     U = rng.standard_normal((N, k)) / np.sqrt(N)
     S = np.sort(rng.gamma(0.5, 2.0, k))[::-1].copy()
-    covar = np.ones((N, 1)) if D == 1 else np.c_[rng.standard_normal((N, D - 1)), np.ones((N, 1))]
+    covar = np.ones((N, 1)) if D == 1 else np.c_[_rescale(rng.standard_normal((N, D - 1)), seed), np.ones((N, 1))]
     y = rng.standard_normal(N) if cont else (rng.random(N) < 0.4).astype(float)
     h2 = float(rng.uniform(0.0, 0.95))
     fp, lp = (1.0, 1.0) if seed % 3 == 0 else (float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.2, 0.9)))
