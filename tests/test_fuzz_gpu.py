@@ -179,3 +179,40 @@ def test_forced_firth_random_configurations(seed):
         for w in orc.firth_noise_variants(lambda: orc.firth_batch(y, K.astype(float), W if q else None))[1:]:
             good |= rows_matching(w)
     assert good.all(), (N, q, np.argwhere(~good)[:4].tolist())
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_lineage_random_configurations(seed):
+    """fit_lineage_effect (pyseer/model.py:151-199) for random sample counts, lineage widths on both sides of the fixed-width /
+    run-time-width kernel split, MDS-like or cluster-indicator lineage columns, and covariates on unmatched scales."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from test_oracle_golden import _same_or_tied
+    rng = np.random.default_rng(4000 + seed)
+    N = int(rng.choice([90, 128, 200, 333, 600]))
+    nl = int(rng.choice([1, 2, 3, 5, 9, 13, 14, 15, 18, 25]))
+    j = int(rng.choice([0, 0, 1, 3]))
+    V = 48
+    clusters = bool(rng.integers(0, 2)) and nl >= 2
+    if clusters:
+        cl = rng.integers(0, nl + 1, N)
+        lin = np.zeros((N, nl)); lin[np.arange(N)[cl > 0], cl[cl > 0] - 1] = 1.0
+        base = rng.uniform(0.25, 0.75, (V, nl + 1))
+        K = (rng.random((V, N)) < base[:, cl]).astype(np.uint8)
+    else:
+        lin = rng.standard_normal((N, nl)); lin /= np.abs(lin).max(axis=0)           # scale_fix=False MDS columns, input.py:135
+        w = rng.standard_normal((V, nl)) * rng.uniform(0, 2, (V, 1))
+        K = (rng.random((V, N)) < 1 / (1 + np.exp(-(lin @ w.T).T - rng.uniform(-1, 1, (V, 1))))).astype(np.uint8)
+    cov = _rescale(rng.standard_normal((N, j)), seed) if j else None
+    e = Engine(N)
+    e.lineage_setup(lin, cov)
+    got = e.lineage_batch(pack_variants(K))
+    e.close()
+    want = [orc.lineage_effect(lin, cov, K[v].astype(float)) for v in range(V)]
+    # quasi-separated clusters (every member, or none, carries the k-mer) are not a parity target: DESIGN.md section 6, case 5
+    sep = np.zeros(V, bool)
+    if clusters:
+        sep = np.array([any(K[v][cl == c].sum() in (0, (cl == c).sum()) for c in range(nl + 1) if (cl == c).any()) for v in range(V)])
+    g = [None if x < 0 else int(x) for x in got]
+    keep = np.flatnonzero(~sep)
+    _same_or_tied([g[v] for v in keep], [want[v] for v in keep], lin, cov, K[keep])
