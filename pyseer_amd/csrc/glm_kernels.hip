@@ -12,6 +12,7 @@
 // information matrix are per-lane registers.  No cross-lane reduction, no LDS, no atomics on the hot path; the p x p
 // solves (LDL^T) run per lane, fully unrolled in registers.  Variants that need Firth (bad-chisq, high-bse, separation,
 // singular) are appended to a list and handled by the Firth kernel with the same mapping.
+#include <algorithm>
 #include "common.h"
 
 #define GLM_MAXQ 14
@@ -69,13 +70,84 @@ __device__ __forceinline__ void ldl_solve(const double (&A)[P * (P + 1) / 2], do
 }
 
 
+// ---- sample-split blocks: S wavefronts share the same 64 variants (lane = variant) and each walks every S-th 64-sample word --------
+// The list-driven kernels (Firth rounds, the fp64 restart of the Newton iteration) see anything from one to 10^5 variants per
+// launch; with one wavefront per 64 variants a short list is bound by the latency of one lane walking all N samples (3 ms per
+// pass at N = 5000, however few variants there are).  S depends only on N (glm_split_waves), never on the length of a list, so a
+// variant's partial sums are combined in the same order whatever else is in its batch: results do not depend on batch composition.
+// Partial sums go through LDS in chunks of XW_CH accumulators: wave 0 adds waves 1..S-1 in that order.
+#define XW_CH 16
+extern __shared__ double xw_lds[];
+struct XWave { int w, lane, S; };
+// readfirstlane: the wavefront index is uniform within a wavefront, but the compiler cannot know it; without this every address
+// derived from it (the sample index, hence the covariate rows) is treated as divergent and loaded per lane instead of through SGPRs
+__device__ __forceinline__ XWave xwave()
+{
+    return XWave{__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (int)(blockDim.x >> 6)};
+}
+
+template <int NA>
+__device__ __forceinline__ void xw_sum(const XWave &x, double (&a)[NA])            // block-uniform call; total valid in wave 0
+{
+    if (x.S == 1) return;
+#pragma unroll
+    for (int c0 = 0; c0 < NA; c0 += XW_CH) {
+        if (x.w > 0) {
+#pragma unroll
+            for (int k = 0; k < XW_CH; ++k) if (c0 + k < NA) xw_lds[((x.w - 1) * XW_CH + k) * 64 + x.lane] = a[c0 + k];
+        }
+        __syncthreads();
+        if (x.w == 0) {
+            for (int ww = 1; ww < x.S; ++ww) {
+#pragma unroll
+                for (int k = 0; k < XW_CH; ++k) if (c0 + k < NA) a[c0 + k] += xw_lds[((ww - 1) * XW_CH + k) * 64 + x.lane];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void xw_sum_max(const XWave &x, double &sum, double &mx)  // sum and max of two scalars, as xw_sum
+{
+    if (x.S == 1) return;
+    if (x.w > 0) { xw_lds[((x.w - 1) * XW_CH + 0) * 64 + x.lane] = sum; xw_lds[((x.w - 1) * XW_CH + 1) * 64 + x.lane] = mx; }
+    __syncthreads();
+    if (x.w == 0) {
+        for (int ww = 1; ww < x.S; ++ww) {
+            sum += xw_lds[((ww - 1) * XW_CH + 0) * 64 + x.lane];
+            mx = fmax(mx, xw_lds[((ww - 1) * XW_CH + 1) * 64 + x.lane]);
+        }
+    }
+    __syncthreads();
+}
+
+template <int NA>
+__device__ __forceinline__ void xw_bcast(const XWave &x, double (&a)[NA], bool &flag)   // wave 0 -> every wave (NA <= XW_CH)
+{
+    static_assert(NA <= XW_CH, "broadcast area is one chunk plus the flag row");
+    if (x.S == 1) return;
+    if (x.w == 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) xw_lds[k * 64 + x.lane] = a[k];
+        xw_lds[NA * 64 + x.lane] = flag ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (x.w > 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) a[k] = xw_lds[k * 64 + x.lane];
+        flag = xw_lds[NA * 64 + x.lane] != 0.0;
+    }
+    __syncthreads();
+}
+
 // ---- one pass over the samples at beta: X^T W X (packed), optional score, log-likelihood, max |mu - y| --------------
 // column order of the design: 0 = intercept, 1 = variant, 2.. = W columns (model.py:286-297)
 template <int Q, bool SCORE, bool LOGLIK>
 __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
                                           const double *__restrict__ y, const double *__restrict__ W,
                                           const double (&beta)[Q + 2], double (&H)[(Q + 2) * (Q + 3) / 2],
-                                          double (&g)[Q + 2], double &ll, double &maxdev, bool want_ll = true)
+                                          double (&g)[Q + 2], double &ll, double &maxdev, bool want_ll = true,
+                                          int sb0 = 0, int sbs = 1)
 {
     constexpr int P = Q + 2;
 #pragma unroll
@@ -85,7 +157,7 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
         for (int a = 0; a < P; ++a) g[a] = 0.0;
     }
     ll = 0.0; maxdev = 0.0;
-    for (int sb = 0; sb < NB64; ++sb) {
+    for (int sb = sb0; sb < NB64; sb += sbs) {                                 // (sb0, sbs) = (wave, waves) of a sample-split block
         const uint64_t w64 = T[(int64_t)sb * Vpad + v];
         const int nb = min(64, N - sb * 64);
         for (int b = 0; b < nb; ++b) {
@@ -391,7 +463,7 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
 
 // ---- kernel 2: phase B, the reference's all-fp64 iteration restarted for the listed variants -------------------------------
 template <int Q>
-__global__ __launch_bounds__(64) void k_glm_slow(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+__global__ __launch_bounds__(256) void k_glm_slow(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                  const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                  GlmWork wk, uint32_t *__restrict__ flags,
                                                  int *__restrict__ firth_list, int *__restrict__ firth_count)
@@ -399,7 +471,8 @@ __global__ __launch_bounds__(64) void k_glm_slow(const uint64_t *__restrict__ T,
     constexpr int PC = Q + 2;
     const int cnt = *wk.slow_count;
     if ((int64_t)blockIdx.x * 64 >= cnt) return;
-    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const XWave xw = xwave();                                        // blockDim.x = 64 * glm_split_waves(N)
+    const int slot = blockIdx.x * 64 + xw.lane;
     const bool live = slot < cnt;
     const int64_t v = wk.slow_list[live ? slot : 0];
     const int N = P.N, NB64 = P.NB64;
@@ -409,11 +482,12 @@ __global__ __launch_bounds__(64) void k_glm_slow(const uint64_t *__restrict__ T,
     for (int a = 0; a < PC; ++a) beta[a] = 0.0;
     beta[0] = P.ymean_logit;
     int it = 0, status = 0;
-    bool active = live;
+    bool active = live;                                              // kept identical in all the waves of the block
     while (__any(active)) {
-        if (active) {
-            double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
-            info_pass<Q, true, false>(T, Vpad, v, N, NB64, y, W, beta, H, g, ll, maxdev, false);
+        double H[PC * (PC + 1) / 2], g[PC], ll = 0.0, maxdev = 0.0;
+        if (active) info_pass<Q, true, false>(T, Vpad, v, N, NB64, y, W, beta, H, g, ll, maxdev, false, xw.w, xw.S);
+        xw_sum(xw, H); xw_sum(xw, g); xw_sum_max(xw, ll, maxdev);
+        if (active && xw.w == 0) {
             if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }                      // _check_perfect_pred
             else {
                 // newparams = oldparams - inv(H/n + 1e-10 I) . score/n   with H = -X^T W X   (optimizer.py:415-423)
@@ -433,8 +507,9 @@ __global__ __launch_bounds__(64) void k_glm_slow(const uint64_t *__restrict__ T,
                 }
             }
         }
+        xw_bcast(xw, beta, active);
     }
-    if (!live) return;
+    if (!live || xw.w != 0) return;
     if (status == 0) {
         wk.state[v] = 1;
 #pragma unroll
@@ -678,7 +753,7 @@ __global__ __launch_bounds__(64) void k_firth_init(const int *__restrict__ firth
 
 // penalised likelihood at cand; accept / halve / converge / fail (the state == 1 arm of k_glm_firth)
 template <int Q>
-__global__ __launch_bounds__(64, 2) void k_firth_eval(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+__global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                       const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                       FirthWork fw, const int *__restrict__ eval_list, const int *__restrict__ eval_count,
                                                       int *__restrict__ next_eval, int *__restrict__ next_eval_count,
@@ -690,7 +765,8 @@ __global__ __launch_bounds__(64, 2) void k_firth_eval(const uint64_t *__restrict
     const double SING_TOL = 1e-12;
     const int cnt = *eval_count;
     if ((int64_t)blockIdx.x * 64 >= cnt) return;
-    const int li = blockIdx.x * 64 + threadIdx.x;
+    const XWave xw = xwave();
+    const int li = blockIdx.x * 64 + xw.lane;
     const bool live = li < cnt;
     const int s = eval_list[live ? li : 0];
     const int64_t v = fw.var[s];
@@ -699,8 +775,9 @@ __global__ __launch_bounds__(64, 2) void k_firth_eval(const uint64_t *__restrict
 #pragma unroll
     for (int a = 0; a < PC; ++a) cand[a] = fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s];
     double ll, maxdev, det;
-    info_pass<Q, false, true>(T, Vpad, v, P.N, P.NB64, y, W, cand, A, dummy, ll, maxdev);
-    if (!live) return;
+    info_pass<Q, false, true>(T, Vpad, v, P.N, P.NB64, y, W, cand, A, dummy, ll, maxdev, true, xw.w, xw.S);
+    xw_sum(xw, A); xw_sum_max(xw, ll, maxdev);
+    if (!live || xw.w != 0) return;
     const double i11c = A[sidx(1, 1)];
     const bool singular = !ldl_factor<PC>(A, SING_TOL, &det);
     if (singular) {                     // handled by k_glm_firth_pinv (numpy.linalg.pinv semantics, model.py:450)
@@ -775,7 +852,7 @@ __global__ __launch_bounds__(64, 2) void k_firth_eval(const uint64_t *__restrict
 
 // penalised score at beta through the stored factor, Newton step -> cand (the state == 0 arm of k_glm_firth)
 template <int Q>
-__global__ __launch_bounds__(64, 2) void k_firth_step(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
+__global__ __launch_bounds__(512) void k_firth_step(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
                                                       const double *__restrict__ W, GlmParams P, FirthWork fw,
                                                       const int *__restrict__ step_list, const int *__restrict__ step_count,
                                                       int *__restrict__ next_eval, int *__restrict__ next_eval_count)
@@ -783,7 +860,8 @@ __global__ __launch_bounds__(64, 2) void k_firth_step(const uint64_t *__restrict
     constexpr int PC = Q + 2;
     const int cnt = *step_count;
     if ((int64_t)blockIdx.x * 64 >= cnt) return;
-    const int li = blockIdx.x * 64 + threadIdx.x;
+    const XWave xw = xwave();
+    const int li = blockIdx.x * 64 + xw.lane;
     const bool live = li < cnt;
     const int s = step_list[live ? li : 0];
     const int64_t v = fw.var[s];
@@ -796,7 +874,7 @@ __global__ __launch_bounds__(64, 2) void k_firth_step(const uint64_t *__restrict
     for (int a = 0; a < PC * (PC + 1) / 2; ++a) A[a] = fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { U[a] = 0.0; dinv[a] = 1.0 / A[sidx(a, a)]; }
-    for (int sb = 0; sb < NB64; ++sb) {
+    for (int sb = xw.w; sb < NB64; sb += xw.S) {
         const uint64_t w64 = T[(int64_t)sb * Vpad + v];
         const int nb = min(64, N - sb * 64);
         for (int b = 0; b < nb; ++b) {
@@ -824,7 +902,8 @@ __global__ __launch_bounds__(64, 2) void k_firth_step(const uint64_t *__restrict
             for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
         }
     }
-    if (!live) return;
+    xw_sum(xw, U);
+    if (!live || xw.w != 0) return;
     ldl_solve<PC>(A, U);                                             // var_covar_mat . U, model.py:463
 #pragma unroll
     for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = beta[a] + U[a];
@@ -1425,6 +1504,16 @@ extern "C" hipError_t shk_glm_lineage(hipStream_t st, int PC, const uint64_t *T,
 // ---------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
+// wavefronts per 64 variants in the list-driven kernels: a function of the sample count only (at least eight 64-sample words per
+// wavefront), so that results do not depend on what else is in a batch.  SEERHIP_SPLIT=1|2|4|8 overrides it (A/B timing).
+static int glm_split_waves(int NB64)
+{
+    static const int forced = [] { const char *e = getenv("SEERHIP_SPLIT"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    return NB64 >= 64 ? 8 : NB64 >= 32 ? 4 : NB64 >= 16 ? 2 : 1;
+}
+static size_t glm_split_lds(int S) { return S > 1 ? (size_t)((S - 1) * XW_CH + 2) * 64 * sizeof(double) : 0; }
+
 template <int Q>
 static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
                              const double *W, const float *Wf, const uint64_t *y1, const uint64_t *y0, const double *yc, const double *ZtZ,
@@ -1433,7 +1522,10 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
 {
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
     if (which == 0) hipLaunchKernelGGL(k_glm_fast<Q>, grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
-    else if (which == 4) hipLaunchKernelGGL(k_glm_slow<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
+    else if (which == 4) {
+        const int S = std::min(4, glm_split_waves(P.NB64));      // 400+ VGPRs per lane: at most four wavefronts per block
+        hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
+    }
     else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
@@ -1466,11 +1558,12 @@ static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint6
                                int *next_eval_count, int *step_list, int *step_count, double *out, uint32_t *flags, int *plist, int *pcount)
 {
     if (n <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 63) / 64)), blk(64);
+    const int S = glm_split_waves(P.NB64);
+    const dim3 grid((unsigned)((n + 63) / 64)), blk(64), blks(64 * S);
     if (which == 0) hipLaunchKernelGGL(k_firth_init<Q>, grid, blk, 0, st, in_list, in_count, P, fw, next_eval, next_eval_count);
-    else if (which == 1) hipLaunchKernelGGL(k_firth_eval<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval, next_eval_count,
-                                            step_list, step_count, out, flags, plist, pcount);
-    else hipLaunchKernelGGL(k_firth_step<Q>, grid, blk, 0, st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    else if (which == 1) hipLaunchKernelGGL(k_firth_eval<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
+                                            next_eval_count, step_list, step_count, out, flags, plist, pcount);
+    else hipLaunchKernelGGL(k_firth_step<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
     return hipGetLastError();
 }
 

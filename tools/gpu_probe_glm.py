@@ -28,7 +28,9 @@ def run(N, q, V, force_firth, cont=False):
           % (N, q, V, force_firth, cont, dt * 1e3, ms, V / dt, 100 * np.mean((f & 0x7C) != 0), 100 * np.mean((f >> 16) & 1)))
     e.close()
 
-if os.environ.get("FIRTH_V"):
+if os.environ.get("LOGIT_V"):
+    run(int(os.environ.get("N", 5000)), 10, int(os.environ["LOGIT_V"]), False)
+elif os.environ.get("FIRTH_V"):
     run(int(os.environ.get("N", 5000)), 10, int(os.environ["FIRTH_V"]), True)
 else:
     run(1000, 10, 1 << 18, False)
