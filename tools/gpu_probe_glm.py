@@ -15,7 +15,7 @@ def run(N, q, V, force_firth, cont=False):
     e0 = np.zeros((0, 0))
     nl = fit_null(y, W, e0, cont).llf
     nf = np.nan if cont else fit_null(y, W, e0, False, firth=True)
-    e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
+    e = Engine(N); e.use_torch_stream(); e.set_af_filter(*((0.0005, 0.9995) if os.environ.get("MIXED") else (0.01, 0.99)))
     e.glm_setup(y, W, cont, nl, nf, force_firth=force_firth)
     bits = synth_bits(V, N, row_bytes_for(N), 5, torch.device("cuda"))
     out, fl = e.glm_batch_dev(bits); torch.cuda.synchronize()
