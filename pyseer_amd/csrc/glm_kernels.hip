@@ -86,6 +86,16 @@ __device__ __forceinline__ XWave xwave()
     return XWave{__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (int)(blockDim.x >> 6)};
 }
 
+// wavefronts per 64 variants in the list-driven kernels: a function of the sample count only, so that results do not depend
+// on what else is in a batch.  SEERHIP_SPLIT=1|2|4|8 overrides it (A/B timing).
+static int glm_split_waves(int NB64)
+{
+    static const int forced = [] { const char *e = getenv("SEERHIP_SPLIT"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    return NB64 >= 64 ? 8 : NB64 >= 8 ? 4 : NB64 >= 4 ? 2 : 1;      // measured at N = 500 ... 5000 (DESIGN.md section 5)
+}
+static size_t glm_split_lds(int S) { return S > 1 ? (size_t)((S - 1) * XW_CH + 2) * 64 * sizeof(double) : 0; }
+
 template <int NA>
 __device__ __forceinline__ void xw_sum(const XWave &x, double (&a)[NA])            // block-uniform call; total valid in wave 0
 {
@@ -912,42 +922,8 @@ __global__ __launch_bounds__(512) void k_firth_step(const uint64_t *__restrict__
 
 // =====================================================================================================================
 // Firth slow path: literal restatement of fit_firth with numpy.linalg.pinv semantics (model.py:450) for variants whose
-// information matrix is (near-)singular, e.g. a k-mer that duplicates a binary covariate.  Arrays live in scratch and
-// loops are not unrolled: this kernel is about semantics, not speed, and sees a handful of variants per batch.
+// information matrix is (near-)singular, e.g. a k-mer that duplicates a binary covariate.
 // =====================================================================================================================
-template <int PC>
-__device__ __noinline__ void slow_info(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
-                                       const double *__restrict__ y, const double *__restrict__ W, const double *beta,
-                                       double *I, double *ll_out)
-{
-    constexpr int Q = PC - 2;
-    for (int a = 0; a < PC * PC; ++a) I[a] = 0.0;
-    double ll = 0.0;
-    for (int sb = 0; sb < NB64; ++sb) {
-        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
-        const int nb = min(64, N - sb * 64);
-        for (int b = 0; b < nb; ++b) {
-            const int i = sb * 64 + b;
-            double x[PC];
-            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
-#pragma unroll 1
-            for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
-            double eta = 0.0;
-#pragma unroll 1
-            for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
-            const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
-            ll += log(logit_cdf((2.0 * y[i] - 1.0) * eta));
-#pragma unroll 1
-            for (int a = 0; a < PC; ++a) {
-                const double wa = wgt * x[a];
-#pragma unroll 1
-                for (int c = 0; c < PC; ++c) I[a * PC + c] = fma(wa, x[c], I[a * PC + c]);
-            }
-        }
-    }
-    *ll_out = ll;
-}
-
 // numpy.linalg.det: LU with partial pivoting on a copy
 template <int PC>
 __device__ __noinline__ double slow_det(const double *Ain)
@@ -1020,89 +996,174 @@ __device__ __noinline__ void slow_pinv(const double *Ain, double *Pm, double rco
         }
 }
 
-template <int Q>
-__global__ __launch_bounds__(64) void k_glm_firth_pinv(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
-                                                       const double *__restrict__ y, const double *__restrict__ W,
-                                                       GlmParams P, const int *__restrict__ pinv_list,
-                                                       const int *__restrict__ pinv_count,
-                                                       double *__restrict__ out, uint32_t *__restrict__ flags)
+// One workgroup of 256 threads per listed variant, thread t takes samples t, t+256, ...: the variants that come here are few
+// (a k-mer that duplicates a binary covariate), and a single lane walking all N samples through un-unrolled loops for every
+// pass of every iteration cost about a second per batch at N = 5000.  The p x p algebra (numpy's pinv and det) stays on thread
+// 0; sums are combined in a fixed order (lanes by xor-shuffle, then waves 0..3).
+template <int NA>
+__device__ __forceinline__ void blk_sum(double (&a)[NA], double *red /* [4][NA] */, int tid)
 {
-    constexpr int PC = Q + 2;
-    const int cnt = *pinv_count;
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    if (slot >= cnt) return;
-    const int64_t v = pinv_list[slot];
-    const int N = P.N, NB64 = P.NB64;
-    double beta[PC], cand[PC], I[PC * PC], Vm[PC * PC], U[PC];
-    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
-    beta[0] = P.ymean_logit;
-    double ll;
-    slow_info<PC>(T, Vpad, v, N, NB64, y, W, beta, I, &ll);
-    double Fcur = -(ll + 0.5 * log(slow_det<PC>(I)));
-    double i11 = I[PC + 1], sn_prev = INFINITY;
-    bool failed = false, conv = false;
-    for (int iter = 0; iter < 1000 && !failed && !conv; ++iter) {
-        slow_pinv<PC>(I, Vm);
-        for (int a = 0; a < PC; ++a) U[a] = 0.0;
-        for (int sb = 0; sb < NB64; ++sb) {
-            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
-            const int nb = min(64, N - sb * 64);
-            for (int b = 0; b < nb; ++b) {
-                const int i = sb * 64 + b;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        double t = a[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+        a[k] = t;
+    }
+    __syncthreads();                                              // red may still be read from the previous use
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) red[(tid >> 6) * NA + k] = a[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) a[k] = ((red[k] + red[NA + k]) + red[2 * NA + k]) + red[3 * NA + k];
+    }
+}
+
+// I(b) (full PC x PC into I_out, thread 0) and the log-likelihood at b (shared memory vector)
+template <int PC>
+__device__ __forceinline__ void blk_info(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N,
+                                         const double *__restrict__ y, const double *__restrict__ W, const double *b_sh,
+                                         double *I_out, double *ll_out, double *red, int tid)
+{
+    constexpr int Q = PC - 2, NH = PC * (PC + 1) / 2;
+    double acc[NH + 1], beta[PC];
+#pragma unroll
+    for (int a = 0; a < NH + 1; ++a) acc[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = b_sh[a];
+    for (int i = tid; i < N; i += 256) {
+        const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
+        double x[PC];
+        x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+        double eta = 0.0;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+        const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+        acc[NH] += log(logit_cdf((2.0 * y[i] - 1.0) * eta));
+#pragma unroll
+        for (int a = 0; a < PC; ++a) {
+            const double wa = wgt * x[a];
+#pragma unroll
+            for (int c = 0; c <= a; ++c) acc[sidx(a, c)] = fma(wa, x[c], acc[sidx(a, c)]);
+        }
+    }
+    blk_sum<NH + 1>(acc, red, tid);
+    if (tid == 0) {
+#pragma unroll
+        for (int a = 0; a < PC; ++a)
+#pragma unroll
+            for (int c = 0; c <= a; ++c) { I_out[a * PC + c] = acc[sidx(a, c)]; I_out[c * PC + a] = acc[sidx(a, c)]; }
+        *ll_out = acc[NH];
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void k_glm_firth_pinv(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                        const double *__restrict__ y, const double *__restrict__ W,
+                                                        GlmParams P, const int *__restrict__ pinv_list,
+                                                        const int *__restrict__ pinv_count,
+                                                        double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    __shared__ double s_beta[PC], s_cand[PC], s_Vm[PC * PC], s_red[4 * (NH + 1)];
+    __shared__ int s_ctl;                                          // 0 = halve again, 1 = step accepted, 2 = done (converged or failed)
+    const int cnt = *pinv_count, tid = threadIdx.x, N = P.N;
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const int64_t v = pinv_list[slot];
+        // thread-0 state
+        double I[PC * PC], ll = 0.0, Fcur = 0.0, Fcand = 0.0, i11 = 0.0, sn_prev = INFINITY;
+        bool failed = false, conv = false;
+        int halvings = 0;
+        __syncthreads();
+        if (tid == 0) { for (int a = 0; a < PC; ++a) s_beta[a] = 0.0; s_beta[0] = P.ymean_logit; }
+        __syncthreads();
+        blk_info<PC>(T, Vpad, v, N, y, W, s_beta, I, &ll, s_red, tid);
+        if (tid == 0) { Fcur = -(ll + 0.5 * log(slow_det<PC>(I))); i11 = I[PC + 1]; }
+        for (int iter = 0; iter < 1000; ++iter) {
+            if (tid == 0) {
+                double Vm[PC * PC];
+                slow_pinv<PC>(I, Vm);                                                  // model.py:450
+                for (int a = 0; a < PC * PC; ++a) s_Vm[a] = Vm[a];
+            }
+            __syncthreads();
+            double U[PC], beta[PC];
+#pragma unroll
+            for (int a = 0; a < PC; ++a) { U[a] = 0.0; beta[a] = s_beta[a]; }
+            for (int i = tid; i < N; i += 256) {
+                const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
                 double x[PC];
-                x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
-#pragma unroll 1
+                x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
+#pragma unroll
                 for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
                 double eta = 0.0, qf = 0.0;
-#pragma unroll 1
+#pragma unroll
                 for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
                 const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
-#pragma unroll 1
-                for (int a = 0; a < PC; ++a) { double s = 0.0;
-#pragma unroll 1
-                    for (int c = 0; c < PC; ++c) s = fma(Vm[a * PC + c], x[c], s);
-                    qf = fma(x[a], s, qf); }
-                const double res = y[i] - mu + wgt * qf * (0.5 - mu);
-#pragma unroll 1
+#pragma unroll
+                for (int a = 0; a < PC; ++a) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int c = 0; c < PC; ++c) t = fma(s_Vm[a * PC + c], x[c], t);
+                    qf = fma(x[a], t, qf);
+                }
+                const double res = y[i] - mu + wgt * qf * (0.5 - mu);                    // model.py:455-462
+#pragma unroll
                 for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
             }
+            blk_sum<PC>(U, s_red, tid);
+            if (tid == 0) {
+                for (int a = 0; a < PC; ++a) {
+                    double t = 0.0;
+                    for (int c = 0; c < PC; ++c) t = fma(s_Vm[a * PC + c], U[c], t);
+                    s_cand[a] = s_beta[a] + t;
+                }
+                halvings = 0;
+            }
+            for (;;) {                                                                 // step halving, model.py:465-474
+                __syncthreads();
+                blk_info<PC>(T, Vpad, v, N, y, W, s_cand, I, &ll, s_red, tid);
+                if (tid == 0) {
+                    Fcand = -(ll + 0.5 * log(slow_det<PC>(I)));
+                    if (!(Fcand > Fcur)) s_ctl = 1;
+                    else if (++halvings > 1000) { failed = true; s_ctl = 2; }
+                    else { for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); s_ctl = 0; }
+                }
+                __syncthreads();
+                if (s_ctl != 0) break;
+            }
+            if (tid == 0 && !failed) {
+                double sn = 0.0;
+                for (int a = 0; a < PC; ++a) { const double d = s_cand[a] - s_beta[a]; sn = fma(d, d, sn); s_beta[a] = s_cand[a]; }
+                sn = sqrt(sn); Fcur = Fcand; i11 = I[PC + 1];
+                if (iter > 0 && sn_prev < 1e-4) conv = true;                          // the PREVIOUS step, model.py:477-479
+                sn_prev = sn;
+                s_ctl = conv ? 2 : 1;
+            }
+            __syncthreads();
+            if (s_ctl == 2) break;
         }
-#pragma unroll 1
-        for (int a = 0; a < PC; ++a) { double s = 0.0;
-#pragma unroll 1
-            for (int c = 0; c < PC; ++c) s = fma(Vm[a * PC + c], U[c], s);
-            cand[a] = beta[a] + s; }
-        int halvings = 0; double Fcand;
-        for (;;) {
-            slow_info<PC>(T, Vpad, v, N, NB64, y, W, cand, I, &ll);
-            Fcand = -(ll + 0.5 * log(slow_det<PC>(I)));
-            if (!(Fcand > Fcur)) break;
-#pragma unroll 1
-            for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
-            if (++halvings > 1000) { failed = true; break; }
+        if (tid == 0) {
+            if (!conv) failed = true;
+            uint32_t fl = flags[v];
+            if (failed) {
+                fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;
+                out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+                for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
+            } else {
+                const double lrstat = -2.0 * (P.null_firth - (-Fcur));
+                double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);
+                out[V + v] = pval; out[2 * V + v] = s_beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = s_beta[0];
+                for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = s_beta[2 + j];
+                if (pval > P.lrtt || !isfinite(pval) || !isfinite(s_beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+            }
+            flags[v] = fl;
         }
-        if (failed) break;
-        double sn = 0.0;
-#pragma unroll 1
-        for (int a = 0; a < PC; ++a) { const double d = cand[a] - beta[a]; sn = fma(d, d, sn); beta[a] = cand[a]; }
-        sn = sqrt(sn); Fcur = Fcand; i11 = I[PC + 1];
-        if (iter > 0 && sn_prev < 1e-4) conv = true;
-        sn_prev = sn;
     }
-    if (!conv) failed = true;
-    uint32_t fl = flags[v];
-    if (failed) {
-        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;
-        out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
-        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
-    } else {
-        const double lrstat = -2.0 * (P.null_firth - (-Fcur));
-        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);
-        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0];
-        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
-        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
-    }
-    flags[v] = fl;
 }
 
 // =====================================================================================================================
@@ -1402,10 +1463,11 @@ __global__ __launch_bounds__(64) void k_glm_ols_pinv(const uint64_t *__restrict_
 // X: N x PC row-major with the intercept in column 0.
 // =====================================================================================================================
 template <int PC>
-__global__ __launch_bounds__(64) void k_glm_lineage(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int N, int NB64,
+__global__ __launch_bounds__(256) void k_glm_lineage(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int N, int NB64,
                                                     const double *__restrict__ X, int nlin, int *__restrict__ out)
 {
-    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const XWave xw = xwave();                                        // up to four wavefronts share the 64 variants of a block
+    const int64_t v = (int64_t)blockIdx.x * 64 + xw.lane;
     const bool live = v < V;
     const int64_t vr = live ? v : 0;
     double beta[PC];
@@ -1414,14 +1476,14 @@ __global__ __launch_bounds__(64) void k_glm_lineage(const uint64_t *__restrict__
     int it = 0, status = 0, best = -1;
     bool fin = false, active = live;
     const double nobs = (double)N;
-    while (__any(active)) {
+    while (__any(active)) {                                          // `active` is kept identical in all the waves of a block
+        double H[PC * (PC + 1) / 2], g[PC], maxdev = 0.0, unused = 0.0;
+#pragma unroll
+        for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) g[a] = 0.0;
         if (active) {
-            double H[PC * (PC + 1) / 2], g[PC], maxdev = 0.0;
-#pragma unroll
-            for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = 0.0;
-#pragma unroll
-            for (int a = 0; a < PC; ++a) g[a] = 0.0;
-            for (int sb = 0; sb < NB64; ++sb) {
+            for (int sb = xw.w; sb < NB64; sb += xw.S) {
                 const uint64_t w64 = T[(int64_t)sb * Vpad + vr];
                 const int nb = min(64, N - sb * 64);
                 for (int b = 0; b < nb; ++b) {
@@ -1444,6 +1506,9 @@ __global__ __launch_bounds__(64) void k_glm_lineage(const uint64_t *__restrict__
                     }
                 }
             }
+        }
+        xw_sum(xw, H); xw_sum(xw, g); xw_sum_max(xw, unused, maxdev);
+        if (active && xw.w == 0) {
 #pragma unroll
             for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
             double det;
@@ -1483,15 +1548,17 @@ __global__ __launch_bounds__(64) void k_glm_lineage(const uint64_t *__restrict__
                 }
             }
         }
+        xw_bcast(xw, beta, active);
     }
-    if (live) out[v] = (status == 0) ? best : -1;
+    if (live && xw.w == 0) out[v] = (status == 0) ? best : -1;
 }
 
 extern "C" hipError_t shk_glm_lineage(hipStream_t st, int PC, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64,
                                       const double *X, int nlin, int *out)
 {
-    const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
-#define LIN_CASE(p) case p: hipLaunchKernelGGL(k_glm_lineage<p>, grid, blk, 0, st, T, Vpad, V, N, NB64, X, nlin, out); break;
+    const int S = std::min(4, glm_split_waves(NB64));
+    const dim3 grid((unsigned)((V + 63) / 64)), blk(64 * S);
+#define LIN_CASE(p) case p: hipLaunchKernelGGL(k_glm_lineage<p>, grid, blk, glm_split_lds(S), st, T, Vpad, V, N, NB64, X, nlin, out); break;
     switch (PC) {
         LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(5) LIN_CASE(6) LIN_CASE(7) LIN_CASE(8) LIN_CASE(9) LIN_CASE(10)
         LIN_CASE(11) LIN_CASE(12) LIN_CASE(13) LIN_CASE(14) LIN_CASE(15) LIN_CASE(16)
@@ -1504,15 +1571,6 @@ extern "C" hipError_t shk_glm_lineage(hipStream_t st, int PC, const uint64_t *T,
 // ---------------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------------
-// wavefronts per 64 variants in the list-driven kernels: a function of the sample count only, so that results do not depend
-// on what else is in a batch.  SEERHIP_SPLIT=1|2|4|8 overrides it (A/B timing).
-static int glm_split_waves(int NB64)
-{
-    static const int forced = [] { const char *e = getenv("SEERHIP_SPLIT"); return e ? atoi(e) : 0; }();
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
-    return NB64 >= 64 ? 8 : NB64 >= 8 ? 4 : NB64 >= 4 ? 2 : 1;      // measured at N = 500 ... 5000 (DESIGN.md section 5)
-}
-static size_t glm_split_lds(int S) { return S > 1 ? (size_t)((S - 1) * XW_CH + 2) * 64 * sizeof(double) : 0; }
 
 template <int Q>
 static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
@@ -1528,7 +1586,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
     }
     else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
-    else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
+    else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else if (which == 6) hipLaunchKernelGGL(k_glm_ols_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else if (which > 6) return hipErrorInvalidValue;
     else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, plist, pcount);
