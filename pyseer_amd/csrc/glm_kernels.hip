@@ -1393,67 +1393,74 @@ __global__ __launch_bounds__(256) void k_glm_ols_tab(const uint64_t *__restrict_
 // df_resid = N - rank(X).  Here (X^T X)^+ comes from a Jacobi eigendecomposition of X^T X; its eigenvalues resolve the singular
 // values of X only down to sqrt(eps) * s_max, so directions with lambda <= 1e-10 * lambda_max (s <= 1e-5 * s_max) are the null
 // space -- exact collinearity, which is what 0/1 columns against real covariates produce; numpy's own cut-off is s <= 1e-15 s_max.
+// One workgroup of 256 threads per listed variant (see k_glm_firth_pinv): thread t takes samples t, t+256, ...
 template <int Q>
-__global__ __launch_bounds__(64) void k_glm_ols_pinv(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
-                                                     const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
-                                                     const int *__restrict__ pinv_list, const int *__restrict__ pinv_count,
-                                                     double *__restrict__ out, uint32_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_glm_ols_pinv(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                      const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                      const int *__restrict__ pinv_list, const int *__restrict__ pinv_count,
+                                                      double *__restrict__ out, uint32_t *__restrict__ flags)
 {
-    constexpr int PC = Q + 2;
-    const int cnt = *pinv_count;
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    if (slot >= cnt) return;
-    const int64_t v = pinv_list[slot];
-    const int N = P.N, NB64 = P.NB64;
-    double A[PC * PC], Pm[PC * PC], rhs[PC], beta[PC];
-    for (int a = 0; a < PC * PC; ++a) A[a] = 0.0;
-    for (int a = 0; a < PC; ++a) rhs[a] = 0.0;
-    for (int sb = 0; sb < NB64; ++sb) {
-        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
-        const int nb = min(64, N - sb * 64);
-        for (int b = 0; b < nb; ++b) {
-            const int i = sb * 64 + b;
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    __shared__ double s_beta[PC], s_red[4 * (NH + PC)];
+    const int cnt = *pinv_count, tid = threadIdx.x, N = P.N;
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const int64_t v = pinv_list[slot];
+        double acc[NH + PC];                                        // packed lower X^T X, then X^T y
+#pragma unroll
+        for (int a = 0; a < NH + PC; ++a) acc[a] = 0.0;
+        for (int i = tid; i < N; i += 256) {
+            const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
             double x[PC];
-            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
-#pragma unroll 1
+            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
+#pragma unroll
             for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
-#pragma unroll 1
+            const double yi = y[i];
+#pragma unroll
             for (int a = 0; a < PC; ++a) {
-                rhs[a] = fma(x[a], y[i], rhs[a]);
-#pragma unroll 1
-                for (int c = 0; c < PC; ++c) A[a * PC + c] = fma(x[a], x[c], A[a * PC + c]);
+                acc[NH + a] = fma(x[a], yi, acc[NH + a]);
+#pragma unroll
+                for (int c = 0; c <= a; ++c) acc[sidx(a, c)] = fma(x[a], x[c], acc[sidx(a, c)]);
             }
         }
-    }
-    int rank = PC;
-    slow_pinv<PC>(A, Pm, 1e-10, &rank);
-#pragma unroll 1
-    for (int a = 0; a < PC; ++a) { double s = 0.0;
-#pragma unroll 1
-        for (int c = 0; c < PC; ++c) s = fma(Pm[a * PC + c], rhs[c], s);
-        beta[a] = s; }
-    double ssr = 0.0;
-    for (int sb = 0; sb < NB64; ++sb) {
-        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
-        const int nb = min(64, N - sb * 64);
-        for (int b = 0; b < nb; ++b) {
-            const int i = sb * 64 + b;
-            double f = fma(beta[1], (double)(unsigned)((w64 >> b) & 1ull), beta[0]);
-#pragma unroll 1
+        blk_sum<NH + PC>(acc, s_red, tid);
+        double Pm[PC * PC];
+        int rank = PC;
+        if (tid == 0) {
+            double A[PC * PC];
+            for (int a = 0; a < PC; ++a)
+                for (int c = 0; c <= a; ++c) { A[a * PC + c] = acc[sidx(a, c)]; A[c * PC + a] = acc[sidx(a, c)]; }
+            slow_pinv<PC>(A, Pm, 1e-10, &rank);
+            for (int a = 0; a < PC; ++a) {
+                double t = 0.0;
+                for (int c = 0; c < PC; ++c) t = fma(Pm[a * PC + c], acc[NH + c], t);
+                s_beta[a] = t;
+            }
+        }
+        __syncthreads();
+        double ssr[1] = {0.0}, beta[PC];
+#pragma unroll
+        for (int a = 0; a < PC; ++a) beta[a] = s_beta[a];
+        for (int i = tid; i < N; i += 256) {
+            const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
+            double f = fma(beta[1], (double)(unsigned)((w64 >> (i & 63)) & 1ull), beta[0]);
+#pragma unroll
             for (int j = 0; j < Q; ++j) f = fma(beta[2 + j], W[(int64_t)i * Q + j], f);
             const double r = y[i] - f;
-            ssr = fma(r, r, ssr);
+            ssr[0] = fma(r, r, ssr[0]);
         }
+        blk_sum<1>(ssr, s_red, tid);
+        if (tid == 0) {
+            const double dfr = (double)(N - rank);
+            const double kbse = sqrt(ssr[0] / dfr * Pm[PC + 1]);
+            const double pval = sh_t_sf2(beta[1] / kbse, dfr);
+            uint32_t fl = flags[v];
+            if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+            out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = kbse; out[4 * V + v] = beta[0];
+            for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+            flags[v] = fl;
+        }
+        __syncthreads();                                             // s_beta / s_red are reused by the next variant
     }
-    const double dfr = (double)(N - rank);
-    const double kbse = sqrt(ssr / dfr * Pm[PC + 1]);
-    const double pval = sh_t_sf2(beta[1] / kbse, dfr);
-    uint32_t fl = flags[v];
-    if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
-    out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = kbse; out[4 * V + v] = beta[0];
-#pragma unroll 1
-    for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
-    flags[v] = fl;
 }
 
 // =====================================================================================================================
@@ -1587,7 +1594,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
     else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
-    else if (which == 6) hipLaunchKernelGGL(k_glm_ols_pinv<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
+    else if (which == 6) hipLaunchKernelGGL(k_glm_ols_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else if (which > 6) return hipErrorInvalidValue;
     else hipLaunchKernelGGL(k_glm_ols<Q>, grid, blk, 0, st, T, Vpad, V, y, W, y1, y0, yc, ZtZ, Zty, P, out, flags, plist, pcount);
     return hipGetLastError();

@@ -40,3 +40,9 @@ for n in (1, 64, 4096, 131072):
     bb = pack_variants(Kbig[:n])
     print("lineage_batch, %d variants: %.2f ms" % (n, timed(lambda: e.lineage_batch(bb))))
 e.close()
+yc = eta + rng.standard_normal(N)
+nlc = fit_null(yc, W, e0, True).llf
+e = Engine(N); e.glm_setup(yc, W, True, nlc, None)
+print("OLS, %d ordinary variants: %.2f ms" % (V, timed(lambda: e.glm_batch(base))))
+print("  + 1 variant equal to a covariate (rank-deficient, pinv OLS): %.2f ms" % timed(lambda: e.glm_batch(b2)), e.glm_info())
+e.close()
