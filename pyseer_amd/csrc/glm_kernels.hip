@@ -732,7 +732,12 @@ struct FirthWork {
     double *st;                 // [FW_ND(PC)][cap]
     int *iter, *halv, *var;     // [cap] accepted steps (-1 = initial evaluation pending), halvings of the current step, variant index
     int64_t cap;
+    int *blk_list, *blk_count;  // slots handed to k_firth_blk after FIRTH_HANDOFF accepted steps
 };
+// A variant still iterating after this many accepted steps leaves the rounds and is finished by one workgroup (k_firth_blk).
+// The rule looks at the variant alone, so which kernel finishes a variant -- and hence the order of its sums -- does not depend
+// on what else is in the batch.  Ordinary variants converge in 5-14 steps; (quasi-)separated ones need hundreds.
+#define FIRTH_HANDOFF 16
 template <int PC> __host__ __device__ constexpr int fw_beta() { return 0; }
 template <int PC> __host__ __device__ constexpr int fw_cand() { return PC; }
 template <int PC> __host__ __device__ constexpr int fw_fac() { return 2 * PC; }
@@ -838,7 +843,8 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
         for (int a = 0; a < PC * (PC + 1) / 2; ++a) fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s] = A[a];
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = Fcand;
         fw.iter[s] = iter; fw.halv[s] = 0;
-        step_list[atomicAdd(step_count, 1)] = s;
+        if (iter >= FIRTH_HANDOFF) fw.blk_list[atomicAdd(fw.blk_count, 1)] = s;
+        else step_list[atomicAdd(step_count, 1)] = s;
         return;
     }
     if (!failed && !conv) return;                                    // halved: queued above
@@ -918,6 +924,190 @@ __global__ __launch_bounds__(512) void k_firth_step(const uint64_t *__restrict__
 #pragma unroll
     for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = beta[a] + U[a];
     next_eval[atomicAdd(next_eval_count, 1)] = s;
+}
+
+// ---- workgroup reductions for the one-variant-per-workgroup kernels: lanes by xor-shuffle, then waves 0..3, result in thread 0
+template <int NA>
+__device__ __forceinline__ void blk_sum(double (&a)[NA], double *red /* [4][NA] */, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        double t = a[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+        a[k] = t;
+    }
+    __syncthreads();                                              // red may still be read from the previous use
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) red[(tid >> 6) * NA + k] = a[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) a[k] = ((red[k] + red[NA + k]) + red[2 * NA + k]) + red[3 * NA + k];
+    }
+}
+
+// packed lower I(b) and the log-likelihood at b (b in shared memory), samples t, t+256, ... per thread; result in thread 0
+template <int PC>
+__device__ __forceinline__ void blk_info_packed(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N,
+                                                const double *__restrict__ y, const double *__restrict__ W, const double *b_sh,
+                                                double (&acc)[PC * (PC + 1) / 2 + 1], double *red, int tid)
+{
+    constexpr int Q = PC - 2, NH = PC * (PC + 1) / 2;
+    double beta[PC];
+#pragma unroll
+    for (int a = 0; a < NH + 1; ++a) acc[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = b_sh[a];
+    for (int i = tid; i < N; i += 256) {
+        const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
+        double x[PC];
+        x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+        double eta = 0.0;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+        const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+        const double yi = y[i], lm = log(mu);
+        acc[NH] += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));   // as info_pass
+#pragma unroll
+        for (int a = 0; a < PC; ++a) {
+            const double wa = wgt * x[a];
+#pragma unroll
+            for (int c = 0; c <= a; ++c) acc[sidx(a, c)] = fma(wa, x[c], acc[sidx(a, c)]);
+        }
+    }
+    blk_sum<NH + 1>(acc, red, tid);
+}
+
+// Continues fit_firth for the slots on the hand-off list, one workgroup per variant, from the state the rounds left (beta, F(beta),
+// previous step norm, step count): the same iteration and the same decisions as k_firth_eval / k_firth_step, with the samples
+// spread over 256 threads, so an iteration costs ~30 us instead of two latency-bound launches.
+template <int Q>
+__global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                   const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                   FirthWork fw, double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                   int *__restrict__ pinv_list, int *__restrict__ pinv_count)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    const double SING_TOL = 1e-12;
+    __shared__ double s_beta[PC], s_cand[PC], s_fac[NH], s_dinv[PC], s_red[4 * (NH + 1)];
+    __shared__ int s_ctl;                                          // 0 = evaluate the candidate again, 1 = step accepted, 2 = variant done
+    const int cnt = *fw.blk_count, tid = threadIdx.x, N = P.N;
+    const int64_t cap = fw.cap;
+    for (int idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const int s = fw.blk_list[idx];
+        const int64_t v = fw.var[s];
+        double acc[NH + 1];
+        // thread-0 state
+        double Fcur = 0.0, snp = 0.0;
+        int iter = 0, halv = 0;
+        __syncthreads();
+        if (tid == 0) {
+            for (int a = 0; a < PC; ++a) s_beta[a] = fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
+            Fcur = fw.st[(int64_t)fw_fcur<PC>() * cap + s]; snp = fw.st[(int64_t)fw_snp<PC>() * cap + s]; iter = fw.iter[s];
+        }
+        __syncthreads();
+        blk_info_packed<PC>(T, Vpad, v, N, y, W, s_beta, acc, s_red, tid);             // the factor of I(beta) for the score pass
+        if (tid == 0) {
+            double A[NH], det;
+            for (int a = 0; a < NH; ++a) A[a] = acc[a];
+            if (!ldl_factor<PC>(A, SING_TOL, &det)) { pinv_list[atomicAdd(pinv_count, 1)] = (int)v; s_ctl = 2; }
+            else { for (int a = 0; a < NH; ++a) s_fac[a] = A[a]; for (int a = 0; a < PC; ++a) s_dinv[a] = 1.0 / A[sidx(a, a)]; s_ctl = 1; }
+        }
+        __syncthreads();
+        while (s_ctl != 2) {
+            // ---- penalised score at beta through the factor, Newton step -> cand (k_firth_step)
+            double U[PC], beta[PC];
+#pragma unroll
+            for (int a = 0; a < PC; ++a) { U[a] = 0.0; beta[a] = s_beta[a]; }
+            for (int i = tid; i < N; i += 256) {
+                const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
+                double x[PC];
+                x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
+#pragma unroll
+                for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+                double eta = 0.0;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+                const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+                double zt[PC], qf = 0.0;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) {
+                    double t = x[a];
+#pragma unroll
+                    for (int k = 0; k < a; ++k) t = fma(-s_fac[sidx(a, k)], zt[k], t);
+                    zt[a] = t;
+                    qf = fma(t * t, s_dinv[a], qf);
+                }
+                const double res = y[i] - mu + wgt * qf * (0.5 - mu);                    // model.py:455-462
+#pragma unroll
+                for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
+            }
+            blk_sum<PC>(U, s_red, tid);
+            if (tid == 0) {
+                double A[NH];
+                for (int a = 0; a < NH; ++a) A[a] = s_fac[a];
+                ldl_solve<PC>(A, U);                                                   // var_covar_mat . U, model.py:463
+                for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + U[a];
+                halv = 0;
+            }
+            // ---- penalised likelihood at cand; accept / halve / converge / fail (k_firth_eval)
+            for (;;) {
+                __syncthreads();
+                blk_info_packed<PC>(T, Vpad, v, N, y, W, s_cand, acc, s_red, tid);
+                if (tid == 0) {
+                    double A[NH], det;
+                    for (int a = 0; a < NH; ++a) A[a] = acc[a];
+                    const double i11c = A[sidx(1, 1)];
+                    if (!ldl_factor<PC>(A, SING_TOL, &det)) { pinv_list[atomicAdd(pinv_count, 1)] = (int)v; s_ctl = 2; }
+                    else {
+                        const double Fcand = -(acc[NH] + 0.5 * log(det));
+                        double stepmax = 0.0, sn = 0.0;
+                        for (int a = 0; a < PC; ++a) { const double d = s_cand[a] - s_beta[a]; stepmax = fmax(stepmax, fabs(d)); sn = fma(d, d, sn); }
+                        bool failed = false, conv = false;
+                        if (Fcand > Fcur && !(stepmax < 1e-10)) {                       // step halving, model.py:467-474
+                            if (++halv > 1000) failed = true;
+                            else { for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); s_ctl = 0; }
+                        } else {
+                            sn = sqrt(sn);
+                            conv = (iter > 0) && (snp < 1e-4);                           // the PREVIOUS step, model.py:477-479
+                            snp = sn; ++iter;
+                            if (!conv && iter >= 1000) failed = true;                    // step_limit exhausted, model.py:482-484
+                            if (!conv && !failed) {
+                                for (int a = 0; a < PC; ++a) s_beta[a] = s_cand[a];
+                                for (int a = 0; a < NH; ++a) s_fac[a] = A[a];
+                                for (int a = 0; a < PC; ++a) s_dinv[a] = 1.0 / A[sidx(a, a)];
+                                Fcur = Fcand; s_ctl = 1;
+                            }
+                        }
+                        if (failed || conv) {
+                            uint32_t fl = flags[v];
+                            if (failed) {
+                                fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;               // model.py:357-362
+                                out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+                                for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
+                            } else {
+                                const double lrstat = -2.0 * (P.null_firth - (-Fcand));
+                                double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
+                                out[V + v] = pval; out[2 * V + v] = s_cand[1]; out[3 * V + v] = sqrt(i11c); out[4 * V + v] = s_cand[0];
+                                for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = s_cand[2 + j];
+                                if (pval > P.lrtt || !isfinite(pval) || !isfinite(s_cand[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+                            }
+                            flags[v] = fl;
+                            s_ctl = 2;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_ctl != 0) break;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // =====================================================================================================================
@@ -1000,28 +1190,6 @@ __device__ __noinline__ void slow_pinv(const double *Ain, double *Pm, double rco
 // (a k-mer that duplicates a binary covariate), and a single lane walking all N samples through un-unrolled loops for every
 // pass of every iteration cost about a second per batch at N = 5000.  The p x p algebra (numpy's pinv and det) stays on thread
 // 0; sums are combined in a fixed order (lanes by xor-shuffle, then waves 0..3).
-template <int NA>
-__device__ __forceinline__ void blk_sum(double (&a)[NA], double *red /* [4][NA] */, int tid)
-{
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-        double t = a[k];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
-        a[k] = t;
-    }
-    __syncthreads();                                              // red may still be read from the previous use
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k) red[(tid >> 6) * NA + k] = a[k];
-    }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k) a[k] = ((red[k] + red[NA + k]) + red[2 * NA + k]) + red[3 * NA + k];
-    }
-}
-
 // I(b) (full PC x PC into I_out, thread 0) and the log-likelihood at b (shared memory vector)
 template <int PC>
 __device__ __forceinline__ void blk_info(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N,
@@ -1616,7 +1784,7 @@ extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uin
 #undef GLM_CASE
 }
 
-// ---- Firth state machine launchers: which = 0 init, 1 eval, 2 step; n = upper bound of the list length (grid size) ----
+// ---- Firth state machine launchers: which = 0 init, 1 eval, 2 step, 3 hand-off list; n = upper bound of the list length ----
 template <int Q>
 static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
                                const double *W, GlmParams P, FirthWork fw, const int *in_list, const int *in_count, int *next_eval,
@@ -1628,7 +1796,8 @@ static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint6
     if (which == 0) hipLaunchKernelGGL(k_firth_init<Q>, grid, blk, 0, st, in_list, in_count, P, fw, next_eval, next_eval_count);
     else if (which == 1) hipLaunchKernelGGL(k_firth_eval<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
                                             next_eval_count, step_list, step_count, out, flags, plist, pcount);
-    else hipLaunchKernelGGL(k_firth_step<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    else if (which == 2) hipLaunchKernelGGL(k_firth_step<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    else hipLaunchKernelGGL(k_firth_blk<Q>, dim3((unsigned)std::min<int64_t>(n, 2048)), dim3(256), 0, st, T, Vpad, V, y, W, P, fw, out, flags, plist, pcount);
     return hipGetLastError();
 }
 
@@ -1637,9 +1806,10 @@ extern "C" int shk_firth_state_doubles(int Q) { const int PC = Q + 2; return 2 *
 extern "C" hipError_t shk_firth_launch(hipStream_t st, int Q, int which, int64_t n, const uint64_t *T, int64_t Vpad, int64_t V,
                                        const double *y, const double *W, GlmParams P, double *fst, int *fiter, int *fhalv, int *fvar,
                                        int64_t fcap, const int *in_list, const int *in_count, int *next_eval, int *next_eval_count,
-                                       int *step_list, int *step_count, double *out, uint32_t *flags, int *plist, int *pcount)
+                                       int *step_list, int *step_count, double *out, uint32_t *flags, int *plist, int *pcount,
+                                       int *blk_list, int *blk_count)
 {
-    FirthWork fw{fst, fiter, fhalv, fvar, fcap};
+    FirthWork fw{fst, fiter, fhalv, fvar, fcap, blk_list, blk_count};
 #define FIRTH_CASE(q) case q: return launch_firth<q>(st, which, n, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval, next_eval_count, step_list, step_count, out, flags, plist, pcount);
     switch (Q) {
         FIRTH_CASE(0) FIRTH_CASE(1) FIRTH_CASE(2) FIRTH_CASE(3) FIRTH_CASE(4) FIRTH_CASE(5) FIRTH_CASE(6) FIRTH_CASE(7)

@@ -70,6 +70,28 @@ def _firth_case(seed):
     return N, q, _rescale(W, seed), y, K
 
 
+def _lineage_case(seed):
+    rng = np.random.default_rng(4000 + seed)
+    N = int(rng.choice([90, 128, 200, 333, 600]))
+    nl = int(rng.choice([1, 2, 3, 5, 9, 13, 14, 15, 18, 25]))
+    j = int(rng.choice([0, 0, 1, 3]))
+    nl = max(1, min(nl, N // 12 - 1 - j))                          # 19 columns on 90 samples separate almost every k-mer: not a parity case
+    V = 48
+    clusters = bool(rng.integers(0, 2)) and nl >= 2
+    cl = None
+    if clusters:
+        cl = rng.integers(0, nl + 1, N)
+        lin = np.zeros((N, nl)); lin[np.arange(N)[cl > 0], cl[cl > 0] - 1] = 1.0
+        base = rng.uniform(0.25, 0.75, (V, nl + 1))
+        K = (rng.random((V, N)) < base[:, cl]).astype(np.uint8)
+    else:
+        lin = rng.standard_normal((N, nl)); lin /= np.abs(lin).max(axis=0)           # scale_fix=False MDS columns, input.py:135
+        w = rng.standard_normal((V, nl)) * rng.uniform(0, 2, (V, 1))
+        K = (rng.random((V, N)) < 1 / (1 + np.exp(-(lin @ w.T).T - rng.uniform(-1, 1, (V, 1))))).astype(np.uint8)
+    cov = _rescale(rng.standard_normal((N, j)), seed) if j else None
+    return N, nl, j, V, clusters, cl, lin, cov, K
+
+
 @pytest.mark.parametrize("seed", _SEEDS)
 def test_lmm_random_configurations(seed):
     from oracle import oracle as orc
@@ -188,22 +210,7 @@ def test_lineage_random_configurations(seed):
     from oracle import oracle as orc
     from pyseer_amd.engine import Engine, pack_variants
     from test_oracle_golden import _same_or_tied
-    rng = np.random.default_rng(4000 + seed)
-    N = int(rng.choice([90, 128, 200, 333, 600]))
-    nl = int(rng.choice([1, 2, 3, 5, 9, 13, 14, 15, 18, 25]))
-    j = int(rng.choice([0, 0, 1, 3]))
-    V = 48
-    clusters = bool(rng.integers(0, 2)) and nl >= 2
-    if clusters:
-        cl = rng.integers(0, nl + 1, N)
-        lin = np.zeros((N, nl)); lin[np.arange(N)[cl > 0], cl[cl > 0] - 1] = 1.0
-        base = rng.uniform(0.25, 0.75, (V, nl + 1))
-        K = (rng.random((V, N)) < base[:, cl]).astype(np.uint8)
-    else:
-        lin = rng.standard_normal((N, nl)); lin /= np.abs(lin).max(axis=0)           # scale_fix=False MDS columns, input.py:135
-        w = rng.standard_normal((V, nl)) * rng.uniform(0, 2, (V, 1))
-        K = (rng.random((V, N)) < 1 / (1 + np.exp(-(lin @ w.T).T - rng.uniform(-1, 1, (V, 1))))).astype(np.uint8)
-    cov = _rescale(rng.standard_normal((N, j)), seed) if j else None
+    N, nl, j, V, clusters, cl, lin, cov, K = _lineage_case(seed)
     e = Engine(N)
     e.lineage_setup(lin, cov)
     got = e.lineage_batch(pack_variants(K))

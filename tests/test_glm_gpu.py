@@ -357,3 +357,44 @@ def test_wide_lineage_vs_oracle(nl, j):
     assert (~sep).sum() >= V // 2
     g = [None if x < 0 else int(x) for x in got]
     _same_or_tied([g[v] for v in range(V) if not sep[v]], [want[v] for v in range(V) if not sep[v]], lin, cov, K[~sep])
+
+
+def test_firth_long_iterations_finish_in_the_workgroup_kernel():
+    """(Quasi-)separated variants need far more than 16 Firth steps; after 16 the rounds hand a variant to k_firth_blk (one
+    workgroup per variant), which must continue the same iteration: same decisions, same results as the oracle."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null, _cdf, _info, firth_likelihood
+    rng = np.random.default_rng(90210)
+    N, q = 700, 3
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    y = (rng.random(N) < 1 / (1 + np.exp(0.2 - W[:, 0]))).astype(float)
+    K = np.stack([y, 1 - y, y * (rng.random(N) < 0.9), 1 - y * (rng.random(N) < 0.8), np.maximum(y, rng.random(N) < 0.05),
+                  (rng.random(N) < 0.4).astype(float)]).astype(np.uint8)
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+
+    def firth_steps(k):                                        # accepted steps of fit_firth (numpy restatement of model.py:414-504)
+        X = np.c_[np.ones(N), k, W]; b = np.zeros(q + 2); b[0] = np.log(y.mean() / (1 - y.mean())); prev = np.inf
+        for it in range(1000):
+            pi = _cdf(X.dot(b)); w = pi * (1 - pi); Vm = np.linalg.pinv(_info(X, b))
+            h = w * np.einsum("ij,jk,ik->i", X, Vm, X)
+            nb = b + Vm.dot(X.T.dot(y - pi + h * (0.5 - pi)))
+            while firth_likelihood(nb, X, y) > firth_likelihood(b, X, y):
+                nb = b + 0.5 * (nb - b)
+            sn = np.linalg.norm(nb - b); b = nb
+            if it > 0 and prev < 1e-4:
+                return it + 1
+            prev = sn
+        return 1000
+    steps = [firth_steps(k.astype(float)) for k in K]
+    assert max(steps) > 40 and min(steps) < 16, steps          # both sides of the hand-off are exercised
+    want = orc.firth_batch(y, K.astype(float), W)
+    e = Engine(N)
+    e.glm_setup(y, W, False, nl, nf, force_firth=True)
+    r = e.glm_batch(pack_variants(K))
+    e.close()
+    assert (want["status"] == 0).all() and not ((r["flags"] >> 6) & 1).any()
+    for f in ("intercept", "kbeta", "bse"):
+        close(r[f], want[f], rtol=2e-6, atol=1e-6, what=f)
+    close(r["betas"], want["betas"], rtol=2e-6, atol=1e-6, what="betas")
