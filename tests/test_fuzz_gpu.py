@@ -108,6 +108,10 @@ def test_lmm_random_configurations(seed):
     covar = np.ones((N, 1)) if D == 1 else np.c_[_rescale(rng.standard_normal((N, D - 1)), seed), np.ones((N, 1))]
     y = rng.standard_normal(N) if cont else (rng.random(N) < 0.4).astype(float)
     h2 = float(rng.uniform(0.0, 0.95))
+    if seed % 5 == 2:                                             # rank-deficient kinship: numerically zero eigenvalues of either sign
+        nz = max(2, k // 6); S[-nz:] = np.random.default_rng(6000 + seed).uniform(-1, 1, nz) * 1e-13
+    elif seed % 5 == 4:                                           # a similarity matrix that is not PSD: negative eigenvalues, Sd still > 0
+        S[-3:] = -np.array([0.5, 0.3, 0.1]) * min(1.0, (1 - h2) / max(h2, 1e-3))
     fp, lp = (1.0, 1.0) if seed % 3 == 0 else (float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.2, 0.9)))
     Kv = _variants(rng, N, V)
     af = Kv.mean(axis=1)
