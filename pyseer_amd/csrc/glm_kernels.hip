@@ -289,7 +289,7 @@ template <int Q> struct FastCols {
     static constexpr int LDS_FLOATS = 32 * (STRIDE + 1);
 };
 
-template <int Q>
+template <int Q, bool F32>
 __device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
                                                const double *__restrict__ y, const double *__restrict__ W,
                                                const float *__restrict__ Wf, const float *__restrict__ ZZ,
@@ -311,7 +311,29 @@ __device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, i
 #pragma unroll
     for (int a = 0; a < P; ++a) g[a] = 0.0;
     maxdev = 0.0;
+    // F32: the whole sample in single precision (one v_exp_f32 instead of the fp64 exp sequence, half-cost FMAs).  Used for the first
+    // Newton steps only; they need to land within ~1e-4 of the optimum, and the fp64 steps that follow set the fixed point.
+    float bf[P], gf[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) { bf[a] = (float)beta[a]; gf[a] = 0.0f; }
     auto sample = [&](int i, bool xb) -> float {
+        if constexpr (F32) {
+            float eta = bf[0] + (xb ? bf[1] : 0.0f);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j], Wf[(int64_t)i * Q + j], eta);
+            const float mu = 1.0f / (1.0f + __expf(-eta));
+            const float r = (float)y[i] - mu;
+            gf[0] += r; gf[1] += xb ? r : 0.0f;
+            const float wf = mu * (1.0f - mu);
+            const float wx = xb ? wf : 0.0f;
+            h00 += wf; h10 += wx;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const float zj = Wf[(int64_t)i * Q + j];
+                gf[2 + j] = fmaf(r, zj, gf[2 + j]); hz0[j] = fmaf(wf, zj, hz0[j]); hz1[j] = fmaf(wx, zj, hz1[j]);
+            }
+            return wf;
+        }
         double eta = beta[0] + (xb ? beta[1] : 0.0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], W[(int64_t)i * Q + j], eta);
@@ -362,6 +384,11 @@ __device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, i
         }
     } else {
         for (int i = 0; i < N; ++i) sample(i, (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+    }
+    if constexpr (F32) {
+#pragma unroll
+        for (int a = 0; a < P; ++a) g[a] = (double)gf[a];
+        maxdev = 1.0;                                                         // no separation verdict from a single-precision pass
     }
     H[sidx(0, 0)] = h00; H[sidx(1, 0)] = h10; H[sidx(1, 1)] = h10;
 #pragma unroll
@@ -426,13 +453,20 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
     beta[0] = P.ymean_logit;
     bool need_slow = want_fit && (P.newton_mode == 1);
     bool active = want_fit && !need_slow;
-    int it = 0;
+    int it = 0, pass = 0;
     __shared__ float tr[FastCols<Q>::LDS_FLOATS];
     while (__any(active)) {
         float Hf[PC * (PC + 1) / 2];
         double g[PC], maxdev;
-        // the matrix-pipe pass is wave-wide (permlane swap, MFMA): lanes that already stopped ride along with their frozen beta
-        if (P.zz) fast_pass_mfma<Q>(T, Vpad, vr, N, NB64, y, W, Wf, P.zz, beta, Hf, g, maxdev, tr);
+        // the matrix-pipe pass is wave-wide (permlane swap, MFMA): lanes that already stopped ride along with their frozen beta.
+        // The first P.f32_steps passes of a wavefront run entirely in single precision (all its lanes start together, so a lane's
+        // step count is the wavefront's pass count); a lane cannot be declared converged by such a pass.
+        const bool f32 = pass < P.f32_steps;
+        if (P.zz) {
+            if (f32) fast_pass_mfma<Q, true>(T, Vpad, vr, N, NB64, y, W, Wf, P.zz, beta, Hf, g, maxdev, tr);
+            else fast_pass_mfma<Q, false>(T, Vpad, vr, N, NB64, y, W, Wf, P.zz, beta, Hf, g, maxdev, tr);
+        }
+        ++pass;
         if (active) {
             if (!P.zz) fast_pass<Q>(T, Vpad, vr, N, NB64, y, W, Wf, beta, Hf, g, maxdev);
             if (it > 0 && maxdev <= 1e-8) { need_slow = true; active = false; }
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
                     for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); finite = finite && isfinite(beta[a]); }
                     ++it;
                     if (!finite) { need_slow = true; active = false; }
-                    else if (!moving) active = false;                                               // converged
+                    else if (!moving && !(f32 && P.zz)) active = false;                             // converged (fp64 score only)
                     else if (it >= 12) { need_slow = true; active = false; }
                 }
             }
