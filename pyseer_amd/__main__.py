@@ -76,6 +76,8 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
+    ot.add_argument('--gpus', default=None, help='Comma-separated GPU indices, or a count N (= 0..N-1): every block of variants is '
+                    'split into contiguous shards, one per GPU, results keep the input order [Default: the single --gpu]')
     ot.add_argument('--save-packed', default=None,
                     help='Also write the parsed k-mer file as packed bit rows (for --load-packed in later runs over the same samples)')
     ot.add_argument('--load-packed', default=None,
@@ -207,15 +209,24 @@ def main(argv=None):
                 lineage_out.write("\t".join([lineage, str(wald), str(2 * (1 - norm.cdf(wald)))]) + "\n")
 
     from .engine import Engine
+
+    def make_engine(n):
+        if options.gpus is None:
+            return Engine(n, device=options.gpu)
+        devs = [int(x) for x in options.gpus.split(",")] if "," in options.gpus else list(range(int(options.gpus)))
+        if len(devs) == 1:
+            return Engine(n, device=devs[0])
+        from .parallel import ShardedEngine                          # one context and one host thread per GPU
+        return ShardedEngine(n, devs)
     if options.lmm:
         sys.stderr.write("Setting up LMM\n")
         p, lmm, h2 = initialise_lmm(p, cov, options.similarity, options.load_lmm, options.save_lmm,
                                     use_gpu=not options.cpu_eigh, device=options.gpu)
         sys.stderr.write("h^2 = " + '{0:.2f}'.format(h2) + "\n")
-        eng = Engine(len(p), device=options.gpu)
+        eng = make_engine(len(p))
         eng.lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)
     else:
-        eng = Engine(len(p), device=options.gpu)
+        eng = make_engine(len(p))
         eng.glm_setup(p.values, covariate_block(len(p), m, cov), options.continuous,
                       np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
                       options.filter_pvalue, options.lrt_pvalue)

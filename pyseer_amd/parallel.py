@@ -88,3 +88,16 @@ class ShardedEngine(object):
 
     def glm_batch(self, bits):
         return self._sharded(bits, "glm_batch")
+
+    def set_dedup(self, on=True):
+        """Per shard: a pattern repeated within one shard is tested once; results are identical either way."""
+        self._each(lambda i, e: e.set_dedup(on))
+
+    def lineage_setup(self, lin, cov=None):
+        self._each(lambda i, e: e.lineage_setup(lin, cov))
+
+    def lineage_batch(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        world = len(self.engines)
+        spans = [shard_bounds(bits.shape[0], r, world) for r in range(world)]
+        return np.concatenate(self._each(lambda i, e: e.lineage_batch(bits[spans[i][0]:spans[i][1]])), axis=0)
