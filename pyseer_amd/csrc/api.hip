@@ -25,6 +25,8 @@ hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, const double *, LmmLinOut);
 hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, const double *, const double *, int, int, int, int, double *);
 hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *);
+hipError_t shk_af_compact(hipStream_t, int, int64_t, int, const int *, double, double, int *, int *, const uint64_t *, int64_t, uint64_t *,
+                          int64_t, int, int, const double *, double *);
 hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
                            unsigned long long *, int8_t *);
@@ -63,6 +65,9 @@ struct sh_ctx {
     uint64_t *d_T = nullptr;
     int *d_t11 = nullptr, *d_t01 = nullptr, *d_m = nullptr;
     double *d_xky = nullptr, *d_dg = nullptr, *d_rss = nullptr, *d_s1 = nullptr, *d_q1 = nullptr, *d_q = nullptr;
+    uint64_t *d_T2 = nullptr; double *d_q2 = nullptr; int *d_keep = nullptr, *d_nkeep = nullptr; int64_t cap_keep = 0;   // AF compaction
+    int af_compact = 1; int64_t last_kept = -1;
+    int *h_nkeep = nullptr; hipEvent_t keep_ev = nullptr; bool keep_pending = false; int64_t keep_V = 0; double filtered_hint = 0.0;
     // ---- optional timing of the dominant kernel (sh_set_timing / sh_get_timing)
     int timing = 0;
     int lin_tab = 1;                                  // SEERHIP_LIN=0: per-sample k_lmm_linear instead of the nibble tables
@@ -89,6 +94,8 @@ static void free_ws(sh_ctx *c)
     hipFree(c->d_rss); hipFree(c->d_s1); hipFree(c->d_q1); hipFree(c->d_q);
     c->d_T = nullptr; c->d_t11 = c->d_t01 = c->d_m = nullptr;
     c->d_xky = c->d_dg = c->d_rss = c->d_s1 = c->d_q1 = c->d_q = nullptr; c->capV = 0;
+    hipFree(c->d_T2); hipFree(c->d_q2); hipFree(c->d_keep); hipFree(c->d_nkeep);
+    c->d_T2 = nullptr; c->d_q2 = nullptr; c->d_keep = c->d_nkeep = nullptr; c->cap_keep = 0;
 }
 
 static int ensure_ws(sh_ctx *c, int64_t Vpad)
@@ -259,6 +266,7 @@ sh_ctx *sh_create(int device, int n_samples)
     if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
     if (const char *qs = std::getenv("SEERHIP_QF_SPLIT")) c->qf_split = std::atoi(qs);
     if (const char *ql = std::getenv("SEERHIP_LIN")) c->lin_tab = std::atoi(ql);
+    if (const char *ac = std::getenv("SEERHIP_AFCOMPACT")) c->af_compact = std::atoi(ac);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
     return c;
@@ -269,6 +277,8 @@ void sh_destroy(sh_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     free_ws(c);
+    if (c->h_nkeep) hipHostFree(c->h_nkeep);
+    if (c->keep_ev) hipEventDestroy(c->keep_ev);
     hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_tab);
     hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);
     for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
@@ -494,7 +504,45 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const int lsplit = c->qf_split ? c->L : 1;
-    HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q));
+    // AF-filtered variants never read their quadratic form: contract only the kept columns when >= 3 % of the batch is filtered.
+    // Knowing the count costs a host round trip, which would serialise back-to-back batches; so a stream whose last counted batch
+    // had < 3 % filtered is only counted asynchronously (pinned counter + event, looked at when the next batch arrives) and runs the
+    // plain path, and a stream that does filter pays the round trip and saves the work.  Results are identical either way.
+    int64_t nk = V;
+    bool compact = false;
+    if (c->af_on && c->af_compact) {
+        if (Vpad > c->cap_keep) {
+            hipFree(c->d_T2); hipFree(c->d_q2); hipFree(c->d_keep); hipFree(c->d_nkeep);
+            c->d_T2 = nullptr; c->d_q2 = nullptr; c->d_keep = c->d_nkeep = nullptr;
+            HIPCHK(dmalloc(&c->d_T2, (size_t)Vpad * c->NB64p)); HIPCHK(dmalloc(&c->d_q2, Vpad * 8)); HIPCHK(dmalloc(&c->d_keep, Vpad));
+            HIPCHK(dmalloc(&c->d_nkeep, 1)); c->cap_keep = Vpad;
+        }
+        if (!c->h_nkeep) { HIPCHK(hipHostMalloc((void **)&c->h_nkeep, sizeof(int))); HIPCHK(hipEventCreateWithFlags(&c->keep_ev, hipEventDisableTiming)); }
+        if (c->keep_pending && hipEventQuery(c->keep_ev) == hipSuccess) {
+            c->filtered_hint = 1.0 - (double)*c->h_nkeep / (double)c->keep_V; c->keep_pending = false;
+        }
+        if (!c->keep_pending) {
+            HIPCHK(hipMemsetAsync(c->d_nkeep, 0, sizeof(int), st));
+            HIPCHK(shk_af_compact(st, 0, V, c->N, c->d_m, c->min_af, c->max_af, c->d_keep, c->d_nkeep, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr));
+            HIPCHK(hipMemcpyAsync(c->h_nkeep, c->d_nkeep, sizeof(int), hipMemcpyDeviceToHost, st));
+            if (c->filtered_hint >= 0.03 || c->af_compact == 2) {                 // SEERHIP_AFCOMPACT=2: always count (tests)
+                HIPCHK(hipStreamSynchronize(st));
+                nk = *c->h_nkeep; c->filtered_hint = 1.0 - (double)nk / (double)V;
+                compact = nk * 100 <= V * 97;
+            } else {
+                HIPCHK(hipEventRecord(c->keep_ev, st)); c->keep_pending = true; c->keep_V = V;
+            }
+        }
+    }
+    c->last_kept = compact ? nk : -1;
+    if (compact && nk > 0) {
+        const int64_t Vpad2 = (nk + 511) / 512 * 512;
+        HIPCHK(shk_af_compact(st, 1, V, c->N, nullptr, 0, 0, c->d_keep, nullptr, c->d_T, Vpad, c->d_T2, Vpad2, c->NB64p, (int)nk, nullptr, nullptr));
+        HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T2, Vpad2, 2 * c->NT, c->L, lsplit, c->d_q2));
+        HIPCHK(shk_af_compact(st, 2, V, c->N, nullptr, 0, 0, c->d_keep, nullptr, nullptr, Vpad, nullptr, Vpad2, lsplit, (int)nk, c->d_q2, c->d_q));
+    } else if (!compact) {
+        HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q));
+    }
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->tev.emplace_back(e0, e1); }
     LmmFinParams P = c->fin; P.min_af = c->min_af; P.max_af = c->max_af; P.af_on = c->af_on;
     HIPCHK(shk_lmm_finalize(st, V, Vpad, lsplit, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags));

@@ -580,6 +580,44 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, i
     flags[v] = fl;
 }
 
+// ---- AF compaction: the quadratic form is the whole cost of a variant and an AF-filtered variant never reads it (k_lmm_finalize),
+// so when enough of a batch is filtered the kept columns of T are gathered into a dense image and only those are contracted.
+__global__ __launch_bounds__(256) void k_af_keep(int64_t V, int N, const int *__restrict__ m, double min_af, double max_af,
+                                                 int *__restrict__ idx, int *__restrict__ n)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const double af = (double)m[v] / (double)N;
+    if (min_af <= af && af <= max_af) idx[atomicAdd(n, 1)] = (int)v;      // any order: results are per variant and scattered back
+}
+
+__global__ __launch_bounds__(256) void k_gather_T(const uint64_t *__restrict__ T, int64_t Vpad, uint64_t *__restrict__ T2, int64_t Vpad2,
+                                                  const int *__restrict__ idx, int nk)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= Vpad2) return;
+    const int64_t sb = blockIdx.y;
+    T2[sb * Vpad2 + j] = j < nk ? T[sb * Vpad + idx[j]] : 0ull;            // padding columns: empty variants
+}
+
+__global__ __launch_bounds__(256) void k_scatter_q(const double *__restrict__ q2, int64_t Vpad2, double *__restrict__ q, int64_t Vpad,
+                                                   const int *__restrict__ idx, int nk)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nk) return;
+    q[(int64_t)blockIdx.y * Vpad + idx[j]] = q2[(int64_t)blockIdx.y * Vpad2 + j];
+}
+
+extern "C" hipError_t shk_af_compact(hipStream_t st, int which, int64_t V, int N, const int *m, double min_af, double max_af, int *idx, int *n,
+                                     const uint64_t *T, int64_t Vpad, uint64_t *T2, int64_t Vpad2, int rows, int nk,
+                                     const double *q2, double *q)
+{
+    if (which == 0) hipLaunchKernelGGL(k_af_keep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, m, min_af, max_af, idx, n);
+    else if (which == 1) hipLaunchKernelGGL(k_gather_T, dim3((unsigned)((Vpad2 + 255) / 256), (unsigned)rows), dim3(256), 0, st, T, Vpad, T2, Vpad2, idx, nk);
+    else hipLaunchKernelGGL(k_scatter_q, dim3((unsigned)((nk + 255) / 256), (unsigned)rows), dim3(256), 0, st, q2, Vpad2, q, Vpad, idx, nk);
+    return hipGetLastError();
+}
+
 // =============================================================================================
 // Setup kernels (once per run)
 // =============================================================================================

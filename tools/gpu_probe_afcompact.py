@@ -1,0 +1,26 @@
+"""Development probe: LMM batch time at N = 5000 when a fraction of the k-mers is AF-filtered (real k-mer tables are U-shaped)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pyseer_amd.engine import Engine, row_bytes_for
+from bench import synth_lmm_inputs, synth_bits
+N, V = 5000, 1 << 19
+dev = torch.device("cuda", 0)
+U, S, h2, C, y, _ = synth_lmm_inputs(N, 1003, dev)
+bits = synth_bits(V, N, row_bytes_for(N), 11, dev)
+for frac in (0.0, 0.02, 0.1, 0.3, 0.6):
+    b = bits.clone()
+    nr = int(V * frac)
+    if nr:
+        rare = torch.randperm(V, device=dev)[:nr]
+        b[rare] = 0; b[rare, 0] = 1                                  # one carrier: AF = 1/N < 1 %
+    for on in ("0", "1"):
+        os.environ["SEERHIP_AFCOMPACT"] = on
+        e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
+        e.lmm_setup(U, S, y, C, h2)
+        e.lmm_batch_dev(b); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): e.lmm_batch_dev(b)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        print("extra filtered %.0f%%  compaction %s: %.2f ms per %d variants (%.1f M/s)" % (100 * frac, on, dt * 1e3, V, V / dt / 1e6))
+        e.close()
