@@ -31,6 +31,7 @@ hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
                            unsigned long long *, int8_t *);
 hipError_t shk_dd_find(hipStream_t, const uint64_t *, int64_t, int64_t, int, uint64_t *, uint64_t, unsigned long long *, int *, int *, int *, int *);
+hipError_t shk_af_rows(hipStream_t, int, const uint8_t *, int64_t, int64_t, int, double, double, int *, int *, int *);
 hipError_t shk_dd_gather(hipStream_t, const uint8_t *, int64_t, int64_t, const int *, const int *, uint8_t *);
 hipError_t shk_dd_scatter(hipStream_t, int64_t, int64_t, int, const int *, const int *, const double *, const uint32_t *, double *, uint32_t *);
 }
@@ -76,6 +77,10 @@ struct sh_ctx {
     int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
     uint64_t *dd_h = nullptr; unsigned long long *dd_keys = nullptr; int *dd_idx = nullptr, *dd_rep = nullptr, *dd_slot = nullptr, *dd_n = nullptr;
     uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0;
+    // row-level AF compaction of the fixed-effects path (af_wrap): its own buffers, because the wrapped call may de-duplicate
+    int *af_rep = nullptr, *af_slot = nullptr, *af_cnt = nullptr, *h_af_cnt = nullptr; int64_t af_capV = 0;
+    uint8_t *af_bits = nullptr; double *af_out = nullptr; uint32_t *af_flags = nullptr; int64_t af_cap_bits = 0, af_cap_out = 0;
+    hipEvent_t af_ev = nullptr; bool af_pending = false; int64_t af_pending_V = 0; double af_hint = 0.0; int64_t af_last_rows = -1; unsigned af_tick = 0;
     // ---- similarity accumulation (sim_kernels.hip)
     unsigned long long *sim_K = nullptr; uint64_t *sim_S = nullptr, *sim_keep = nullptr; double *sim_out = nullptr; int64_t sim_capV = 0; int NS = 0;
     // ---- pipelined host-pointer batches (host_batch)
@@ -237,6 +242,58 @@ static int dedup_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t 
     return SH_OK;
 }
 
+// Rows outside the AF window all give the same output, so one of them stands for all: only the kept rows (+ that one) go through
+// `inner`.  Same adaptive rule as in lmm_batch_dev_inner: a stream that does not filter is only counted asynchronously.
+template <typename F>
+static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags, int nrow, F inner)
+{
+    c->af_last_rows = -1;
+    if (!(c->af_on && c->af_compact) || V < 1024) return inner(d_bits, V, d_out, d_flags);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (V > c->af_capV) {
+        hipFree(c->af_rep); hipFree(c->af_slot); c->af_rep = c->af_slot = nullptr;
+        HIPCHK(dmalloc(&c->af_rep, V)); HIPCHK(dmalloc(&c->af_slot, V)); c->af_capV = V;
+    }
+    if (!c->af_cnt) {
+        HIPCHK(dmalloc(&c->af_cnt, 2)); HIPCHK(hipHostMalloc((void **)&c->h_af_cnt, 2 * sizeof(int)));
+        HIPCHK(hipEventCreateWithFlags(&c->af_ev, hipEventDisableTiming));
+    }
+    if (c->af_pending && hipEventQuery(c->af_ev) == hipSuccess) {
+        c->af_hint = 1.0 - (double)c->h_af_cnt[0] / (double)c->af_pending_V; c->af_pending = false;
+    }
+    bool compact = false; int nk = 0, R = 0;
+    // a stream that does not filter is sampled: every fourth batch is counted
+    // (a wavefront holds 64 variants and a batch is a few rounds of wavefronts, so dropping < 10 % of the rows rarely removes a round)
+    if (!c->af_pending && (c->af_hint >= 0.10 || c->af_compact == 2 || (c->af_tick++ & 3) == 0)) {
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->af_cnt, 0, 1, st));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->af_cnt + 1), 2147483647, 1, st));
+        HIPCHK(shk_af_rows(st, 0, (const uint8_t *)d_bits, row_bytes, V, c->N, c->min_af, c->max_af, c->af_rep, c->af_slot, c->af_cnt));
+        HIPCHK(hipMemcpyAsync(c->h_af_cnt, c->af_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (c->af_hint >= 0.10 || c->af_compact == 2) {
+            HIPCHK(hipStreamSynchronize(st));
+            nk = c->h_af_cnt[0]; R = c->h_af_cnt[1];
+            c->af_hint = 1.0 - (double)nk / (double)V;
+            compact = (int64_t)nk * 100 <= V * 90 || (c->af_compact == 2 && (int64_t)nk * 100 <= V * 97);
+        } else {
+            HIPCHK(hipEventRecord(c->af_ev, st)); c->af_pending = true; c->af_pending_V = V;
+        }
+    }
+    if (!compact) return inner(d_bits, V, d_out, d_flags);
+    const int64_t nu = (int64_t)nk + (R != 2147483647 ? 1 : 0);
+    if (nu * row_bytes > c->af_cap_bits) { hipFree(c->af_bits); c->af_bits = nullptr; HIPCHK(hipMalloc((void **)&c->af_bits, nu * row_bytes)); c->af_cap_bits = nu * row_bytes; }
+    if (nu * nrow > c->af_cap_out) {
+        hipFree(c->af_out); hipFree(c->af_flags); c->af_out = nullptr; c->af_flags = nullptr;
+        HIPCHK(dmalloc(&c->af_out, nu * nrow)); HIPCHK(dmalloc(&c->af_flags, nu)); c->af_cap_out = nu * nrow;
+    }
+    HIPCHK(shk_af_rows(st, 1, nullptr, 0, V, 0, 0, 0, c->af_rep, c->af_slot, c->af_cnt));
+    HIPCHK(shk_dd_gather(st, (const uint8_t *)d_bits, row_bytes, V, c->af_rep, c->af_slot, c->af_bits));
+    c->af_last_rows = nu;
+    int rc = inner(c->af_bits, nu, c->af_out, c->af_flags); if (rc) return rc;
+    HIPCHK(shk_dd_scatter(st, V, nu, nrow, c->af_rep, c->af_slot, c->af_out, c->af_flags, (double *)d_out, (uint32_t *)d_flags));
+    return SH_OK;
+}
+
 extern "C" {
 
 int sh_abi_version(void) { return SH_ABI_VERSION; }
@@ -278,6 +335,9 @@ void sh_destroy(sh_ctx *c)
     hipSetDevice(c->device);
     free_ws(c);
     if (c->h_nkeep) hipHostFree(c->h_nkeep);
+    if (c->h_af_cnt) hipHostFree(c->h_af_cnt);
+    if (c->af_ev) hipEventDestroy(c->af_ev);
+    hipFree(c->af_rep); hipFree(c->af_slot); hipFree(c->af_cnt); hipFree(c->af_bits); hipFree(c->af_out); hipFree(c->af_flags);
     if (c->keep_ev) hipEventDestroy(c->keep_ev);
     hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_tab);
     hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);

@@ -586,9 +586,14 @@ __global__ __launch_bounds__(256) void k_af_keep(int64_t V, int N, const int *__
                                                  int *__restrict__ idx, int *__restrict__ n)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
-    const double af = (double)m[v] / (double)N;
-    if (min_af <= af && af <= max_af) idx[atomicAdd(n, 1)] = (int)v;      // any order: results are per variant and scattered back
+    const int lane = threadIdx.x & 63;
+    bool keep = false;
+    if (v < V) { const double af = (double)m[v] / (double)N; keep = (min_af <= af && af <= max_af); }
+    const unsigned long long km = __ballot(keep);                          // one atomic per wavefront, not per variant
+    int base = 0;
+    if (lane == 0 && km) base = atomicAdd(n, __popcll(km));
+    base = __shfl(base, 0);
+    if (keep) idx[base + __popcll(km & ((1ull << lane) - 1ull))] = (int)v;   // any order of wavefronts: results are scattered back
 }
 
 __global__ __launch_bounds__(256) void k_gather_T(const uint64_t *__restrict__ T, int64_t Vpad, uint64_t *__restrict__ T2, int64_t Vpad2,

@@ -398,3 +398,42 @@ def test_firth_long_iterations_finish_in_the_workgroup_kernel():
     for f in ("intercept", "kbeta", "bse"):
         close(r[f], want[f], rtol=2e-6, atol=1e-6, what=f)
     close(r["betas"], want["betas"], rtol=2e-6, atol=1e-6, what="betas")
+
+
+@pytest.mark.parametrize("cont,dedup", [(False, False), (False, True), (True, False)])
+def test_af_compaction_changes_nothing(cont, dedup, monkeypatch):
+    """Rows outside the AF window all give the same output; when >= 3 % of a batch is such rows only the kept ones (plus one
+    representative) go through the kernels.  Bit-identical outputs with the compaction forced, off, and adaptive; oracle on the rest."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(4242)
+    N, q, V = 400, 3, 2600
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.2 + W[:, 0]
+    y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    K = (rng.random((V, N)) < rng.uniform(0.05, 0.95, (V, 1))).astype(np.uint8)
+    rare = rng.random(V) < 0.45
+    K[rare] = (rng.random((int(rare.sum()), N)) < 0.003).astype(np.uint8)
+    K[5] = K[6]                                                     # a duplicated pattern for the de-duplication inside
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, cont).llf; nf = np.nan if cont else fit_null(y, W, e0, False, firth=True)
+    bits = pack_variants(K)
+    res = []
+    for mode in ("2", "0", "1"):
+        monkeypatch.setenv("SEERHIP_AFCOMPACT", mode)
+        e = Engine(N); e.set_af_filter(0.01, 0.99); e.set_dedup(dedup)
+        e.glm_setup(y, W, cont, nl, nf)
+        res.append(e.glm_batch(bits)); res.append(e.glm_batch(bits)); e.close()
+    for other in res[1:]:
+        for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas"):
+            assert np.array_equal(res[0][f], other[f], equal_nan=True), f
+        assert np.array_equal(res[0]["flags"], other["flags"])
+    af = K.mean(axis=1); kept = (af >= 0.01) & (af <= 0.99)
+    assert (~kept).sum() > 0.3 * V
+    assert ((res[0]["flags"][~kept] & 0x101FF) == 0x10001).all() and np.isnan(res[0]["pvalue"][~kept]).all() and np.isnan(res[0]["prep"][~kept]).all()
+    want = orc.fixed_effects_batch(y, K[kept].astype(float), W, cont, 1.0, 1.0, nl, nf)
+    firth = (want["notes"] & 0x7C) != 0
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(res[0][f][kept][~firth], want[f][~firth], rtol=1e-6, atol=1e-12, what=f)
+    assert ((res[0]["flags"][kept] & 0x1FF) == want["notes"]).all()
