@@ -3,7 +3,7 @@
  *
  * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP engine in
  * pyseer_amd/csrc/.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
- * leg may load it; the product path (pyseer_amd/*) never imports, links or calls it.
+ * leg may load it; the product path (everything under pyseer_amd/) never imports, links or calls it.
  *
  * Parity status: PINNED.  Every function below is checked (tests/test_oracle_golden.py)
  * against vectors produced by importing the reference itself (tests/golden/make_golden.py,
@@ -738,7 +738,8 @@ ORC_API void orc_firth_batch(const double *y, const double *Kv, const double *Z,
         double *X = (double *)malloc(sizeof(double) * (size_t)n * pc);
         for (int i = 0; i < n; i++) { X[(size_t)i * pc] = 1.0; X[(size_t)i * pc + 1] = Kv[(size_t)v * n + i]; for (int a = 0; a < q; a++) X[(size_t)i * pc + 2 + a] = Z[(size_t)i * q + a]; }
         double start[64], beta[64], b1, fitll;
-        for (int a = 0; a < pc; a++) start[a] = 0; start[0] = log(mean / (1 - mean));
+        for (int a = 0; a < pc; a++) start[a] = 0;
+        start[0] = log(mean / (1 - mean));
         int st = orc_fit_firth(X, y, n, pc, start, 1000, 1e-4, beta, &b1, &fitll);
         status[v] = st;
         for (int a = 0; a < 4; a++) out4[(size_t)v * 4 + a] = NAN;
