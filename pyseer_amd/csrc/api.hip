@@ -11,11 +11,7 @@
 #include <algorithm>
 
 // ---- kernel launchers (lmm_kernels.hip / glm_kernels.hip) -----------------------------------------------------
-struct LmmLinOut { int *t11, *t01, *m; double *xky, *dg, *rss, *s1, *q1; };
-struct LmmFinParams {
-    int N, D, continuous; int n1, n0; double yc_sum, yc_sq; double yKy, inv_scale; double pret, lrtt;
-    double min_af, max_af; int af_on;
-};
+#include "lmm_params.h"
 extern "C" {
 hipError_t shk_sim_accumulate(hipStream_t st, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64, double min_af, double max_af,
                               int af_on, uint64_t *keep, uint64_t *S, int NS, unsigned long long *Kacc);

@@ -5,17 +5,7 @@
 
 __host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, i >= j
 
-struct GlmParams {
-    int N, NB64, continuous, force_firth;
-    int n1, n0;                   // #(y==1), #(y==0)
-    double ymean_logit;           // log(mean(y)/(1-mean(y)))   model.py:323-324
-    double yc_sum, yc_sq;         // centred-phenotype sums (Welch prefilter)
-    double null_llf, null_firth, pret, lrtt;
-    double min_af, max_af; int af_on;
-    int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
-    const float *zz;              // per-sample products table for fast_pass_mfma (FastCols<Q>::STRIDE floats per sample), or null
-    int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
-};
+#include "glm_params.h"
 
 __device__ __forceinline__ double logit_cdf(double x) { return 1.0 / (1.0 + exp(-x)); }    // SM Logit.cdf
 

@@ -1,0 +1,15 @@
+// glm_params.h -- the per-run constants of the fixed-effects kernels: one definition for the kernels (glm_common.h) and the host side
+// (glm_api.inc), which pass it by value across the launcher boundary
+#pragma once
+
+struct GlmParams {
+    int N, NB64, continuous, force_firth;
+    int n1, n0;                   // #(y==1), #(y==0)
+    double ymean_logit;           // log(mean(y)/(1-mean(y)))   model.py:323-324
+    double yc_sum, yc_sq;         // centred-phenotype sums (Welch prefilter)
+    double null_llf, null_firth, pret, lrtt;
+    double min_af, max_af; int af_on;
+    int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
+    const float *zz;              // per-sample products table for fast_pass_mfma (FastCols<Q>::STRIDE floats per sample), or null
+    int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
+};

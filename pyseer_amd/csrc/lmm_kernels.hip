@@ -12,6 +12,7 @@
 // x is exactly representable in int8, and G is held as L balanced base-256 int8 limbs of a fixed-point number, so the
 // contraction runs on v_mfma_i32_32x32x32_i8 with EXACT int32 accumulation; limbs are recombined in fp64.
 #include "common.h"
+#include "lmm_params.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -80,10 +81,6 @@ __global__ __launch_bounds__(256) void k_repack_bits(const uint8_t *__restrict__
 // per-sample constants arrive through the scalar cache.
 //   Qb: N x DP row-major orthonormal basis of the covariate space (only when D > 1; DP = D padded), else DP = 0.
 // ---------------------------------------------------------------------------------------------
-struct LmmLinOut {
-    int *t11, *t01, *m;          // Vpad each
-    double *xky, *dg, *rss, *s1, *q1;
-};
 
 template <int DP>
 __global__ __launch_bounds__(256) void k_lmm_linear(const uint64_t *__restrict__ T, int64_t Vpad, int N, int NB64,
@@ -525,14 +522,6 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
 // ---------------------------------------------------------------------------------------------
 // Per-variant finalisation: a1 prefilter + A5 statistics + a7 filters (pyseer/lmm.py:160-217, 244-258).
 // ---------------------------------------------------------------------------------------------
-struct LmmFinParams {
-    int N, D, continuous;
-    int n1, n0;                 // #(y == 1), #(y == 0)   (binary prefilter margins)
-    double yc_sum, yc_sq;       // sum / sum of squares of the centred phenotype (Welch, group 0 by subtraction)
-    double yKy, inv_scale;
-    double pret, lrtt;
-    double min_af, max_af; int af_on;
-};
 
 __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, int nq, LmmLinOut li, const double *__restrict__ q,
                                                       LmmFinParams P, double *__restrict__ out, uint32_t *__restrict__ flags)
