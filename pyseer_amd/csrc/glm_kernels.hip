@@ -454,6 +454,10 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
     bool need_slow = want_fit && (P.newton_mode == 1);
     bool active = want_fit && !need_slow;
     int it = 0, pass = 0;
+    // Newton's iteration is affine invariant, so this phase runs on covariates standardised per column (Wf and the products table
+    // are built from them too): a column like "year of isolation" (2000 +- 10) would otherwise defeat the fp32 Hessian and send every
+    // variant to the fp64 restart.  Same start vector (the slopes start at 0), same fixed point; beta is mapped back at the end.
+    const double *__restrict__ Wx = P.ws ? P.ws : W;
     __shared__ float tr[FastCols<Q>::LDS_FLOATS];
     while (__any(active)) {
         float Hf[PC * (PC + 1) / 2];
@@ -463,12 +467,12 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
         // step count is the wavefront's pass count); a lane cannot be declared converged by such a pass.
         const bool f32 = pass < P.f32_steps;
         if (P.zz) {
-            if (f32) fast_pass_mfma<Q, true>(T, Vpad, vr, N, NB64, y, W, Wf, P.zz, beta, Hf, g, maxdev, tr);
-            else fast_pass_mfma<Q, false>(T, Vpad, vr, N, NB64, y, W, Wf, P.zz, beta, Hf, g, maxdev, tr);
+            if (f32) fast_pass_mfma<Q, true>(T, Vpad, vr, N, NB64, y, Wx, Wf, P.zz, beta, Hf, g, maxdev, tr);
+            else fast_pass_mfma<Q, false>(T, Vpad, vr, N, NB64, y, Wx, Wf, P.zz, beta, Hf, g, maxdev, tr);
         }
         ++pass;
         if (active) {
-            if (!P.zz) fast_pass<Q>(T, Vpad, vr, N, NB64, y, W, Wf, beta, Hf, g, maxdev);
+            if (!P.zz) fast_pass<Q>(T, Vpad, vr, N, NB64, y, Wx, Wf, beta, Hf, g, maxdev);
             if (it > 0 && maxdev <= 1e-8) { need_slow = true; active = false; }
             else {
                 double A[PC * (PC + 1) / 2];
@@ -498,6 +502,10 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
     flags[v] = fl;
     wk.state[v] = (want_fit && !need_slow) ? 1 : 0;
     if (want_fit && !need_slow) {
+        if (P.ws) {                                                  // z' = (z - mean) / scale  =>  b = b' / scale, b0 = b0' - sum b' mean / scale
+#pragma unroll
+            for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
+        }
 #pragma unroll
         for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
     }

@@ -11,5 +11,7 @@ struct GlmParams {
     double min_af, max_af; int af_on;
     int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
     const float *zz;              // per-sample products table for fast_pass_mfma (FastCols<Q>::STRIDE floats per sample), or null
+    const double *ws;             // N x q covariates standardised per column (the fast Newton path iterates in these coordinates), or null
+    const double *wstd;           // [2q] column means, then column scales, of that standardisation
     int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
 };

@@ -385,13 +385,52 @@ __global__ __launch_bounds__(64) void k_glm_wide_ols(const uint64_t *__restrict_
             }
         }
     }
+    // Full-rank designs (the rule): solve the normal equations on the equilibrated matrix D A D, D = diag(A)^-1/2, by pivoted LU.
+    // Equilibration matters: with an un-centred column such as a year (2000 +- 10) next to a 1e-2-sized one the eigenvalues of A span
+    // more than the 1e-10 window of the pinv path below, which would then drop a genuine direction.  Rank-deficient designs (a
+    // pivot of the equilibrated matrix below 1e-11: exact collinearity) keep numpy's pinv semantics.
     int rank = pc;
-    w_pinv(A, Pm, pc, 1e-10, &rank);                       // see k_glm_ols_pinv for the cut-off
+    double p11 = 0.0;
+    bool solved = false;
+    {
+        double *E = Pm;                                    // scratch: the equilibrated copy
+        double d[WIDE_PM];
+        int piv[WIDE_PM];
+        bool okd = true;
 #pragma unroll 1
-    for (int a = 0; a < pc; ++a) { double s = 0.0;
+        for (int a = 0; a < pc; ++a) { okd = okd && (A[a * pc + a] > 0.0); d[a] = 1.0 / sqrt(A[a * pc + a]); }
+        if (okd) {
 #pragma unroll 1
-        for (int c = 0; c < pc; ++c) s = fma(Pm[a * pc + c], rhs[c], s);
-        beta[a] = s; }
+            for (int a = 0; a < pc; ++a)
+#pragma unroll 1
+                for (int c = 0; c < pc; ++c) E[a * pc + c] = A[a * pc + c] * d[a] * d[c];
+            bool full = w_lu(E, piv, pc) != 0.0;
+#pragma unroll 1
+            for (int a = 0; a < pc && full; ++a) full = fabs(E[a * pc + a]) > 1e-11;
+            if (full) {
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) beta[a] = rhs[a] * d[a];
+                w_lu_solve(E, piv, pc, beta);
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) beta[a] *= d[a];
+                double e1[WIDE_PM];
+#pragma unroll 1
+                for (int a = 0; a < pc; ++a) e1[a] = (a == 1) ? 1.0 : 0.0;
+                w_lu_solve(E, piv, pc, e1);
+                p11 = e1[1] * d[1] * d[1];                 // ((X^T X)^-1)_11
+                solved = true;
+            }
+        }
+    }
+    if (!solved) {
+        w_pinv(A, Pm, pc, 1e-10, &rank);                   // see k_glm_ols_pinv for the cut-off
+#pragma unroll 1
+        for (int a = 0; a < pc; ++a) { double s = 0.0;
+#pragma unroll 1
+            for (int c = 0; c < pc; ++c) s = fma(Pm[a * pc + c], rhs[c], s);
+            beta[a] = s; }
+        p11 = Pm[pc + 1];
+    }
     double ssr = 0.0;
 #pragma unroll 1
     for (int sb = 0; sb < NB64; ++sb) {
@@ -408,7 +447,7 @@ __global__ __launch_bounds__(64) void k_glm_wide_ols(const uint64_t *__restrict_
         }
     }
     const double dfr = (double)(N - rank);
-    const double kbse = sqrt(ssr / dfr * Pm[pc + 1]);
+    const double kbse = sqrt(ssr / dfr * p11);
     const double pval = sh_t_sf2(beta[1] / kbse, dfr);
     uint32_t fl = flags[v];
     if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;

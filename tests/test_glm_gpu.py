@@ -297,7 +297,7 @@ def test_wide_designs_vs_oracle(N, q, cont):
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
 
 
-@pytest.mark.parametrize("N,q,cont", [(400, 17, False), (400, 17, True), (300, 6, False), (600, 24, False)])
+@pytest.mark.parametrize("N,q,cont", [(400, 17, False), (400, 17, True), (300, 6, False), (300, 6, True), (600, 24, False)])
 def test_unscaled_covariates_vs_oracle(N, q, cont):
     """Covariates on very different scales and far from zero mean (age in years next to a 0/1 flag next to a 1e-2-sized principal
     component): the information matrix is badly scaled, so the pivoted LU of the run-time-width kernels really interchanges rows
@@ -310,6 +310,7 @@ def test_unscaled_covariates_vs_oracle(N, q, cont):
     scale = 10.0 ** rng.uniform(-2.0, 1.7, q); shift = rng.uniform(-2, 2, q) * scale
     W = Z * scale + shift
     W[:, q - 1] = (rng.random(N) < 0.3).astype(float)                                  # a 0/1 covariate
+    W[:, q - 2] = 2000.0 + np.round(8.0 * Z[:, q - 2])                                 # year of isolation: far from zero, small spread
     eta = -0.3 + 1.0 * Z[:, 0] - 0.7 * Z[:, 1]
     y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
     V = 80
@@ -327,7 +328,9 @@ def test_unscaled_covariates_vs_oracle(N, q, cont):
     firth = (want["notes"] & 0x7C) != 0
     for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
         close(r[f][~firth], want[f][~firth], rtol=1e-6, atol=1e-12, what=f)
-        close(r[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
+        # Firth rows: the un-centred year column puts cond(X^T W X) at ~1e11, so every solve with it carries ~1e-5 of rounding in
+        # either implementation (numpy's pinv in the reference included); those rows agree to that level, not to 1e-6
+        close(r[f][firth], want[f][firth], rtol=5e-5, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
     close(r["betas"][~firth], want["betas"][~firth], rtol=1e-6, atol=1e-12, what="betas")
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
 

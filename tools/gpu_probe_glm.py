@@ -11,6 +11,8 @@ def run(N, q, V, force_firth, cont=False):
     rng = np.random.default_rng(1002)
     W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
     eta = -0.3 + 1.5 * W[:, 0] - W[:, 1]
+    if os.environ.get("YEARCOL"):                       # an un-centred covariate (e.g. year of isolation): 2000 +- 10
+        W = W.copy(); W[:, 2] = 2000.0 + 10.0 * W[:, 2]
     y = eta + rng.standard_normal(N) if cont else (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
     e0 = np.zeros((0, 0))
     nl = fit_null(y, W, e0, cont).llf
