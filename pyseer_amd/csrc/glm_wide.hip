@@ -362,29 +362,39 @@ __global__ __launch_bounds__(64) void k_glm_wide_ols(const uint64_t *__restrict_
     const int64_t v = list[slot];
     const int pc = q + 2, N = P.N, NB64 = P.NB64;
     double A[WIDE_PM * WIDE_PM], Pm[WIDE_PM * WIDE_PM], rhs[WIDE_PM], beta[WIDE_PM];
-#pragma unroll 1
-    for (int a = 0; a < pc * pc; ++a) A[a] = 0.0;
-#pragma unroll 1
-    for (int a = 0; a < pc; ++a) rhs[a] = 0.0;
+    // X^T X and X^T y: only the variant's row / column depends on the variant (sum x, sum x z_j, sum x y); the [1, W] block is the
+    // per-run Z^T Z, Z^T y from the host (as in k_glm_ols) -- N (q + 1) masked FMAs per variant instead of N (q + 2)^2
+    double sxz[WIDE_PM - 2], sxy = 0.0;
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < WIDE_PM - 2; ++j) sxz[j] = 0.0;
 #pragma unroll 1
     for (int sb = 0; sb < NB64; ++sb) {
         const uint64_t w64 = T[(int64_t)sb * Vpad + v];
         const int nb = min(64, N - sb * 64);
+        m += __popcll(w64);
 #pragma unroll 1
         for (int b = 0; b < nb; ++b) {
             const int i = sb * 64 + b;
-            double x[WIDE_PM];
-            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
-#pragma unroll 1
-            for (int j = 0; j < q; ++j) x[2 + j] = W[(int64_t)i * q + j];
-#pragma unroll 1
-            for (int a = 0; a < pc; ++a) {
-                rhs[a] = fma(x[a], y[i], rhs[a]);
-#pragma unroll 1
-                for (int c = 0; c < pc; ++c) A[a * pc + c] = fma(x[a], x[c], A[a * pc + c]);
-            }
+            const double xd = (double)(unsigned)((w64 >> b) & 1ull);
+            sxy = fma(xd, y[i], sxy);
+#pragma unroll
+            for (int j = 0; j < WIDE_PM - 2; ++j) if (j < q) sxz[j] = fma(xd, W[(int64_t)i * q + j], sxz[j]);
         }
     }
+    A[0] = P.ztz[0]; A[1] = (double)m; A[pc] = (double)m; A[pc + 1] = (double)m;
+    rhs[0] = P.zty[0]; rhs[1] = sxy;
+#pragma unroll
+    for (int j = 0; j < WIDE_PM - 2; ++j) {
+        if (j < q) {
+            const double z0 = P.ztz[sidx(1 + j, 0)];
+            A[(2 + j) * pc] = z0; A[2 + j] = z0; A[(2 + j) * pc + 1] = sxz[j]; A[pc + 2 + j] = sxz[j]; rhs[2 + j] = P.zty[1 + j];
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < q; ++j)
+#pragma unroll 1
+        for (int k = 0; k <= j; ++k) { const double t = P.ztz[sidx(1 + j, 1 + k)]; A[(2 + j) * pc + 2 + k] = t; A[(2 + k) * pc + 2 + j] = t; }
     // Full-rank designs (the rule): solve the normal equations on the equilibrated matrix D A D, D = diag(A)^-1/2, by pivoted LU.
     // Equilibration matters: with an un-centred column such as a year (2000 +- 10) next to a 1e-2-sized one the eigenvalues of A span
     // more than the 1e-10 window of the pinv path below, which would then drop a genuine direction.  Rank-deficient designs (a
