@@ -7,6 +7,7 @@
 // 35 iterations, separation callback, final un-ridged inverse), fit_firth with numpy's pinv, OLS through pinv.  Same notes,
 // same filters, same outputs; throughput is that of scratch memory, not of registers (they exist so that a wide design runs
 // at all: the reference manages ~100 variants/s/core on them).
+#include <algorithm>
 #include "glm_common.h"
 
 #define WIDE_PM 34
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T,
                                                  const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
                                                  const double *__restrict__ yc, GlmParams P, double *__restrict__ out,
                                                  uint32_t *__restrict__ flags, int *__restrict__ firth_list,
-                                                 int *__restrict__ firth_count, int *__restrict__ ols_list, int *__restrict__ ols_count)
+                                                 int *__restrict__ firth_count, int *__restrict__ ols_list, int *__restrict__ ols_count,
+                                                 int *__restrict__ newton_list, int *__restrict__ newton_count)
 {
     const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (v >= V) return;
@@ -189,6 +191,11 @@ __global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T,
         return;
     }
     if (want_fit && (bad || P.force_firth)) { to_firth = true; want_fit = false; }
+    if (want_fit && newton_list) {                                     // fitted by k_glm_wide_newton_blk, one workgroup per variant
+        flags[v] = fl;
+        newton_list[atomicAdd(newton_count, 1)] = (int)v;
+        return;
+    }
     if (want_fit) {
         double beta[WIDE_PM], g[WIDE_PM], I[WIDE_PM * WIDE_PM];
         int piv[WIDE_PM];
@@ -251,6 +258,164 @@ __global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T,
     }
     flags[v] = fl;
     if (to_firth) { const int s = atomicAdd(firth_count, 1); firth_list[s] = (int)v; }
+}
+
+// ---- kernel 1b: the Newton fit of kernel 1, one workgroup per variant --------------------------------------------------------------
+// A lane cannot hold a 34 x 34 information matrix in registers, and one lane updating it in scratch memory for every sample ran at
+// 1.5-7 k variants/s.  Here 256 threads share one variant: samples are taken 128 at a time -- thread t evaluates sample t of the chunk
+// (eta, mu, weight, residual) and stores its design row and weight in LDS -- and the matrix is accumulated in 3 x 3 register tiles:
+// thread (group g, tile (ta, tc)) adds the samples g, g+G, ... of the chunk to its tile, G = 256 / #tiles groups working on disjoint
+// samples.  Partial tiles are summed in a fixed order, thread 0 does the p x p algebra with the same decisions as kernel 1.
+#define WB_CH 128
+#define WB_XS 37
+__global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
+                                                             const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                             const int *__restrict__ nlist, const int *__restrict__ ncount,
+                                                             double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                             int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    __shared__ double xs[WB_CH * WB_XS], wch[WB_CH], rch[WB_CH], s_beta[WIDE_PM + 2], s_g[WIDE_PM + 2], s_H[WIDE_PM * WIDE_PM];
+    __shared__ double s_red[256 * 9], s_sc[8];
+    __shared__ int s_ctl;                                          // 0 = iterate, 1 = evaluate at the final beta, 2 = done
+    const int pc = q + 2, N = P.N, tid = threadIdx.x;
+    const int NT = (pc + 2) / 3, NTT = NT * (NT + 1) / 2, G = 256 / NTT;
+    const int grp = tid / NTT, tile = tid - grp * NTT;
+    const bool tiler = grp < G;
+    int ta = 0; { int t = tile; while (t >= ta + 1) { t -= ta + 1; ++ta; } }
+    int tc = tile - ta * (ta + 1) / 2;
+    const double nobs = (double)N;
+    const int cnt = *ncount;
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const int64_t v = nlist[slot];
+        // thread-0 state
+        int it = 0, status = 0;
+        __syncthreads();
+        if (tid < WIDE_PM + 2) s_beta[tid] = (tid == 0) ? P.ymean_logit : 0.0;         // model.py:323-324
+        if (tid == 0) s_ctl = 0;
+        __syncthreads();
+        for (;;) {
+            // ---- one pass over the samples at s_beta: X^T W X, score, log-likelihood, max |y - mu|
+            double acc[9], gacc = 0.0, sc[2] = {0.0, 0.0};                              // sc: log-likelihood, max deviation
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+            for (int c0 = 0; c0 < N; c0 += WB_CH) {
+                if (tid < WB_CH) {
+                    const int i = c0 + tid;
+                    double *row = xs + tid * WB_XS;
+                    if (i < N) {
+                        const double xb = (double)(unsigned)((T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+                        row[0] = 1.0; row[1] = xb;
+                        double eta = fma(s_beta[1], xb, s_beta[0]);
+#pragma unroll 1
+                        for (int j = 0; j < q; ++j) { const double z = W[(int64_t)i * q + j]; row[2 + j] = z; eta = fma(s_beta[2 + j], z, eta); }
+#pragma unroll 1
+                        for (int a = pc; a < 3 * NT; ++a) row[a] = 0.0;
+                        const double mu = logit_cdf(eta), yi = y[i], r = yi - mu;
+                        wch[tid] = mu * (1.0 - mu); rch[tid] = r;
+                        sc[1] = fmax(sc[1], fabs(r));
+                        const double lm = log(mu);
+                        sc[0] += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                    } else {
+#pragma unroll 1
+                        for (int a = 0; a < 3 * NT; ++a) row[a] = 0.0;
+                        wch[tid] = 0.0; rch[tid] = 0.0;
+                    }
+                }
+                __syncthreads();
+                if (tiler) {
+                    for (int ii = grp; ii < WB_CH; ii += G) {
+                        const double *row = xs + ii * WB_XS;
+                        const double w = wch[ii];
+                        const double a0 = w * row[3 * ta], a1 = w * row[3 * ta + 1], a2 = w * row[3 * ta + 2];
+                        const double c0v = row[3 * tc], c1v = row[3 * tc + 1], c2v = row[3 * tc + 2];
+                        acc[0] = fma(a0, c0v, acc[0]); acc[1] = fma(a0, c1v, acc[1]); acc[2] = fma(a0, c2v, acc[2]);
+                        acc[3] = fma(a1, c0v, acc[3]); acc[4] = fma(a1, c1v, acc[4]); acc[5] = fma(a1, c2v, acc[5]);
+                        acc[6] = fma(a2, c0v, acc[6]); acc[7] = fma(a2, c1v, acc[7]); acc[8] = fma(a2, c2v, acc[8]);
+                    }
+                }
+                if (tid < pc) {
+                    for (int ii = 0; ii < WB_CH; ++ii) gacc = fma(rch[ii], xs[ii * WB_XS + tid], gacc);
+                }
+                __syncthreads();
+            }
+            // ---- combine: tiles over the groups (fixed order), the two scalars over the 128 evaluating threads
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_red[tid * 9 + k] = acc[k];
+            if (tid < pc) s_g[tid] = gacc;
+            __syncthreads();
+            for (int e = tid; e < NTT * 9; e += 256) {
+                const int tl = e / 9, k = e - tl * 9;
+                double t = 0.0;
+                for (int gq = 0; gq < G; ++gq) t += s_red[(gq * NTT + tl) * 9 + k];
+                int ra = 0; { int u = tl; while (u >= ra + 1) { u -= ra + 1; ++ra; } }
+                const int rc = tl - ra * (ra + 1) / 2;
+                const int a = 3 * ra + k / 3, c = 3 * rc + k % 3;
+                if (a < pc && c <= a) { s_H[a * pc + c] = t; s_H[c * pc + a] = t; }     // diagonal tiles: the lower entry defines both
+            }
+            __syncthreads();
+            if (tid < WB_CH) { s_red[tid] = sc[0]; s_red[WB_CH + tid] = sc[1]; }
+            __syncthreads();
+            if (tid == 0) {
+                double ll = 0.0, maxdev = 0.0;
+                for (int k = 0; k < WB_CH; ++k) { ll += s_red[k]; maxdev = fmax(maxdev, s_red[WB_CH + k]); }
+                double *I = s_H, *g = s_g;
+                int piv[WIDE_PM];
+                if (s_ctl == 0) {                                                      // a Newton step (the loop of kernel 1)
+                    if (it > 0 && maxdev <= 1e-8) { status = 1; s_ctl = 2; }           // _check_perfect_pred
+                    else {
+                        for (int a = 0; a < pc * pc; ++a) I[a] = I[a] / nobs;
+                        for (int a = 0; a < pc; ++a) { I[a * pc + a] -= 1e-10; g[a] = g[a] / nobs; }
+                        if (w_lu(I, piv, pc) == 0.0) { status = 2; s_ctl = 2; }
+                        else {
+                            w_lu_solve(I, piv, pc, g);
+                            bool moving = false;
+                            for (int a = 0; a < pc; ++a) { s_beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
+                            ++it;
+                            if (!moving || it >= 35) s_ctl = 1;
+                        }
+                    }
+                } else {                                                               // results at the final beta
+                    double bse1 = NAN, llf = NAN;
+                    if (maxdev <= 1e-8) status = 1;                                    // callback after the last update
+                    else {
+                        llf = ll;
+                        double amax = 0.0;
+                        for (int a = 0; a < pc * pc; ++a) { I[a] = I[a] / nobs; amax = fmax(amax, fabs(I[a])); }
+                        const double det = w_lu(I, piv, pc);
+                        bool tiny = det == 0.0;
+                        for (int a = 0; a < pc && !tiny; ++a) tiny = fabs(I[a * pc + a]) <= 4.0e-16 * amax;
+                        if (tiny) status = 2;
+                        else {
+                            for (int a = 0; a < pc; ++a) g[a] = (a == 1) ? 1.0 : 0.0;
+                            w_lu_solve(I, piv, pc, g);
+                            bse1 = sqrt(g[1] / nobs);
+                        }
+                    }
+                    s_sc[0] = bse1; s_sc[1] = llf;
+                    s_ctl = 2;
+                }
+            }
+            __syncthreads();
+            if (s_ctl == 2) break;
+        }
+        if (tid == 0) {
+            uint32_t fl = flags[v];
+            bool to_firth = false;
+            const double bse1 = s_sc[0], llf = s_sc[1];
+            if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }           // model.py:345-352
+            else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
+            else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }          // model.py:332-334
+            else {
+                const double lrstat = -2.0 * (P.null_llf - llf);
+                double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);       // model.py:336-339
+                out[V + v] = pval; out[2 * V + v] = s_beta[1]; out[3 * V + v] = bse1; out[4 * V + v] = s_beta[0];
+                for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = s_beta[2 + j];
+                if (pval > P.lrtt || !isfinite(pval) || !isfinite(s_beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
+            }
+            flags[v] = fl;
+            if (to_firth) { const int s2 = atomicAdd(firth_count, 1); firth_list[s2] = (int)v; }
+        }
+    }
 }
 
 // ---- kernel 2: fit_firth (model.py:414-504) with numpy's pinv, for the listed variants ------------------------------------
@@ -555,10 +720,13 @@ extern "C" hipError_t shk_glm_wide_lineage(hipStream_t st, const uint64_t *T, in
 
 extern "C" hipError_t shk_glm_wide(hipStream_t st, int which, int q, const uint64_t *T, int64_t Vpad, int64_t V, const double *y,
                                    const double *W, const uint64_t *y1, const uint64_t *y0, const double *yc, GlmParams P,
-                                   double *out, uint32_t *flags, int *flist, int *fcount, int *olist, int *ocount)
+                                   double *out, uint32_t *flags, int *flist, int *fcount, int *olist, int *ocount, int *nlist, int *ncount)
 {
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
-    if (which == 0) hipLaunchKernelGGL(k_glm_wide, grid, blk, 0, st, T, Vpad, V, q, y, W, y1, y0, yc, P, out, flags, flist, fcount, olist, ocount);
+    if (which == 0) hipLaunchKernelGGL(k_glm_wide, grid, blk, 0, st, T, Vpad, V, q, y, W, y1, y0, yc, P, out, flags, flist, fcount, olist, ocount,
+                                       nlist, ncount);
+    else if (which == 3) hipLaunchKernelGGL(k_glm_wide_newton_blk, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, q, y, W, P,
+                                            nlist, ncount, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_wide_firth, grid, blk, 0, st, T, Vpad, V, q, y, W, P, flist, fcount, out, flags);
     else hipLaunchKernelGGL(k_glm_wide_ols, grid, blk, 0, st, T, Vpad, V, q, y, W, P, olist, ocount, out, flags);
     return hipGetLastError();
