@@ -268,6 +268,56 @@ __global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T,
 // samples.  Partial tiles are summed in a fixed order, thread 0 does the p x p algebra with the same decisions as kernel 1.
 #define WB_CH 128
 #define WB_XS 37
+// pivoted LU of the pc x pc matrix in LDS by the whole workgroup: the same operations on every element as w_lu (one lane), four barriers
+// per pivot instead of ~pc^3/3 dependent LDS round trips on thread 0 (0.5 ms per factorisation at pc = 22).  Returns the determinant
+// (0 when a pivot is exactly zero) in every thread.  ctl: 2 shared ints + 1 shared double of scratch.
+__device__ __forceinline__ double wb_lu(double *A, int *piv, int pc, int tid, int *s_i, double *s_d)
+{
+    if (tid == 0) s_d[0] = 1.0;
+    for (int c = 0; c < pc; ++c) {
+        __syncthreads();
+        if (tid == 0) {
+            int p = c; double best = fabs(A[c * pc + c]);
+            for (int r = c + 1; r < pc; ++r) { const double t = fabs(A[r * pc + c]); if (t > best) { best = t; p = r; } }
+            piv[c] = p; s_i[0] = p;
+        }
+        __syncthreads();
+        const int p = s_i[0];
+        if (p != c && tid < pc) { const double t = A[c * pc + tid]; A[c * pc + tid] = A[p * pc + tid]; A[p * pc + tid] = t; }
+        __syncthreads();
+        const double d = A[c * pc + c];
+        if (tid == 0) s_d[0] = (p != c ? -s_d[0] : s_d[0]) * d;
+        if (d == 0.0) { __syncthreads(); return 0.0; }
+        if (tid > c && tid < pc) A[tid * pc + c] = A[tid * pc + c] / d;
+        __syncthreads();
+        const int w = pc - c - 1;
+        for (int e = tid; e < w * w; e += 256) {
+            const int r = c + 1 + e / w, j = c + 1 + e % w;
+            A[r * pc + j] = fma(-A[r * pc + c], A[c * pc + j], A[r * pc + j]);
+        }
+    }
+    __syncthreads();
+    return s_d[0];
+}
+
+// b <- A^-1 b through that factorisation (b in LDS), column-oriented substitutions by the workgroup
+__device__ __forceinline__ void wb_solve(const double *LU, const int *piv, int pc, double *b, int tid)
+{
+    __syncthreads();
+    if (tid == 0) for (int c = 0; c < pc; ++c) { const int p = piv[c]; if (p != c) { const double t = b[c]; b[c] = b[p]; b[p] = t; } }
+    for (int c = 0; c < pc; ++c) {
+        __syncthreads();
+        if (tid > c && tid < pc) b[tid] = fma(-LU[tid * pc + c], b[c], b[tid]);
+    }
+    for (int c = pc - 1; c >= 0; --c) {
+        __syncthreads();
+        if (tid == 0) b[c] = b[c] / LU[c * pc + c];
+        __syncthreads();
+        if (tid < c) b[tid] = fma(-LU[tid * pc + c], b[c], b[tid]);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
                                                              const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                              const int *__restrict__ nlist, const int *__restrict__ ncount,
@@ -276,7 +326,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__r
 {
     __shared__ double xs[WB_CH * WB_XS], wch[WB_CH], rch[WB_CH], s_beta[WIDE_PM + 2], s_g[WIDE_PM + 2], s_H[WIDE_PM * WIDE_PM];
     __shared__ double s_red[256 * 9], s_sc[8];
-    __shared__ int s_ctl;                                          // 0 = iterate, 1 = evaluate at the final beta, 2 = done
+    __shared__ int s_ctl, s_piv[WIDE_PM], s_i[2];                  // s_ctl: 0 = iterate, 1 = evaluate at the final beta, 2 = done
     const int pc = q + 2, N = P.N, tid = threadIdx.x;
     const int NT = (pc + 2) / 3, NTT = NT * (NT + 1) / 2, G = 256 / NTT;
     const int grp = tid / NTT, tile = tid - grp * NTT;
@@ -287,8 +337,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__r
     const int cnt = *ncount;
     for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
         const int64_t v = nlist[slot];
-        // thread-0 state
-        int it = 0, status = 0;
+        int it = 0, status = 0;                                    // kept identical in every thread
         __syncthreads();
         if (tid < WIDE_PM + 2) s_beta[tid] = (tid == 0) ? P.ymean_logit : 0.0;         // model.py:323-324
         if (tid == 0) s_ctl = 0;
@@ -358,42 +407,50 @@ __global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__r
             if (tid == 0) {
                 double ll = 0.0, maxdev = 0.0;
                 for (int k = 0; k < WB_CH; ++k) { ll += s_red[k]; maxdev = fmax(maxdev, s_red[WB_CH + k]); }
-                double *I = s_H, *g = s_g;
-                int piv[WIDE_PM];
-                if (s_ctl == 0) {                                                      // a Newton step (the loop of kernel 1)
-                    if (it > 0 && maxdev <= 1e-8) { status = 1; s_ctl = 2; }           // _check_perfect_pred
+                s_sc[2] = ll; s_sc[3] = maxdev;
+            }
+            __syncthreads();
+            const double ll = s_sc[2], maxdev = s_sc[3];
+            const int mode = s_ctl;                                                    // block-uniform from here on
+            __syncthreads();
+            if (mode == 0) {                                                           // a Newton step (the loop of kernel 1)
+                if (it > 0 && maxdev <= 1e-8) { status = 1; if (tid == 0) s_ctl = 2; } // _check_perfect_pred
+                else {
+                    for (int e = tid; e < pc * pc; e += 256) s_H[e] = s_H[e] / nobs;
+                    __syncthreads();
+                    if (tid < pc) { s_H[tid * pc + tid] -= 1e-10; s_g[tid] = s_g[tid] / nobs; }
+                    if (wb_lu(s_H, s_piv, pc, tid, s_i, s_sc + 4) == 0.0) { status = 2; if (tid == 0) s_ctl = 2; }
                     else {
-                        for (int a = 0; a < pc * pc; ++a) I[a] = I[a] / nobs;
-                        for (int a = 0; a < pc; ++a) { I[a * pc + a] -= 1e-10; g[a] = g[a] / nobs; }
-                        if (w_lu(I, piv, pc) == 0.0) { status = 2; s_ctl = 2; }
-                        else {
-                            w_lu_solve(I, piv, pc, g);
-                            bool moving = false;
-                            for (int a = 0; a < pc; ++a) { s_beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
-                            ++it;
-                            if (!moving || it >= 35) s_ctl = 1;
-                        }
+                        wb_solve(s_H, s_piv, pc, s_g, tid);
+                        bool moving = false;
+                        for (int a = 0; a < pc; ++a) moving = moving || (fabs(s_g[a]) > 1e-8);
+                        __syncthreads();
+                        if (tid < pc) s_beta[tid] += s_g[tid];
+                        ++it;
+                        if (tid == 0 && (!moving || it >= 35)) s_ctl = 1;
                     }
-                } else {                                                               // results at the final beta
-                    double bse1 = NAN, llf = NAN;
-                    if (maxdev <= 1e-8) status = 1;                                    // callback after the last update
-                    else {
-                        llf = ll;
-                        double amax = 0.0;
-                        for (int a = 0; a < pc * pc; ++a) { I[a] = I[a] / nobs; amax = fmax(amax, fabs(I[a])); }
-                        const double det = w_lu(I, piv, pc);
-                        bool tiny = det == 0.0;
-                        for (int a = 0; a < pc && !tiny; ++a) tiny = fabs(I[a * pc + a]) <= 4.0e-16 * amax;
-                        if (tiny) status = 2;
-                        else {
-                            for (int a = 0; a < pc; ++a) g[a] = (a == 1) ? 1.0 : 0.0;
-                            w_lu_solve(I, piv, pc, g);
-                            bse1 = sqrt(g[1] / nobs);
-                        }
-                    }
-                    s_sc[0] = bse1; s_sc[1] = llf;
-                    s_ctl = 2;
                 }
+            } else {                                                                   // results at the final beta
+                double bse1 = NAN, llf = NAN;
+                if (maxdev <= 1e-8) status = 1;                                        // callback after the last update
+                else {
+                    llf = ll;
+                    for (int e = tid; e < pc * pc; e += 256) s_H[e] = s_H[e] / nobs;
+                    __syncthreads();
+                    double amax = 0.0;
+                    for (int a = 0; a < pc * pc; ++a) amax = fmax(amax, fabs(s_H[a]));
+                    const double det = wb_lu(s_H, s_piv, pc, tid, s_i, s_sc + 4);
+                    bool tiny = det == 0.0;
+                    for (int a = 0; a < pc && !tiny; ++a) tiny = fabs(s_H[a * pc + a]) <= 4.0e-16 * amax;
+                    if (tiny) status = 2;
+                    else {
+                        if (tid < pc) s_g[tid] = (tid == 1) ? 1.0 : 0.0;
+                        wb_solve(s_H, s_piv, pc, s_g, tid);
+                        bse1 = sqrt(s_g[1] / nobs);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) { s_sc[0] = bse1; s_sc[1] = llf; s_ctl = 2; }
             }
             __syncthreads();
             if (s_ctl == 2) break;
