@@ -475,6 +475,208 @@ __global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__r
     }
 }
 
+// ---- kernel 2b: fit_firth by one workgroup per variant (same staging and tiles as kernel 1b) ----------------------------------------------
+// The information matrix is inverted through its LU factors (thread a solves for column a); a variant whose matrix is singular to
+// 1e-12 needs numpy's pinv semantics and is handed to kernel 2 (one lane, Jacobi pinv) through `fallback`.
+__global__ __launch_bounds__(256) void k_glm_wide_firth_blk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
+                                                            const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
+                                                            const int *__restrict__ list, const int *__restrict__ count,
+                                                            double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                            int *__restrict__ fallback, int *__restrict__ fallback_count)
+{
+    __shared__ double xs[WB_CH * WB_XS], wch[WB_CH], rch[WB_CH], s_beta[WIDE_PM + 2], s_cand[WIDE_PM + 2], s_U[WIDE_PM + 2];
+    __shared__ double s_H[WIDE_PM * WIDE_PM], s_L[WIDE_PM * WIDE_PM], s_V[WIDE_PM * WIDE_PM], s_red[256 * 9], s_sc[8];
+    __shared__ int s_piv[WIDE_PM], s_i[2];
+    const int pc = q + 2, N = P.N, tid = threadIdx.x;
+    const int NT = (pc + 2) / 3, NTT = NT * (NT + 1) / 2, G = 256 / NTT;
+    const int grp = tid / NTT, tile = tid - grp * NTT;
+    const bool tiler = grp < G;
+    int ta = 0; { int t = tile; while (t >= ta + 1) { t -= ta + 1; ++ta; } }
+    const int tc = tile - ta * (ta + 1) / 2;
+    const int cnt = *count;
+
+    // I(b) -> s_H (full), log-likelihood -> returned (block-uniform); b in LDS
+    auto info_at = [&](const double *b, int64_t v) -> double {
+        double acc[9], ll = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+        for (int c0 = 0; c0 < N; c0 += WB_CH) {
+            __syncthreads();
+            if (tid < WB_CH) {
+                const int i = c0 + tid;
+                double *row = xs + tid * WB_XS;
+                if (i < N) {
+                    const double xb = (double)(unsigned)((T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+                    row[0] = 1.0; row[1] = xb;
+                    double eta = fma(b[1], xb, b[0]);
+#pragma unroll 1
+                    for (int j = 0; j < q; ++j) { const double z = W[(int64_t)i * q + j]; row[2 + j] = z; eta = fma(b[2 + j], z, eta); }
+#pragma unroll 1
+                    for (int a = pc; a < 3 * NT; ++a) row[a] = 0.0;
+                    const double mu = logit_cdf(eta), yi = y[i];
+                    wch[tid] = mu * (1.0 - mu);
+                    const double lm = log(mu);
+                    ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                } else {
+#pragma unroll 1
+                    for (int a = 0; a < 3 * NT; ++a) row[a] = 0.0;
+                    wch[tid] = 0.0;
+                }
+            }
+            __syncthreads();
+            if (tiler) {
+                for (int ii = grp; ii < WB_CH; ii += G) {
+                    const double *row = xs + ii * WB_XS;
+                    const double w = wch[ii];
+                    const double a0 = w * row[3 * ta], a1 = w * row[3 * ta + 1], a2 = w * row[3 * ta + 2];
+                    const double c0v = row[3 * tc], c1v = row[3 * tc + 1], c2v = row[3 * tc + 2];
+                    acc[0] = fma(a0, c0v, acc[0]); acc[1] = fma(a0, c1v, acc[1]); acc[2] = fma(a0, c2v, acc[2]);
+                    acc[3] = fma(a1, c0v, acc[3]); acc[4] = fma(a1, c1v, acc[4]); acc[5] = fma(a1, c2v, acc[5]);
+                    acc[6] = fma(a2, c0v, acc[6]); acc[7] = fma(a2, c1v, acc[7]); acc[8] = fma(a2, c2v, acc[8]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_red[tid * 9 + k] = acc[k];
+        __syncthreads();
+        for (int e = tid; e < NTT * 9; e += 256) {
+            const int tl = e / 9, k = e - tl * 9;
+            double t = 0.0;
+            for (int gq = 0; gq < G; ++gq) t += s_red[(gq * NTT + tl) * 9 + k];
+            int ra = 0; { int u = tl; while (u >= ra + 1) { u -= ra + 1; ++ra; } }
+            const int rc = tl - ra * (ra + 1) / 2;
+            const int a = 3 * ra + k / 3, c = 3 * rc + k % 3;
+            if (a < pc && c <= a) { s_H[a * pc + c] = t; s_H[c * pc + a] = t; }
+        }
+        __syncthreads();
+        if (tid < WB_CH) s_red[tid] = ll;
+        __syncthreads();
+        if (tid == 0) { double t = 0.0; for (int k = 0; k < WB_CH; ++k) t += s_red[k]; s_sc[2] = t; }
+        __syncthreads();
+        return s_sc[2];
+    };
+    // log det of s_H through a factorisation of a copy (s_L, s_piv stay valid for the inverse); -inf / nan as numpy for det <= 0
+    auto logdet = [&]() -> double {
+        for (int e = tid; e < pc * pc; e += 256) s_L[e] = s_H[e];
+        __syncthreads();
+        return log(wb_lu(s_L, s_piv, pc, tid, s_i, s_sc + 4));
+    };
+
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const int64_t v = list[slot];
+        __syncthreads();
+        if (tid < WIDE_PM + 2) s_beta[tid] = (tid == 0) ? P.ymean_logit : 0.0;
+        __syncthreads();
+        double ll = info_at(s_beta, v);
+        double Fcur = -(ll + 0.5 * logdet());                                          // firth_likelihood, model.py:410-411
+        double i11 = s_H[pc + 1], sn_prev = INFINITY;
+        bool failed = false, conv = false, handed = false;
+        for (int iter = 0; iter < 1000 && !failed && !conv && !handed; ++iter) {
+            // ---- V = I(beta)^-1 from the factors left in s_L by the last logdet (they are those of I(beta))
+            double amax = 0.0, pmin = INFINITY;
+            for (int a = 0; a < pc; ++a) { amax = fmax(amax, fabs(s_H[a * pc + a])); pmin = fmin(pmin, fabs(s_L[a * pc + a])); }
+            if (!(pmin > 1e-12 * amax)) { handed = true; break; }                      // (near-)singular: numpy's pinv semantics, kernel 2
+            __syncthreads();
+            if (tid < pc) {                                                            // column tid of the inverse
+                double col[WIDE_PM];
+                for (int a = 0; a < pc; ++a) col[a] = (a == tid) ? 1.0 : 0.0;
+                for (int c = 0; c < pc; ++c) { const int p = s_piv[c]; if (p != c) { const double t = col[c]; col[c] = col[p]; col[p] = t; } }
+                for (int c = 0; c < pc; ++c) for (int r = c + 1; r < pc; ++r) col[r] = fma(-s_L[r * pc + c], col[c], col[r]);
+                for (int c = pc - 1; c >= 0; --c) {
+                    for (int j = c + 1; j < pc; ++j) col[c] = fma(-s_L[c * pc + j], col[j], col[c]);
+                    col[c] = col[c] / s_L[c * pc + c];
+                }
+                for (int a = 0; a < pc; ++a) s_V[a * pc + tid] = col[a];
+            }
+            __syncthreads();
+            // ---- penalised score at beta: U* = X^T (y - mu + h (1/2 - mu)), h = w x^T V x   (model.py:455-463)
+            double uacc = 0.0;
+            for (int c0 = 0; c0 < N; c0 += WB_CH) {
+                __syncthreads();
+                if (tid < WB_CH) {
+                    const int i = c0 + tid;
+                    double *row = xs + tid * WB_XS;
+                    double res = 0.0;
+                    if (i < N) {
+                        const double xb = (double)(unsigned)((T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+                        row[0] = 1.0; row[1] = xb;
+                        double eta = fma(s_beta[1], xb, s_beta[0]);
+#pragma unroll 1
+                        for (int j = 0; j < q; ++j) { const double z = W[(int64_t)i * q + j]; row[2 + j] = z; eta = fma(s_beta[2 + j], z, eta); }
+                        const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+                        double qf = 0.0;
+#pragma unroll 1
+                        for (int a = 0; a < pc; ++a) {
+                            double t = 0.0;
+#pragma unroll 1
+                            for (int c = 0; c < pc; ++c) t = fma(s_V[a * pc + c], row[c], t);
+                            qf = fma(row[a], t, qf);
+                        }
+                        res = y[i] - mu + wgt * qf * (0.5 - mu);
+                    } else {
+#pragma unroll 1
+                        for (int a = 0; a < pc; ++a) row[a] = 0.0;
+                    }
+                    rch[tid] = res;
+                }
+                __syncthreads();
+                if (tid < pc) for (int ii = 0; ii < WB_CH; ++ii) uacc = fma(rch[ii], xs[ii * WB_XS + tid], uacc);
+            }
+            __syncthreads();
+            if (tid < pc) s_U[tid] = uacc;
+            __syncthreads();
+            if (tid < pc) {
+                double t = 0.0;
+                for (int c = 0; c < pc; ++c) t = fma(s_V[tid * pc + c], s_U[c], t);
+                s_cand[tid] = s_beta[tid] + t;
+            }
+            __syncthreads();
+            // ---- step halving (model.py:465-474)
+            int halvings = 0; double Fcand = 0.0;
+            for (;;) {
+                ll = info_at(s_cand, v);
+                Fcand = -(ll + 0.5 * logdet());
+                double stepmax = 0.0;
+                for (int a = 0; a < pc; ++a) stepmax = fmax(stepmax, fabs(s_cand[a] - s_beta[a]));
+                if (!(Fcand > Fcur) || stepmax < 1e-10) break;                         // noise steps accepted outright, see k_glm_firth
+                __syncthreads();
+                if (tid < pc) s_cand[tid] = s_beta[tid] + 0.5 * (s_cand[tid] - s_beta[tid]);
+                __syncthreads();
+                if (++halvings > 1000) { failed = true; break; }
+            }
+            if (failed) break;
+            double sn = 0.0;
+            for (int a = 0; a < pc; ++a) { const double d = s_cand[a] - s_beta[a]; sn = fma(d, d, sn); }
+            __syncthreads();
+            if (tid < pc) s_beta[tid] = s_cand[tid];
+            __syncthreads();
+            sn = sqrt(sn); Fcur = Fcand; i11 = s_H[pc + 1];
+            if (iter > 0 && sn_prev < 1e-4) conv = true;                               // the PREVIOUS step, model.py:477-479
+            sn_prev = sn;
+        }
+        if (tid == 0) {
+            if (handed) fallback[atomicAdd(fallback_count, 1)] = (int)v;
+            else {
+                if (!conv) failed = true;
+                uint32_t fl = flags[v];
+                if (failed) {
+                    fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                         // model.py:357-362
+                    out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
+                    for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = NAN;
+                } else {
+                    const double lrstat = -2.0 * (P.null_firth - (-Fcur));
+                    double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);   // model.py:366-369
+                    out[V + v] = pval; out[2 * V + v] = s_beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = s_beta[0];
+                    for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = s_beta[2 + j];
+                    if (pval > P.lrtt || !isfinite(pval) || !isfinite(s_beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+                }
+                flags[v] = fl;
+            }
+        }
+    }
+}
+
 // ---- kernel 2: fit_firth (model.py:414-504) with numpy's pinv, for the listed variants ------------------------------------
 __global__ __launch_bounds__(64) void k_glm_wide_firth(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int q,
                                                        const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
@@ -782,6 +984,9 @@ extern "C" hipError_t shk_glm_wide(hipStream_t st, int which, int q, const uint6
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
     if (which == 0) hipLaunchKernelGGL(k_glm_wide, grid, blk, 0, st, T, Vpad, V, q, y, W, y1, y0, yc, P, out, flags, flist, fcount, olist, ocount,
                                        nlist, ncount);
+    else if (which == 4) hipLaunchKernelGGL(k_glm_wide_firth_blk, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, q, y, W, P,
+                                            flist, fcount, out, flags, olist, ocount);
+    else if (which == 5) hipLaunchKernelGGL(k_glm_wide_firth, grid, blk, 0, st, T, Vpad, V, q, y, W, P, olist, ocount, out, flags);
     else if (which == 3) hipLaunchKernelGGL(k_glm_wide_newton_blk, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, q, y, W, P,
                                             nlist, ncount, out, flags, flist, fcount);
     else if (which == 1) hipLaunchKernelGGL(k_glm_wide_firth, grid, blk, 0, st, T, Vpad, V, q, y, W, P, flist, fcount, out, flags);
