@@ -774,12 +774,12 @@ struct FirthWork {
     double *st;                 // [FW_ND(PC)][cap]
     int *iter, *halv, *var;     // [cap] accepted steps (-1 = initial evaluation pending), halvings of the current step, variant index
     int64_t cap;
-    int *blk_list, *blk_count;  // slots handed to k_firth_blk after FIRTH_HANDOFF accepted steps
+    int *blk_list, *blk_count;  // slots handed to k_firth_blk after GlmParams.firth_handoff accepted steps
 };
-// A variant still iterating after this many accepted steps leaves the rounds and is finished by one workgroup (k_firth_blk).
+// A variant still iterating after `firth_handoff` accepted steps leaves the rounds and is finished by one workgroup (k_firth_blk).
 // The rule looks at the variant alone, so which kernel finishes a variant -- and hence the order of its sums -- does not depend
 // on what else is in the batch.  Ordinary variants converge in 5-14 steps; (quasi-)separated ones need hundreds.
-#define FIRTH_HANDOFF 16
+// (GlmParams.firth_handoff: 16, or 0 for the routed variants of an ordinary run at N >= 2048, see sh_glm_setup)
 template <int PC> __host__ __device__ constexpr int fw_beta() { return 0; }
 template <int PC> __host__ __device__ constexpr int fw_cand() { return PC; }
 template <int PC> __host__ __device__ constexpr int fw_fac() { return 2 * PC; }
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
         for (int a = 0; a < PC * (PC + 1) / 2; ++a) fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s] = A[a];
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = Fcand;
         fw.iter[s] = iter; fw.halv[s] = 0;
-        if (iter >= FIRTH_HANDOFF) fw.blk_list[atomicAdd(fw.blk_count, 1)] = s;
+        if (iter >= P.firth_handoff) fw.blk_list[atomicAdd(fw.blk_count, 1)] = s;
         else step_list[atomicAdd(step_count, 1)] = s;
         return;
     }

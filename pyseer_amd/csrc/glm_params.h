@@ -14,5 +14,6 @@ struct GlmParams {
     const double *ws;             // N x q covariates standardised per column (the fast Newton path iterates in these coordinates), or null
     const double *wstd;           // [2q] column means, then column scales, of that standardisation
     const double *ztz, *zty;      // Z^T Z (packed lower, (q+1) x (q+1)) and Z^T y for Z = [1, W]: the variant-independent part of the OLS normal equations
+    int firth_handoff;            // accepted Firth steps after which a variant leaves the rounds for k_firth_blk (SEERHIP_FIRTH_HANDOFF)
     int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
 };
