@@ -440,3 +440,36 @@ def test_af_compaction_changes_nothing(cont, dedup, monkeypatch):
     for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
         close(res[0][f][kept][~firth], want[f][~firth], rtol=1e-6, atol=1e-12, what=f)
     assert ((res[0]["flags"][kept] & 0x1FF) == want["notes"]).all()
+
+
+def test_routed_firth_at_large_n_goes_through_the_workgroup_kernel():
+    """For N >= 2048 the Firth-routed variants of an ordinary run skip the rounds (firth_handoff = 0): k_firth_blk fits them from the
+    first step.  Rare k-mers carried by cases only (bad-chisq, quasi-separated) and by controls only, against the oracle."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(2048)
+    N, q, V = 2500, 4, 160
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    y = (rng.random(N) < 1 / (1 + np.exp(0.4 - W[:, 0]))).astype(float)
+    cases, controls = np.flatnonzero(y == 1), np.flatnonzero(y == 0)
+    K = np.zeros((V, N), dtype=np.uint8)
+    for v in range(V):
+        pool = cases if v % 2 == 0 else controls
+        K[v, rng.choice(pool, int(rng.integers(26, 60)), replace=False)] = 1
+        if v % 5 == 0:
+            K[v, rng.choice(controls if v % 2 == 0 else cases, int(rng.integers(1, 4)), replace=False)] = 1   # not quite separated
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W, False, 1.0, 1.0, nl, nf)
+    routed = (want["notes"] & 0x3C) != 0
+    assert routed.sum() > 0.7 * V
+    e = Engine(N); e.set_af_filter(0.01, 0.99)
+    e.glm_setup(y, W, False, nl, nf)
+    r = e.glm_batch(pack_variants(K))
+    info = e.glm_info(); e.close()
+    assert info["firth_routed"] == int(routed.sum())
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(r[f], want[f], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f)
+    close(r["betas"], want["betas"], rtol=2e-6, atol=1e-6, what="betas")
