@@ -16,7 +16,7 @@ def _close(a, b, rtol=1e-6, atol=0.0):
         (np.abs(a - b) <= atol + rtol * np.abs(b))
 
 
-# FUZZ_SEEDS=n widens the sweep, FUZZ_OFFSET=k starts it at seed k (defaults: 12 seeds from 0)
+# FUZZ_SEEDS=n widens the sweep, FUZZ_OFFSET=k starts it at seed k (defaults: 12 seeds from 0), FUZZ_WIDE=1 draws wide designs only
 _SEEDS = range(int(os.environ.get("FUZZ_OFFSET", 0)), int(os.environ.get("FUZZ_OFFSET", 0)) + int(os.environ.get("FUZZ_SEEDS", 12)))
 
 
@@ -41,6 +41,8 @@ def _fixed_case(seed):
     N = int(rng.choice([40, 63, 64, 65, 100, 128, 129, 250, 300]))
     q = int(rng.choice([0, 1, 2, 3, 5, 8, 11, 14, 16]))
     cont = bool(rng.integers(0, 2))
+    if os.environ.get("FUZZ_WIDE"):                                # FUZZ_WIDE=1: only wide designs (workgroup-per-variant kernels)
+        N = int(rng.choice([250, 300, 640])); q = int(rng.choice([15, 20, 27, 32]))
     V = 72
     W = rng.standard_normal((N, q))
     if q:
@@ -58,6 +60,8 @@ def _firth_case(seed):
     rng = np.random.default_rng(3000 + seed)
     N = int(rng.choice([60, 64, 100, 129, 200, 320]))
     q = int(rng.choice([0, 1, 3, 6, 10, 14, 15]))
+    if os.environ.get("FUZZ_WIDE"):
+        N = int(rng.choice([320, 640])); q = int(rng.choice([15, 20, 27, 32]))
     V = 40
     W = rng.standard_normal((N, q))
     if q:
