@@ -7,6 +7,11 @@ __host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + 
 
 #include "glm_params.h"
 
+// Firth step halving (model.py:467-474): an increase of F within four ulp of F is evaluation noise (F sums N terms), and halving on it is a
+// coin flip in the reference too -- the step is ~1e-7 or smaller by then.  It is not treated as an increase, which saves the rounds that
+// only serviced such flips (case 1).
+#define FIRTH_F_NOISE 8.9e-16
+
 __device__ __forceinline__ double logit_cdf(double x) { return 1.0 / (1.0 + exp(-x)); }    // SM Logit.cdf
 
 // ---- a1 prefilter from the packed bits ------------------------------------------------------------------------------
