@@ -28,6 +28,8 @@ hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int
                            unsigned long long *, int8_t *);
 hipError_t shk_dd_find(hipStream_t, const uint64_t *, int64_t, int64_t, int, uint64_t *, uint64_t, unsigned long long *, int *, int *, int *, int *);
 hipError_t shk_af_rows(hipStream_t, int, const uint8_t *, int64_t, int64_t, int, double, double, int *, int *, int *);
+hipError_t shk_pf_rows(hipStream_t, const uint8_t *, int64_t, int64_t, int, const uint64_t *, const uint64_t *, double, double, int, int, int,
+                       double, int, int *, int *, int *, int *, int *, int *, double *, uint32_t *);
 hipError_t shk_dd_gather(hipStream_t, const uint8_t *, int64_t, int64_t, const int *, const int *, uint8_t *);
 hipError_t shk_dd_scatter(hipStream_t, int64_t, int64_t, int, const int *, const int *, const double *, const uint32_t *, double *, uint32_t *);
 }
@@ -75,6 +77,7 @@ struct sh_ctx {
     uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0;
     // row-level AF compaction of the fixed-effects path (af_wrap): its own buffers, because the wrapped call may de-duplicate
     int *af_rep = nullptr, *af_slot = nullptr, *af_cnt = nullptr, *h_af_cnt = nullptr; int64_t af_capV = 0;
+    int *af_m = nullptr;                                          // [3][af_capV]: carrier count and the two case/control cells of each row
     uint8_t *af_bits = nullptr; double *af_out = nullptr; uint32_t *af_flags = nullptr; int64_t af_cap_bits = 0, af_cap_out = 0;
     hipEvent_t af_ev = nullptr; bool af_pending = false; int64_t af_pending_V = 0; double af_hint = 0.0; int64_t af_last_rows = -1; unsigned af_tick = 0;
     // ---- similarity accumulation (sim_kernels.hip)
@@ -240,16 +243,19 @@ static int dedup_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t 
 
 // Rows outside the AF window all give the same output, so one of them stands for all: only the kept rows (+ that one) go through
 // `inner`.  Same adaptive rule as in lmm_batch_dev_inner: a stream that does not filter is only counted asynchronously.
+struct PrefilterRows { const uint64_t *y1 = nullptr, *y0 = nullptr; int n1 = 0, n0 = 0; double pret = 1.0; };   // binary phenotype, --filter-pvalue < 1
 template <typename F>
-static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags, int nrow, F inner)
+static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags, int nrow, F inner,
+                   PrefilterRows pf = PrefilterRows())
 {
     c->af_last_rows = -1;
-    if (!(c->af_on && c->af_compact) || V < 1024) return inner(d_bits, V, d_out, d_flags);
+    const bool use_pf = pf.y1 != nullptr && pf.pret < 1.0;
+    if (!((c->af_on || use_pf) && c->af_compact) || V < 1024) return inner(d_bits, V, d_out, d_flags);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     if (V > c->af_capV) {
-        hipFree(c->af_rep); hipFree(c->af_slot); c->af_rep = c->af_slot = nullptr;
-        HIPCHK(dmalloc(&c->af_rep, V)); HIPCHK(dmalloc(&c->af_slot, V)); c->af_capV = V;
+        hipFree(c->af_rep); hipFree(c->af_slot); hipFree(c->af_m); c->af_rep = c->af_slot = c->af_m = nullptr;
+        HIPCHK(dmalloc(&c->af_rep, V)); HIPCHK(dmalloc(&c->af_slot, V)); HIPCHK(dmalloc(&c->af_m, 3 * V)); c->af_capV = V;
     }
     if (!c->af_cnt) {
         HIPCHK(dmalloc(&c->af_cnt, 2)); HIPCHK(hipHostMalloc((void **)&c->h_af_cnt, 2 * sizeof(int)));
@@ -264,7 +270,12 @@ static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, 
     if (!c->af_pending && (c->af_hint >= 0.10 || c->af_compact == 2 || (c->af_tick++ & 3) == 0)) {
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->af_cnt, 0, 1, st));
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->af_cnt + 1), 2147483647, 1, st));
-        HIPCHK(shk_af_rows(st, 0, (const uint8_t *)d_bits, row_bytes, V, c->N, c->min_af, c->max_af, c->af_rep, c->af_slot, c->af_cnt));
+        if (use_pf)
+            HIPCHK(shk_pf_rows(st, (const uint8_t *)d_bits, row_bytes, V, c->N, pf.y1, pf.y0, c->min_af, c->max_af, c->af_on, pf.n1, pf.n0, pf.pret, nrow,
+                               c->af_m, c->af_m + c->af_capV, c->af_m + 2 * c->af_capV, c->af_rep, c->af_slot, c->af_cnt, (double *)d_out,
+                               (uint32_t *)d_flags));
+        else
+            HIPCHK(shk_af_rows(st, 0, (const uint8_t *)d_bits, row_bytes, V, c->N, c->min_af, c->max_af, c->af_rep, c->af_slot, c->af_cnt));
         HIPCHK(hipMemcpyAsync(c->h_af_cnt, c->af_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         if (c->af_hint >= 0.10 || c->af_compact == 2) {
             HIPCHK(hipStreamSynchronize(st));
@@ -277,6 +288,7 @@ static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, 
     }
     if (!compact) return inner(d_bits, V, d_out, d_flags);
     const int64_t nu = (int64_t)nk + (R != 2147483647 ? 1 : 0);
+    if (nu == 0) { c->af_last_rows = 0; return SH_OK; }            // every row's output was written by the classification kernel
     if (nu * row_bytes > c->af_cap_bits) { hipFree(c->af_bits); c->af_bits = nullptr; HIPCHK(hipMalloc((void **)&c->af_bits, nu * row_bytes)); c->af_cap_bits = nu * row_bytes; }
     if (nu * nrow > c->af_cap_out) {
         hipFree(c->af_out); hipFree(c->af_flags); c->af_out = nullptr; c->af_flags = nullptr;
@@ -333,7 +345,7 @@ void sh_destroy(sh_ctx *c)
     if (c->h_nkeep) hipHostFree(c->h_nkeep);
     if (c->h_af_cnt) hipHostFree(c->h_af_cnt);
     if (c->af_ev) hipEventDestroy(c->af_ev);
-    hipFree(c->af_rep); hipFree(c->af_slot); hipFree(c->af_cnt); hipFree(c->af_bits); hipFree(c->af_out); hipFree(c->af_flags);
+    hipFree(c->af_rep); hipFree(c->af_slot); hipFree(c->af_m); hipFree(c->af_cnt); hipFree(c->af_bits); hipFree(c->af_out); hipFree(c->af_flags);
     if (c->keep_ev) hipEventDestroy(c->keep_ev);
     hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_tab);
     hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_dd_scatter(int64_t V, int64_t Vu, int n
                                                     uint32_t *__restrict__ flags)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
+    if (v >= V || rep[v] < 0) return;                              // rep < 0: the row's output was written directly (k_pf_slots)
     const int64_t s = slot_of[rep[v]];
     for (int a = 0; a < nrow; ++a) out[(int64_t)a * V + v] = out_u[(int64_t)a * Vu + s];
     flags[v] = flags_u[s];
@@ -145,12 +145,72 @@ __global__ __launch_bounds__(256) void k_af_slots(int64_t V, int N, double min_a
     else rep[v] = -1;
 }
 
+// ---- the same with the binary prefilter (model.py:31-70, 266): a row whose 2x2 chi-square p-value exceeds --filter-pvalue is never
+// fitted; its output (prep, notes, NaN statistics) is written here and only the rows that will be fitted go through the kernels.  With
+// --filter-pvalue 1e-3 that is ~99 % of a batch; inside the regression kernel those rows are idle lanes of wavefronts that still run.
+__global__ __launch_bounds__(256) void k_pf_rows(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V, int N,
+                                                 const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
+                                                 int *__restrict__ m_out, int *__restrict__ t11_out, int *__restrict__ t01_out)
+{
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t *row = bits + v * row_bytes;
+    int m = 0, t11 = 0, t01 = 0;
+    const int nw = (N + 63) >> 6;
+    for (int w = lane; w < nw; w += 64) {
+        uint64_t x = 0;
+        if ((row_bytes & 7) == 0 && ((uintptr_t)bits & 7) == 0) x = reinterpret_cast<const uint64_t *>(row)[w];
+        else for (int b = 0; b < 8 && w * 8 + b < row_bytes; ++b) x |= (uint64_t)row[w * 8 + b] << (8 * b);
+        if (w == nw - 1 && (N & 63)) x &= (1ull << (N & 63)) - 1ull;
+        m += __popcll(x); t11 += __popcll(x & y1[w]); t01 += __popcll(x & y0[w]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m += __shfl_xor(m, o); t11 += __shfl_xor(t11, o); t01 += __shfl_xor(t01, o); }
+    if (lane == 0) { m_out[v] = m; t11_out[v] = t11; t01_out[v] = t01; }
+}
+
+__global__ __launch_bounds__(256) void k_pf_slots(int64_t V, int N, double min_af, double max_af, int af_on, int n1, int n0, double pret,
+                                                  int nrow, const int *__restrict__ m_in, const int *__restrict__ t11_in,
+                                                  const int *__restrict__ t01_in, int *__restrict__ rep, int *__restrict__ slot_of,
+                                                  int *__restrict__ cnt, double *__restrict__ out, uint32_t *__restrict__ flags)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = v < V;
+    int cls = 3;                                                   // 0 keep, 1 AF-filtered, 2 prefilter failed, 3 out of range
+    double prep = NAN; bool bad = false;
+    if (valid) {
+        const int m = m_in[v];
+        const double af = (double)m / (double)N;
+        if (af_on && !(min_af <= af && af <= max_af)) cls = 1;
+        else {
+            const int t11 = t11_in[v], t01 = t01_in[v];
+            prep = sh_prefilter_binary(t11, n1 - t11, t01, n0 - t01, &bad);
+            cls = (prep > pret || !isfinite(prep)) ? 2 : 0;                            // model.py:266 (>)
+        }
+    }
+    const unsigned long long km = __ballot(cls == 0);
+    int base = 0;
+    if (lane == 0 && km) base = atomicAdd(&cnt[0], __popcll(km));
+    base = __shfl(base, 0);
+    if (!valid) return;
+    if (cls == 0) { rep[v] = (int)v; slot_of[v] = base + __popcll(km & ((1ull << lane) - 1ull)); }
+    else {                                                         // never fitted: the output is known here (k_glm_fast writes the same)
+        rep[v] = -2;
+        out[v] = prep;                                             // NaN for an AF-filtered row
+        for (int a = 1; a < nrow; ++a) out[(int64_t)a * V + v] = NAN;
+        flags[v] = (cls == 1) ? (SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER)
+                              : ((bad ? SH_NOTE_BAD_CHISQ : 0u) | SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_af_rep(int64_t V, int *__restrict__ rep, int *__restrict__ slot_of, const int *__restrict__ cnt)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const int R = cnt[1];
-    if (rep[v] < 0) { rep[v] = R; if ((int)v == R) slot_of[v] = cnt[0]; }
+    if (rep[v] == -1) { rep[v] = R; if ((int)v == R) slot_of[v] = cnt[0]; }
 }
 
 extern "C" {
@@ -175,6 +235,16 @@ hipError_t shk_af_rows(hipStream_t st, int which, const uint8_t *bits, int64_t r
         hipLaunchKernelGGL(k_af_rows, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, bits, row_bytes, V, N, min_af, max_af, rep, slot_of, cnt);
         hipLaunchKernelGGL(k_af_slots, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, min_af, max_af, rep, slot_of, cnt);
     } else hipLaunchKernelGGL(k_af_rep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, rep, slot_of, cnt);
+    return hipGetLastError();
+}
+
+hipError_t shk_pf_rows(hipStream_t st, const uint8_t *bits, int64_t row_bytes, int64_t V, int N, const uint64_t *y1, const uint64_t *y0,
+                       double min_af, double max_af, int af_on, int n1, int n0, double pret, int nrow, int *m, int *t11, int *t01,
+                       int *rep, int *slot_of, int *cnt, double *out, uint32_t *flags)
+{
+    hipLaunchKernelGGL(k_pf_rows, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, bits, row_bytes, V, N, y1, y0, m, t11, t01);
+    hipLaunchKernelGGL(k_pf_slots, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, min_af, max_af, af_on, n1, n0, pret, nrow, m, t11, t01,
+                       rep, slot_of, cnt, out, flags);
     return hipGetLastError();
 }
 

@@ -473,3 +473,45 @@ def test_routed_firth_at_large_n_goes_through_the_workgroup_kernel():
     for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
         close(r[f], want[f], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f)
     close(r["betas"], want["betas"], rtol=2e-6, atol=1e-6, what="betas")
+
+
+@pytest.mark.parametrize("dedup", [False, True])
+def test_prefilter_compaction_changes_nothing(dedup, monkeypatch):
+    """--filter-pvalue: rows whose 2x2 chi-square p-value exceeds the threshold are never fitted (model.py:266); their output is written
+    by the classification kernel and only the rows to fit go through the regression kernels.  Bit-identical outputs with the compaction
+    forced, off and adaptive; oracle on everything."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(777)
+    N, q, V, pret = 500, 3, 3000, 0.05
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    y = (rng.random(N) < 1 / (1 + np.exp(0.2 - W[:, 0]))).astype(float)
+    K = (rng.random((V, N)) < rng.uniform(0.03, 0.97, (V, 1))).astype(np.uint8)
+    causal = rng.random(V) < 0.05
+    K[causal] = ((rng.random((int(causal.sum()), N)) < 0.25) | ((y == 1) & (rng.random((int(causal.sum()), N)) < 0.3))).astype(np.uint8)
+    K[::50] = (rng.random((len(K[::50]), N)) < 0.004).astype(np.uint8)             # some AF-filtered rows as well
+    K[7] = K[8]
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    bits = pack_variants(K)
+    res = []
+    for mode in ("2", "0", "1"):
+        monkeypatch.setenv("SEERHIP_AFCOMPACT", mode)
+        e = Engine(N); e.set_af_filter(0.01, 0.99); e.set_dedup(dedup)
+        e.glm_setup(y, W, False, nl, nf, pret, 1.0)
+        res.append(e.glm_batch(bits)); res.append(e.glm_batch(bits)); e.close()
+    for other in res[1:]:
+        for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas"):
+            assert np.array_equal(res[0][f], other[f], equal_nan=True), f
+        assert np.array_equal(res[0]["flags"], other["flags"])
+    af = K.mean(axis=1); in_af = (af >= 0.01) & (af <= 0.99)
+    want = orc.fixed_effects_batch(y, K[in_af].astype(float), W, False, pret, 1.0, nl, nf)
+    got = {f: res[0][f][in_af] for f in ("prep", "pvalue", "kbeta", "bse", "intercept")}
+    assert want["prefilter"].mean() > 0.5 and (want["prefilter"] == 0).sum() > 50          # both kinds of rows are present
+    assert ((res[0]["flags"][in_af] & 0x1FF) == want["notes"]).all()
+    assert (((res[0]["flags"][in_af] >> 16) & 1) == want["prefilter"]).all()
+    firth = (want["notes"] & 0x7C) != 0
+    for f in got:
+        close(got[f][~firth], want[f][~firth], rtol=1e-6, atol=1e-12, what=f)
+        close(got[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")

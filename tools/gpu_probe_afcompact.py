@@ -51,3 +51,19 @@ for frac in (0.0, 0.1, 0.3, 0.6):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
         print("logistic: extra filtered %.0f%%  compaction %s: %.2f ms per %d variants (%.1f M/s)" % (100 * frac, on, dt * 1e3, Vg, Vg / dt / 1e6))
         e.close()
+
+# ---- --filter-pvalue: almost every row fails the prefilter and is never fitted
+for pret in (1.0, 1e-2, 1e-4):
+    for on in ("0", "1"):
+        os.environ["SEERHIP_AFCOMPACT"] = on
+        e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
+        e.glm_setup(yb, W, False, nl, nf, pret, 1.0)
+        b = bits[:Vg]
+        for _ in range(4): e.glm_batch_dev(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): out_, fl_ = e.glm_batch_dev(b)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        pf = float(((fl_ >> 16) & 1).float().mean().item())
+        print("logistic --filter-pvalue %g (%.1f%% prefiltered)  compaction %s: %.2f ms per %d variants (%.1f M/s)" % (pret, 100 * pf, on, dt * 1e3, Vg, Vg / dt / 1e6))
+        e.close()
