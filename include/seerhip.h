@@ -84,6 +84,8 @@ int     sh_set_af_filter(sh_ctx *ctx, double min_af, double max_af);
  * C: n x D row-major covariates with the intercept LAST (lmm.X, pyseer/lmm.py:95-99), h2 (lmm.py:115).
  * continuous selects the prefilter test (model.py:52-55 vs :57-68); pret/lrtt = filter_pvalue/lrt_pvalue
  * (compared with >=, lmm.py:174,201).  n_limbs = 4..7 int8 limbs of the fixed-point kernel matrix (0 = default 5).
+ * With pret < 1 a pre-filtered variant is not fitted and carries NaN statistics (fit_lmm); with pret >= 1 every AF-passing variant
+ * carries its statistics (fit_lmm_block) and masking by the prefilter flag is the caller's.
  * ------------------------------------------------------------------------------------------- */
 int sh_lmm_setup(sh_ctx *ctx, const double *U, const double *S, int k, const double *y,
                  const double *C, int D, double h2, int continuous, double pret, double lrtt, int n_limbs);

@@ -21,7 +21,7 @@ hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, const double *, LmmLinOut);
 hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, const double *, const double *, int, int, int, int, double *);
 hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *);
-hipError_t shk_af_compact(hipStream_t, int, int64_t, int, const int *, double, double, int *, int *, const uint64_t *, int64_t, uint64_t *,
+hipError_t shk_af_compact(hipStream_t, int, int64_t, LmmLinOut, LmmFinParams, int *, int *, const uint64_t *, int64_t, uint64_t *,
                           int64_t, int, int, const double *, double *);
 hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
 hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
@@ -578,7 +578,8 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     // plain path, and a stream that does filter pays the round trip and saves the work.  Results are identical either way.
     int64_t nk = V;
     bool compact = false;
-    if (c->af_on && c->af_compact) {
+    LmmFinParams KP = c->fin; KP.min_af = c->min_af; KP.max_af = c->max_af; KP.af_on = c->af_on;
+    if ((c->af_on || KP.pret < 1.0) && c->af_compact) {
         if (Vpad > c->cap_keep) {
             hipFree(c->d_T2); hipFree(c->d_q2); hipFree(c->d_keep); hipFree(c->d_nkeep);
             c->d_T2 = nullptr; c->d_q2 = nullptr; c->d_keep = c->d_nkeep = nullptr;
@@ -591,7 +592,7 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
         }
         if (!c->keep_pending) {
             HIPCHK(hipMemsetAsync(c->d_nkeep, 0, sizeof(int), st));
-            HIPCHK(shk_af_compact(st, 0, V, c->N, c->d_m, c->min_af, c->max_af, c->d_keep, c->d_nkeep, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr));
+            HIPCHK(shk_af_compact(st, 0, V, lo, KP, c->d_keep, c->d_nkeep, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr));
             HIPCHK(hipMemcpyAsync(c->h_nkeep, c->d_nkeep, sizeof(int), hipMemcpyDeviceToHost, st));
             if (c->filtered_hint >= 0.03 || c->af_compact == 2) {                 // SEERHIP_AFCOMPACT=2: always count (tests)
                 HIPCHK(hipStreamSynchronize(st));
@@ -605,9 +606,9 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     c->last_kept = compact ? nk : -1;
     if (compact && nk > 0) {
         const int64_t Vpad2 = (nk + 511) / 512 * 512;
-        HIPCHK(shk_af_compact(st, 1, V, c->N, nullptr, 0, 0, c->d_keep, nullptr, c->d_T, Vpad, c->d_T2, Vpad2, c->NB64p, (int)nk, nullptr, nullptr));
+        HIPCHK(shk_af_compact(st, 1, V, lo, KP, c->d_keep, nullptr, c->d_T, Vpad, c->d_T2, Vpad2, c->NB64p, (int)nk, nullptr, nullptr));
         HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T2, Vpad2, 2 * c->NT, c->L, lsplit, c->d_q2));
-        HIPCHK(shk_af_compact(st, 2, V, c->N, nullptr, 0, 0, c->d_keep, nullptr, nullptr, Vpad, nullptr, Vpad2, lsplit, (int)nk, c->d_q2, c->d_q));
+        HIPCHK(shk_af_compact(st, 2, V, lo, KP, c->d_keep, nullptr, nullptr, Vpad, nullptr, Vpad2, lsplit, (int)nk, c->d_q2, c->d_q));
     } else if (!compact) {
         HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q));
     }

@@ -548,7 +548,11 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, i
         }
         if (bad) fl |= SH_NOTE_BAD_CHISQ;
         if (prep >= P.pret || !isfinite(prep)) fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER;      // lmm.py:174 (>=)
-        // statistics (computed for every AF-passing variant; masking by flags is the caller's, lmm.py:176-217)
+    }
+    // With a prefilter requested (filter_pvalue < 1) a pre-filtered variant is never fitted (lmm.py:174-185): no statistics, and its quadratic
+    // form is not even computed (k_af_keep).  Without one every AF-passing variant carries its statistics, as fit_lmm_block gives them; the
+    // masking of the rows that only fail `prep >= 1` or have no finite prep is the caller's (lmm.py:176-217).
+    if (go && !((fl & SH_FLAG_PREFILTER) && P.pret < 1.0)) {
         const bool zeroed = sqrt(li.rss[v] / (double)P.N) <= 1e-10;                              // lmm_cov.py:179-181
         double qs = 0.0;
         for (int a = 0; a < nq; ++a) qs += q[(int64_t)a * Vpad + v];          // per-limb-group partial sums, fixed order
@@ -571,13 +575,22 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, i
 
 // ---- AF compaction: the quadratic form is the whole cost of a variant and an AF-filtered variant never reads it (k_lmm_finalize),
 // so when enough of a batch is filtered the kept columns of T are gathered into a dense image and only those are contracted.
-__global__ __launch_bounds__(256) void k_af_keep(int64_t V, int N, const int *__restrict__ m, double min_af, double max_af,
-                                                 int *__restrict__ idx, int *__restrict__ n)
+__global__ __launch_bounds__(256) void k_af_keep(int64_t V, LmmLinOut li, LmmFinParams P, int *__restrict__ idx, int *__restrict__ n)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool keep = false;
-    if (v < V) { const double af = (double)m[v] / (double)N; keep = (min_af <= af && af <= max_af); }
+    if (v < V) {                                                   // the decisions of k_lmm_finalize, on the same numbers
+        const int m = li.m[v];
+        keep = true;
+        if (P.af_on) { const double af = (double)m / (double)P.N; keep = (P.min_af <= af && af <= P.max_af); }
+        if (keep && P.pret < 1.0) {
+            bool bad = false; double prep;
+            if (P.continuous) prep = sh_prefilter_welch((double)m, li.s1[v], li.q1[v], (double)(P.N - m), P.yc_sum - li.s1[v], P.yc_sq - li.q1[v]);
+            else { const int t11 = li.t11[v], t01 = li.t01[v]; prep = sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, &bad); }
+            keep = !(prep >= P.pret || !isfinite(prep));
+        }
+    }
     const unsigned long long km = __ballot(keep);                          // one atomic per wavefront, not per variant
     int base = 0;
     if (lane == 0 && km) base = atomicAdd(n, __popcll(km));
@@ -602,11 +615,11 @@ __global__ __launch_bounds__(256) void k_scatter_q(const double *__restrict__ q2
     q[(int64_t)blockIdx.y * Vpad + idx[j]] = q2[(int64_t)blockIdx.y * Vpad2 + j];
 }
 
-extern "C" hipError_t shk_af_compact(hipStream_t st, int which, int64_t V, int N, const int *m, double min_af, double max_af, int *idx, int *n,
+extern "C" hipError_t shk_af_compact(hipStream_t st, int which, int64_t V, LmmLinOut li, LmmFinParams P, int *idx, int *n,
                                      const uint64_t *T, int64_t Vpad, uint64_t *T2, int64_t Vpad2, int rows, int nk,
                                      const double *q2, double *q)
 {
-    if (which == 0) hipLaunchKernelGGL(k_af_keep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, N, m, min_af, max_af, idx, n);
+    if (which == 0) hipLaunchKernelGGL(k_af_keep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, li, P, idx, n);
     else if (which == 1) hipLaunchKernelGGL(k_gather_T, dim3((unsigned)((Vpad2 + 255) / 256), (unsigned)rows), dim3(256), 0, st, T, Vpad, T2, Vpad2, idx, nk);
     else hipLaunchKernelGGL(k_scatter_q, dim3((unsigned)((nk + 255) / 256), (unsigned)rows), dim3(256), 0, st, q2, Vpad2, q, Vpad, idx, nk);
     return hipGetLastError();

@@ -423,3 +423,37 @@ def test_af_compaction_changes_nothing(engine_mod, frac_rare, monkeypatch):
     if kept.any():
         wb, ws, wf, wp = orc.LmmOracle(U, S, y, covar).block(0.41, Kv[kept].astype(float))
         close(res[0]["beta"][kept], wb, atol=1e-12, what="beta"); close(res[0]["pvalue"][kept], wp, atol=1e-300, what="p")
+
+
+def test_prefilter_compaction_changes_nothing(engine_mod, monkeypatch):
+    """--filter-pvalue with --lmm: a pre-filtered variant is never fitted, so its quadratic form is not computed (k_af_keep drops it along
+    with the AF-filtered ones).  Same outputs as the reference's fit_lmm (oracle), and identical with the compaction forced, off, adaptive."""
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    from pyseer_amd.lmm import mask_like_fit_lmm
+    N, V, pret = 700, 2000, 0.05
+    U, S, covar, y, Kv = _random_lmm(N, 2, 123, V)
+    rng = np.random.default_rng(8)
+    causal = rng.random(V) < 0.04
+    Kv[causal] = ((rng.random((int(causal.sum()), N)) < 0.2) | ((y == 1) & (rng.random((int(causal.sum()), N)) < 0.35))).astype(np.uint8)
+    Kv[::40] = (rng.random((len(Kv[::40]), N)) < 0.004).astype(np.uint8)
+    bits = pack(Kv)
+    res = []
+    for on in ("2", "0", "1"):
+        monkeypatch.setenv("SEERHIP_AFCOMPACT", on)
+        e = Engine(N); e.set_af_filter(0.01, 0.99)
+        e.lmm_setup(U, S, y, covar, 0.33, continuous=False, filter_pvalue=pret, lrt_pvalue=0.5)
+        res.append(e.lmm_batch(bits)); res.append(e.lmm_batch(bits)); e.close()
+    for other in res[1:]:
+        for f in ("prep", "pvalue", "beta", "bse", "frac_h2"):
+            assert np.array_equal(res[0][f], other[f], equal_nan=True), f
+        assert np.array_equal(res[0]["flags"], other["flags"])
+    af = Kv.mean(axis=1)
+    afm = (~((af >= 0.01) & (af <= 0.99))).astype(np.uint8)
+    want = orc.LmmOracle(U, S, y, covar).fit_lmm(0.33, Kv.astype(float), afm, False, pret, 0.5)
+    r = mask_like_fit_lmm(res[0])
+    assert want["prefilter"].mean() > 0.5 and (want["prefilter"] == 0).sum() > 30
+    for f, g in (("prep", "prep"), ("pvalue", "pvalue"), ("beta", "kbeta"), ("bse", "bse"), ("frac_h2", "frac_h2")):
+        close(r[f], want[g], atol=1e-12 if f in ("beta", "frac_h2") else 1e-300, what=f)
+    assert ((r["flags"] & 0x1FF) == want["notes"]).all()
+    assert (((r["flags"] >> 16) & 1) == want["prefilter"]).all() and (((r["flags"] >> 17) & 1) == want["filter"]).all()

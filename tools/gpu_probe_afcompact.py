@@ -67,3 +67,17 @@ for pret in (1.0, 1e-2, 1e-4):
         pf = float(((fl_ >> 16) & 1).float().mean().item())
         print("logistic --filter-pvalue %g (%.1f%% prefiltered)  compaction %s: %.2f ms per %d variants (%.1f M/s)" % (pret, 100 * pf, on, dt * 1e3, Vg, Vg / dt / 1e6))
         e.close()
+
+# ---- --filter-pvalue with --lmm: pre-filtered variants never reach the quadratic form
+for pret in (1.0, 1e-2):
+    for on in ("0", "1"):
+        os.environ["SEERHIP_AFCOMPACT"] = on
+        e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
+        e.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=pret, lrt_pvalue=1.0)
+        for _ in range(4): e.lmm_batch_dev(bits)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): e.lmm_batch_dev(bits)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        print("LMM --filter-pvalue %g  compaction %s: %.2f ms per %d variants (%.1f M/s)" % (pret, on, dt * 1e3, V, V / dt / 1e6))
+        e.close()
