@@ -250,7 +250,7 @@ static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, 
 {
     c->af_last_rows = -1;
     const bool use_pf = pf.y1 != nullptr && pf.pret < 1.0;
-    if (!((c->af_on || use_pf) && c->af_compact) || V < 1024) return inner(d_bits, V, d_out, d_flags);
+    if (!((c->af_on || use_pf) && c->af_compact) || (V < 1024 && c->af_compact != 2)) return inner(d_bits, V, d_out, d_flags);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     if (V > c->af_capV) {
