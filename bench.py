@@ -1,13 +1,17 @@
 #!/usr/bin/env python
-"""bench.py -- k-mer tests/second of the LMM hot path at N = 5000 samples on MI355X (BASELINE.json config C3).
+"""bench.py -- k-mer tests/second of the per-variant association hot path on MI355X (BASELINE.json configs C2 / C3 / C4).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config C3|C2|C2N5000|C4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the LMM per-variant path (sh_lmm_batch_dev: repack -> linear terms -> int8-MFMA quadratic
-form -> finalise) over one batch of --variants-per-step synthetic packed k-mer presence rows that already live in HBM.
+A "step" is one pass of the hot path over one batch of synthetic packed k-mer presence rows that already live in HBM:
+  C3 (default)  LMM, N = 5000, D = 1: sh_lmm_batch_dev = repack -> linear terms -> int8-MFMA quadratic form -> finalise
+  C2            fixed-effects logistic regression, N = 1000, 10 covariates: sh_glm_batch_dev (Newton kernels, Firth for routed rows)
+  C2N5000       the same at N = 5000 (the "fixed-effects at N = 5000" half of BASELINE's metric)
+  C4            N = 5000, 10 covariates, every variant through Firth (force_firth)
 The k-mer stream shards across ranks with no collective on the data path (weak scaling: every rank tests its own
---variants-per-step rows per step).  One JSON line is printed by rank 0.
+--variants-per-step rows per step).  One JSON line is printed by rank 0; it carries `roofline`, `cpu_baseline` (N = 1) and
+`parity_checked` = number of variants of the TIMED output that were re-checked against the CPU oracle after the timed region.
 """
 import argparse
 import json
@@ -22,13 +26,18 @@ sys.path.insert(0, ROOT)
 
 N_SAMPLES = 5000
 INT8_DENSE_PEAK_TOPS = 5000.0      # gfx950 int8 MFMA dense (2x the ~2.5 PF bf16 dense peak, MI355X_MICROARCH.md)
-FP64_FLOP_PER_TEST = 5.0e7         # SURVEY.md §8(d): 2*k*N + 6k fp64 flop of the reference formulation, k=4999
-ALGO_BYTES_PER_TEST = 673          # SURVEY.md §8(d): ceil(N/8) in + 48 out
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # gfx950 fp64 vector peak
+FP64_FLOP_PER_TEST = 5.0e7         # SURVEY.md section 8(d): 2*k*N + 6k fp64 flop of the reference formulation, k=4999
+ALGO_BYTES_PER_TEST = 673          # SURVEY.md section 8(d): ceil(N/8) in + 48 out
+PROFILE_DIRS = ("r02", "r01")      # committed rocprofv3 summaries, newest first
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic workloads; tests/test_bench_inputs_gpu.py runs the oracle on exactly these
+# ---------------------------------------------------------------------------------------------------------------
 def synth_lmm_inputs(N, seed, device):
-    """C3 of SURVEY.md §8(d): K = G G^T from lineage-structured binary markers, scaled N/trace; D = 1; binary phenotype
-    with a heritable component; decomposition + h2 by the package's own initialise_lmm restatement."""
+    """C3: K = G G^T from lineage-structured binary markers, scaled N/trace; D = 1; binary phenotype with a heritable
+    component; decomposition + h2 by the package's own initialise_lmm restatement."""
     import torch
     from pyseer_amd.lmm import initialise_lmm_arrays
     rng = np.random.default_rng(seed)
@@ -44,8 +53,21 @@ def synth_lmm_inputs(N, seed, device):
     return U, S, h2, C, y, lin
 
 
+def synth_glm_inputs(N, q, seed=1002):
+    """C2 / C4: MDS-like covariates scaled by their max-abs (pyseer/input.py:135-136), Bernoulli phenotype, null fits."""
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(seed)
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.3 + 1.5 * W[:, 0] - W[:, 1]
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-eta))).astype(np.float64)
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf
+    nf = fit_null(y, W, e0, False, firth=True)
+    return y, W, nl, nf
+
+
 def synth_bits(V, N, row_bytes, seed, device, chunk=1 << 16):
-    """Packed presence rows, variant-major, generated on the device: AF ~ U(0.02, 0.98) (96 %), rare (2 %), i.i.d.
+    """Packed presence rows, variant-major, generated on the device: AF ~ U(0.02, 0.98) (98 %), rare (2 %), i.i.d.
     Bernoulli(AF) presence.  Returns a (V, row_bytes) uint8 tensor resident in HBM."""
     import torch
     g = torch.Generator(device=device); g.manual_seed(seed)
@@ -63,73 +85,163 @@ def synth_bits(V, N, row_bytes, seed, device, chunk=1 << 16):
     return out
 
 
-def cpu_baseline(U, S, y, C, h2, N, target_s=12.0):
-    """The CPU oracle (oracle/seer_oracle.c: a C port of the reference algorithm, OpenMP over variants) on a bounded
-    sample of the same workload, timed on this host's cores."""
+def unpack_rows(bits_u8, N):
+    """(V, row_bytes) uint8 host array -> (V, N) float64 0/1 (LSB-first, as pyseer_amd/packing.py packs)."""
+    return np.unpackbits(np.ascontiguousarray(bits_u8), axis=1, bitorder="little")[:, :N].astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle/ = test infrastructure: only this leg, tests/ and smoke() may touch it), bounded samples
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline_lmm(U, S, y, C, h2, N, block=1000, blocks_per_proc=3):
+    """The reference's own formulation on this host's cores, run the way `pyseer --cpu P` runs it: P worker processes, one BLAS thread
+    each, whole blocks of variants per task; per block: residualise, `U.T.dot(A)` through BLAS (lmm_cov.py:186), quadratic forms, F tail
+    (oracle/lmm_blas.py).  A separate interpreter forks the workers (oracle/cpu_baseline_lmm.py), so nothing GPU-side is forked."""
+    import subprocess
+    import tempfile
+    procs = max(1, (os.cpu_count() or 2) // 2)                            # physical cores (SMT siblings add nothing to dgemm)
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "lmm_inputs.npz")
+        np.savez(f, U=U, S=S, y=y, C=C, h2=h2)
+        env = dict(os.environ); env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        out = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline_lmm", f, str(procs), str(block), str(blocks_per_proc)],
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    return dict(value=r["variants"] / r["seconds"], unit="variants/s", cores=r["procs"], kind="port",
+                sample="%d synthetic k-mers x %d samples: %d worker processes (as pyseer --cpu), one BLAS thread each, %d blocks of %d variants "
+                       "per worker; fit_lmm_block restated with numpy (oracle/lmm_blas.py): U.T.dot(A) through OpenBLAS dgemm as the reference "
+                       "issues it; %.1f variants/s per core" % (r["variants"], N, r["procs"], blocks_per_proc, r["block"],
+                                                               r["variants"] / r["seconds"] / r["procs"]))
+
+
+def cpu_baseline_glm(y, W, nl, nf, N, force_firth, target_s=12.0):
+    """oracle/seer_oracle.c (C port of model.py:202-504, OpenMP over variants) on a bounded sample of the same workload."""
     from oracle import oracle as orc
     ncores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
-    L = orc.LmmOracle(U, S, y, C)
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(78)
 
     def run(v):
         af = rng.uniform(0.02, 0.98, v)
         Kv = (rng.random((v, N)) < af[:, None]).astype(np.float64)
-        t0 = time.time(); L.block(h2, Kv); return time.time() - t0
-    v0 = 8 * ncores
+        t0 = time.time()
+        if force_firth:
+            orc.firth_batch(y, Kv, W)
+        else:
+            orc.fixed_effects_batch(y, Kv, W, False, 1.0, 1.0, nl, nf)
+        return time.time() - t0
+    v0 = 2 * ncores
     t = run(v0)
-    v1 = int(min(max(v0, v0 * target_s / max(t, 1e-3)), 200000))
-    v1 = max(8, (v1 // 8) * 8)
-    t1 = run(v1)
-    return dict(value=v1 / t1, unit="variants/s", cores=ncores, kind="port",
-                sample="%d synthetic k-mers x %d samples, LMM block test (oracle/seer_oracle.c orc_lmm_block, OpenMP)" % (v1, N))
+    per = int(min(max(v0, v0 * 3.0 / max(t, 1e-3)), (1 << 30) // (8 * N)))   # ~3 s per call, at most 1 GB of rows
+    per = max(ncores, per // ncores * ncores)
+    done, spent = 0, 0.0
+    while spent < target_s:
+        spent += run(per); done += per
+    what = "fit_firth on every variant (orc_firth_batch)" if force_firth else "fixed_effects_regression (orc_fixed_effects_batch)"
+    return dict(value=done / spent, unit="variants/s", cores=ncores, kind="port",
+                sample="%d synthetic k-mers x %d samples, %d covariates, %s, oracle/seer_oracle.c with OpenMP on %d threads"
+                       % (done, N, W.shape[1], what, ncores))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# committed counter measurements (PMC passes cannot run inside this process: they need their own rocprofv3 runs)
+# ---------------------------------------------------------------------------------------------------------------
+def _profile_json(name):
+    for d in PROFILE_DIRS:
+        p = os.path.join(ROOT, "profiles", d, name)
+        if os.path.exists(p):
+            return json.load(open(p)), "profiles/%s/%s" % (d, name)
+    return None, None
+
+
+def measured_traffic(tag, Vs):
+    """HBM-side bytes per launch of the dominant kernel(s) from the committed FETCH_SIZE / WRITE_SIZE passes, scaled to the launch."""
+    t, src = _profile_json("traffic_%s.json" % tag)
+    if t is None:
+        return None, None
+    per_variant = (t["FETCH_SIZE_KB"] * t["fetch_correction"] + (t.get("WRITE_SIZE_KB") or 0.0)) * 1024.0 / t["variants_per_dispatch"]
+    return per_variant * Vs, "%s: %s" % (src, t["source"])
+
+
+def measured_flops(tag):
+    """fp64/fp32 lane-flops per variant of the fixed-effects kernels, counted by SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64/F32 and
+    SQ_INSTS_VALU_MFMA_MOPS_F32 over one batch of the same synthetic workload (tools/profile_r02.sh)."""
+    t, src = _profile_json("flops_%s.json" % tag)
+    if t is None:
+        return None, None, None
+    return t["fp64_flops_per_variant"], t.get("fp32_flops_per_variant", 0.0), "%s: %s" % (src, t["source"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def fixed_effects_extra(dev, local, N, q=10, V=1 << 18, reps=3):
-    """Secondary numbers for the fixed-effects half of the metric (BASELINE configs C2/C4 shapes at N samples):
-    logistic with 10 MDS-like covariates, and Firth forced on every variant.  Same packed-bit inputs, resident in HBM."""
+    """Secondary numbers printed with the default (C3) line: logistic and Firth-on-everything at N samples; the first-class lines
+    are `--config C2 / C2N5000 / C4`."""
     import torch
     from pyseer_amd.engine import Engine, row_bytes_for
-    from pyseer_amd.model import fit_null
-    rng = np.random.default_rng(1002)
-    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
-    eta = -0.3 + 1.5 * W[:, 0] - W[:, 1]
-    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-eta))).astype(np.float64)
-    e0 = np.zeros((0, 0))
-    nl = fit_null(y, W, e0, False).llf
-    nf = fit_null(y, W, e0, False, firth=True)
+    y, W, nl, nf = synth_glm_inputs(N, q)
     out = {}
-    for name, force, v in (("logistic", False, V), ("firth", True, V)):
+    for name, force in (("logistic", False), ("firth", True)):
         eng = Engine(N, device=local); eng.use_torch_stream(); eng.set_af_filter(0.01, 0.99)
         eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=force)
-        bits = synth_bits(v, N, row_bytes_for(N), 4242, dev)
-        o = torch.empty((5 + q, v), dtype=torch.float64, device=dev); f = torch.empty((v,), dtype=torch.int32, device=dev)
+        bits = synth_bits(V, N, row_bytes_for(N), 4242, dev)
+        o = torch.empty((5 + q, V), dtype=torch.float64, device=dev); f = torch.empty((V,), dtype=torch.int32, device=dev)
         eng.glm_batch_dev(bits, o, f); torch.cuda.synchronize()
-        eng.set_timing(True)
         t0 = time.perf_counter()
         for _ in range(reps):
             eng.glm_batch_dev(bits, o, f)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        kms, kl = eng.get_timing()
-        # SURVEY.md §8(d) work model: logistic ~1.1e6 fp64 flop/test at N=1000 (x N/1000), Firth ~9e6 at N=5000
-        flop = (1.1e6 * N / 1000.0) if not force else (9.0e6 * N / 5000.0)
-        out[name] = {"variants_per_s": v / dt, "n_samples": N, "q": q, "variants": v,
-                     "dominant_kernel": "k_firth_eval + k_firth_step (rounds)" if force else "k_glm_fast + k_glm_slow + k_glm_final", "kernel_ms": kms / max(kl, 1),
-                     "fp64_vector_tflops_model": flop * v / (kms / max(kl, 1) * 1e-3) / 1e12, "fp64_vector_peak_tflops": 78.6}
+        out[name] = {"variants_per_s": V / dt, "n_samples": N, "q": q, "variants": V}
         eng.close()
     return out
 
 
-def measured_traffic(Vs):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (they cannot run inside
-    this process: counters need their own rocprofv3 runs), scaled by variants per launch.  None if no measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic_lmm.json")
-    if not os.path.exists(path):
-        return None, None
-    t = json.load(open(path))
-    per_variant = (t["FETCH_SIZE_KB"] * t["fetch_correction"] + t["WRITE_SIZE_KB"]) * 1024.0 / t["variants_per_dispatch"]
-    return per_variant * Vs, t["source"]
+def rel_dev(got, want, floor=1e-300):
+    got = np.asarray(got, dtype=float); want = np.asarray(want, dtype=float)
+    ok = np.isfinite(want) & np.isfinite(got)
+    if not ok.any():
+        return 0.0
+    return float(np.max(np.abs(got[ok] - want[ok]) / np.maximum(np.abs(want[ok]), floor)))
+
+
+def parity_lmm(U, S, y, C, h2, bits_t, out_t, N, n_check=64):
+    """Re-check n_check variants of the timed output against the CPU oracle (orc_lmm_block: the reference's fit_lmm_block)."""
+    from oracle import oracle as orc
+    V = bits_t.shape[0]
+    idx = np.linspace(0, V - 1, n_check).astype(np.int64)
+    import torch
+    ti = torch.from_numpy(idx).to(bits_t.device)
+    rows = unpack_rows(bits_t[ti].cpu().numpy(), N)
+    got = out_t[:, ti].cpu().numpy()                                     # prep, p, beta, bse, frac_h2
+    wb, ws, wf, wp = orc.LmmOracle(U, S, y, C).block(h2, rows)
+    dev = {"beta": rel_dev(got[2], wb), "bse": rel_dev(got[3], ws), "frac_h2": rel_dev(got[4], wf, 1e-12), "pvalue": rel_dev(got[1], wp)}
+    return len(idx), dev
+
+
+def parity_glm(y, W, nl, nf, force_firth, bits_t, out_t, fl_t, N, n_check=64):
+    from oracle import oracle as orc
+    import torch
+    V = bits_t.shape[0]
+    idx = np.linspace(0, V - 1, n_check).astype(np.int64)
+    ti = torch.from_numpy(idx).to(bits_t.device)
+    rows = unpack_rows(bits_t[ti].cpu().numpy(), N)
+    got = out_t[:, ti].cpu().numpy(); fl = fl_t[ti].cpu().numpy().astype(np.uint32)
+    af = rows.mean(axis=1); inwin = (af >= 0.01) & (af <= 0.99)           # the engine's AF window in this bench
+    if force_firth:
+        w = orc.firth_batch(y, rows, W)
+        ok = inwin & (w["status"] == 0)
+        lr = -2.0 * (nf - w["fitll"])
+        wp = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
+        dev = {"kbeta": rel_dev(got[2][ok], w["kbeta"][ok]), "bse": rel_dev(got[3][ok], w["bse"][ok]),
+               "intercept": rel_dev(got[4][ok], w["intercept"][ok]), "pvalue": rel_dev(got[1][ok], wp[ok])}
+    else:
+        w = orc.fixed_effects_batch(y, rows, W, False, 1.0, 1.0, nl, nf)
+        ok = inwin
+        dev = {f: rel_dev(got[i][ok], w[f][ok]) for i, f in ((0, "prep"), (1, "pvalue"), (2, "kbeta"), (3, "bse"), (4, "intercept"))}
+        dev["notes_equal"] = bool(((fl[ok] & 0x1FF) == w["notes"][ok]).all())
+    return int(ok.sum()), dev
 
 
 def main():
@@ -137,10 +249,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--variants-per-step", type=int, default=1 << 20)
-    ap.add_argument("--limbs", type=int, default=5)
+    ap.add_argument("--config", default="C3", choices=["C3", "C2", "C2N5000", "C4"])
+    ap.add_argument("--variants-per-step", type=int, default=0, help="default: 2^20 (C3, C2), 2^18 (C2N5000, C4)")
+    ap.add_argument("--limbs", type=int, default=0, help="int8 limbs of the LMM contraction (0 = the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary fixed-effects measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary fixed-effects measurements of the C3 line")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle re-check of the timed output")
     args = ap.parse_args()
 
     import torch
@@ -149,28 +263,60 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pyseer_amd.engine import Engine, row_bytes_for
-    N = N_SAMPLES
-    U, S, h2, C, y, _ = synth_lmm_inputs(N, 1003, dev)          # identical per-run constants on every rank (replicated)
+    cfg = args.config
+    lmm = cfg == "C3"
+    N = 1000 if cfg == "C2" else N_SAMPLES
+    q = 10
+    Vs = args.variants_per_step or ((1 << 20) if cfg in ("C3", "C2") else (1 << 18))
+    rb = row_bytes_for(N)
     eng = Engine(N, device=local)
     eng.use_torch_stream()
-    eng.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=1.0, lrt_pvalue=1.0, n_limbs=args.limbs)
-    info = eng.lmm_info()
-    rb = row_bytes_for(N)
-    Vs = args.variants_per_step
+
+    if lmm:
+        # per-run constants: rank 0 decomposes the kinship once and broadcasts (U, S, h2, y) at set-up time; the data path has no collective
+        if rank == 0:
+            U, S, h2, C, y, _ = synth_lmm_inputs(N, 1003, dev)
+        if world > 1:
+            shp = torch.tensor([U.shape[0], U.shape[1]] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
+            dist.broadcast(shp, 0)
+            n_, k_ = int(shp[0]), int(shp[1])
+            tU = torch.from_numpy(np.ascontiguousarray(U)).to(dev) if rank == 0 else torch.empty((n_, k_), dtype=torch.float64, device=dev)
+            tS = torch.from_numpy(np.ascontiguousarray(S)).to(dev) if rank == 0 else torch.empty((k_,), dtype=torch.float64, device=dev)
+            ty = torch.from_numpy(np.ascontiguousarray(y)).to(dev) if rank == 0 else torch.empty((n_,), dtype=torch.float64, device=dev)
+            th = torch.tensor([h2 if rank == 0 else 0.0], dtype=torch.float64, device=dev)
+            for t in (tU, tS, ty, th):
+                dist.broadcast(t, 0)
+            if rank != 0:
+                U, S, y, h2 = tU.cpu().numpy(), tS.cpu().numpy(), ty.cpu().numpy(), float(th.item())
+                C = np.ones((n_, 1))
+            del tU
+        eng.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=1.0, lrt_pvalue=1.0, n_limbs=args.limbs)
+        info = eng.lmm_info()
+        nrow = 5
+        run = eng.lmm_batch_dev
+    else:
+        y, W, nl, nf = synth_glm_inputs(N, q)
+        eng.set_af_filter(0.01, 0.99)
+        eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=(cfg == "C4"))
+        nrow = 5 + q
+        run = eng.glm_batch_dev
+
     nbuf = args.steps + args.warmup
-    # every step has its own rows (seed + rank shard), all resident in HBM before the timed region
-    bits = [synth_bits(Vs, N, rb, 1003 + 1000 * rank + i, dev) for i in range(nbuf)]
-    out = torch.empty((5, Vs), dtype=torch.float64, device=dev)
+    # every step has its own rows (seed + rank shard), all resident in HBM before the timed region; at most 16 distinct buffers (10 GB)
+    ndist = min(nbuf, 16)
+    bits = [synth_bits(Vs, N, rb, 1003 + 1000 * rank + i, dev) for i in range(ndist)]
+    out = torch.empty((nrow, Vs), dtype=torch.float64, device=dev)
     fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
 
     for i in range(args.warmup):
-        eng.lmm_batch_dev(bits[i], out, fl)
+        run(bits[i % ndist], out, fl)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,51 +324,97 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.lmm_batch_dev(bits[args.warmup + i], out, fl)
+        run(bits[(args.warmup + i) % ndist], out, fl)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
     kms, klaunch = eng.get_timing()
+    # sanity: the timed work produced finite statistics (row 2 = beta / kbeta; AF-filtered rows of the fixed-effects configs are NaN by contract)
+    fin = torch.isfinite(out[2])
+    if not lmm:
+        fin = fin | ((fl & 1) != 0)
+    frac_finite = float(fin.double().mean().item())
+    per_rank = [float(Vs) * args.steps / dt_local]
+    fin_all = [frac_finite]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # sanity: the timed work produced finite statistics
-    frac_finite = float(torch.isfinite(out[2]).double().mean().item())
+        g = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([per_rank[0], frac_finite], dtype=torch.float64, device=dev))
+        per_rank = [float(x[0]) for x in g]; fin_all = [float(x[1]) for x in g]
+    assert min(fin_all) == 1.0, "a rank produced non-finite statistics: %s" % fin_all
 
     if rank == 0:
+        last = bits[(args.warmup + args.steps - 1) % ndist]
         total = float(Vs) * args.steps * world
         value = total / dt
         kern_s = kms / max(klaunch, 1) * 1e-3
-        int8_ops = 2.0 * info["int8_macs_per_variant"] * Vs
-        achieved = int8_ops / kern_s / 1e12
-        traffic, traffic_src = measured_traffic(Vs)
-        res = {
-            "metric": "k-mer tests/sec at N=5000 samples (LMM), whole job",
-            "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 limbs x%d (exact int32 MFMA accumulation, fp64 recombination and statistics)" % info["n_limbs"],
-            "data": "synthetic",
-            "config": {"workload": "C3: LMM (FaST-LMM per-variant test), %d synthetic k-mers x %d samples per step per GPU, "
-                                   "D=1, k=%d, h2=%.4f, inputs resident in HBM" % (Vs, N, U.shape[1], h2),
-                       "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                         "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "kernel": "k_lmm_quadform_i8", "kernel_ms": kern_s * 1e3, "launches": klaunch,
-                         "ops": "int8 multiply-adds x2 actually issued: L*NR*(NR+1)*128*64 per variant, NR = ceil(N/128)",
-                         "fp64_equiv_tflops": FP64_FLOP_PER_TEST * Vs / kern_s / 1e12,
-                         "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9},
-            "finite_fraction": frac_finite,
-        }
-        if world == 1 and not args.no_extra:
-            res["extra"] = {"fixed_effects_N5000": fixed_effects_extra(dev, local, N_SAMPLES),
-                            "fixed_effects_N1000": fixed_effects_extra(dev, local, 1000, V=1 << 20)}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(U, S, y, C, h2, N)
+        res = {"value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "data": "synthetic", "world": world, "per_rank_value": per_rank, "finite_fraction": min(fin_all)}
+        if lmm:
+            int8_ops = 2.0 * info["int8_macs_per_variant"] * Vs
+            achieved = int8_ops / kern_s / 1e12
+            traffic, traffic_src = measured_traffic("lmm", Vs)
+            res.update({
+                "metric": "k-mer tests/sec at N=5000 samples (LMM), whole job",
+                "dtype": "int8 limbs x%d (exact int32 MFMA accumulation, fp64 recombination and statistics)" % info["n_limbs"],
+                "config": {"workload": "C3: LMM (FaST-LMM per-variant test), %d synthetic k-mers x %d samples per step per GPU, "
+                                       "D=1, k=%d, h2=%.4f, inputs resident in HBM" % (Vs, N, U.shape[1], h2),
+                           "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"},
+                "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                             "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                             "traffic_source": traffic_src,
+                             "kernel": "k_lmm_quadform_i8", "kernel_ms": kern_s * 1e3, "launches": klaunch,
+                             "ops": "int8 multiply-adds x2 actually issued per variant (sh_lmm_info) x variants per launch",
+                             "int8_macs_per_variant": info["int8_macs_per_variant"],
+                             "fp64_equiv_tflops": FP64_FLOP_PER_TEST * Vs / kern_s / 1e12,
+                             "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9},
+                "error_bound": {k: info[k] for k in ("quant_err_norm", "bound_rel_typical", "refined_last_batch") if k in info},
+            })
+            if not args.no_parity:
+                n, devs = parity_lmm(U, S, y, C, h2, last, out, N)
+                res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
+                assert max(devs.values()) < 1e-6, "timed output deviates from the oracle: %s" % devs
+            if world == 1 and not args.no_extra:
+                res["extra"] = {"fixed_effects_N5000": fixed_effects_extra(dev, local, N_SAMPLES),
+                                "fixed_effects_N1000": fixed_effects_extra(dev, local, 1000, V=1 << 20)}
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline_lmm(U, S, y, C, h2, N)
+        else:
+            force = cfg == "C4"
+            tag = cfg.lower()
+            f64, f32, fsrc = measured_flops(tag)
+            traffic, traffic_src = measured_traffic(tag, Vs)
+            achieved = None if f64 is None else f64 * Vs / kern_s / 1e12
+            what = "Firth-penalised logistic regression on every variant (force_firth)" if force else "logistic regression (Firth for routed variants)"
+            res.update({
+                "metric": "k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
+                "dtype": "f64" if force else "f64 (score, likelihood, final information matrix) + f32 Hessian in the first Newton phase",
+                "config": {"workload": "%s: %s, %d synthetic k-mers x %d samples per step per GPU, %d covariates, inputs resident in HBM"
+                                       % (cfg, what, Vs, N, q),
+                           "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"},
+                "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": None if achieved is None else achieved / FP64_VECTOR_PEAK_TFLOPS,
+                             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                             "kernel": "k_firth_init + k_firth_eval/k_firth_step rounds + k_firth_blk" if force else "k_glm_fast + k_glm_slow + k_glm_final",
+                             "kernel_ms": kern_s * 1e3, "launches": klaunch,
+                             "ops": "fp64 lane-flops actually executed per variant (PMC: 64 x (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64)) x variants per step "
+                                    "/ HIP-event time of those kernels per step; fp32 work of the first Newton phase is reported beside it, not added",
+                             "fp64_flops_per_variant": f64, "fp32_flops_per_variant": f32, "flops_source": fsrc,
+                             "hbm_algorithmic_GBps": (rb + (5 + q) * 8 + 4) * Vs / kern_s / 1e9},
+            })
+            if not args.no_parity:
+                n, devs = parity_glm(y, W, nl, nf, force, last, out, fl, N)
+                res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, force)
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

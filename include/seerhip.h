@@ -65,8 +65,9 @@ void    sh_destroy(sh_ctx *ctx);
 /* enqueue all later work on this hipStream_t (NULL = the device's default stream) */
 int     sh_set_stream(sh_ctx *ctx, void *hip_stream);
 int     sh_synchronize(sh_ctx *ctx);
-/* HIP-event timing of the dominant kernel of each later *_batch_dev call (k_lmm_quadform_i8 / the GLM Newton kernel),
- * recorded on the context's stream.  sh_get_timing synchronises on the recorded events and returns their sum. */
+/* HIP-event timing of the dominant kernel(s) of each later *_batch_dev call, recorded on the context's stream: k_lmm_quadform_i8 (main
+ * pass) for the LMM; every fit kernel of a fixed-effects batch (Newton, Firth rounds, final pass; the bit repack is outside).
+ * sh_get_timing synchronises on the recorded events and returns their sum. */
 int     sh_set_timing(sh_ctx *ctx, int on);
 int     sh_get_timing(sh_ctx *ctx, double *total_ms, int64_t *launches);
 /* Pattern de-duplication (pyseer/input.py:710 hash_pattern, scripts/count_patterns.py): when on, every later
@@ -97,6 +98,16 @@ int sh_lmm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
 int sh_lmm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 /* introspection for tests/benchmarks: dominant-kernel work of the last batch */
 int sh_lmm_info(sh_ctx *ctx, int *n_limbs, int64_t *int8_macs_per_variant, double *quant_scale);
+/* Accuracy of the fixed-point contraction that replaces the reference's fp64 U.T.dot(A) (pyseer/fastlmm/lmm_cov.py:186-193) and
+ * computeAKA (:885-900).  The kernel matrix G is held as n_limbs int8 limbs; the only error of x^T K^-1 x is that quantisation, and for a
+ * stored row with m' carriers it is bounded by err_norm * ulp * m', err_norm = spectral norm of the (symmetrised) quantisation error in
+ * units of ulp, estimated at set-up by power iteration (x 1.25).  A variant whose relative bound err_norm*ulp*m'/xKx exceeds `tol`
+ * (default 1e-8, sh_set_lmm_tol; 0 = never) is contracted again with `extra_limbs` more limbs (up to 56 bits in all = fp64) inside the
+ * same call.  bound_typical: the bound of a variant carried by half of the samples on an unstructured population; bound_max_last /
+ * refined_last: the largest final bound and the number of re-contracted variants of the LAST batch (synchronises the stream). */
+int sh_set_lmm_tol(sh_ctx *ctx, double tol);
+int sh_lmm_bound(sh_ctx *ctx, double *err_norm_ulp, double *ulp, double *tol, int *extra_limbs, double *bound_typical,
+                 double *bound_max_last, int64_t *refined_last);
 
 /* ---------------------------------------------------------------------------------------------
  * Fixed effects (replaces pyseer/model.py:202 fixed_effects_regression = a1 prefilter + statsmodels Logit newton /

@@ -16,16 +16,18 @@ extern "C" {
 hipError_t shk_sim_accumulate(hipStream_t st, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64, double min_af, double max_af,
                               int af_on, uint64_t *keep, uint64_t *S, int NS, unsigned long long *Kacc);
 hipError_t shk_sim_finish(hipStream_t st, const unsigned long long *Kacc, int NS, int N, double *K);
-hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *);
+hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64_t, int, int, uint64_t *, uint8_t *);
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, const double *, LmmLinOut);
 hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, const double *, const double *, int, int, int, int, double *);
-hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *);
+hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *, const int *);
+hipError_t shk_lmm_refine(hipStream_t, int64_t, int64_t, int, int, int, int, const int8_t *, const uint64_t *, uint64_t *, double *, LmmLinOut,
+                          const double *, LmmFinParams, double *, uint32_t *, LmmRefine);
 hipError_t shk_af_compact(hipStream_t, int, int64_t, LmmLinOut, LmmFinParams, int *, int *, const uint64_t *, int64_t, uint64_t *,
                           int64_t, int, int, const double *, double *);
-hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *);
-hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, double *, double *,
-                           unsigned long long *, int8_t *);
+hipError_t shk_lmm_finalize(hipStream_t, int64_t, int64_t, int, LmmLinOut, const double *, LmmFinParams, double *, uint32_t *, LmmRefine);
+hipError_t shk_lmm_build_G(hipStream_t, const double *, const double *, int, int, int, int, int, int, double *, double *,
+                           unsigned long long *, int8_t *, float *, double *, double *, double *, int);
 hipError_t shk_dd_find(hipStream_t, const uint64_t *, int64_t, int64_t, int, uint64_t *, uint64_t, unsigned long long *, int *, int *, int *, int *);
 hipError_t shk_af_rows(hipStream_t, int, const uint8_t *, int64_t, int64_t, int, double, double, int *, int *, int *);
 hipError_t shk_pf_rows(hipStream_t, const uint8_t *, int64_t, int64_t, int, const uint64_t *, const uint64_t *, double, double, int, int, int,
@@ -55,6 +57,11 @@ struct sh_ctx {
     uint64_t *d_y1 = nullptr, *d_y0 = nullptr;
     int8_t *d_G = nullptr;
     double quant_scale = 0.0;
+    int E = 0;                    // extra (low) limbs stored below the L of the main pass; contracted only for variants whose bound exceeds lmm_tol
+    bool complement = false;      // rows with more than N/2 carriers are stored complemented (needs the intercept in the covariate span)
+    double err_norm_ulp = 0.0, lmm_tol = 1e-8, trace_M = 0.0;
+    uint8_t *d_flip = nullptr; uint64_t *d_T3 = nullptr; double *d_q3 = nullptr; int *d_rlist = nullptr, *d_rcount = nullptr;
+    unsigned long long *d_bmax = nullptr; int64_t cap_ref = 0;
     int qf_split = 1;             // 1: one block per (variant tile, limb) (SEERHIP_QF_SPLIT=0: one block per tile loops over the limbs)
     int qf_variant = 0;           // hot-kernel variant (SEERHIP_QF=1 selects the first-generation kernel, for A/B runs)
     // ---- GLM state
@@ -74,21 +81,21 @@ struct sh_ctx {
     // ---- pattern de-duplication (sh_set_dedup)
     int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
     uint64_t *dd_h = nullptr; unsigned long long *dd_keys = nullptr; int *dd_idx = nullptr, *dd_rep = nullptr, *dd_slot = nullptr, *dd_n = nullptr;
-    uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0;
+    uint8_t *dd_bits = nullptr; double *dd_out = nullptr; uint32_t *dd_flags = nullptr; int64_t dd_cap_bits = 0, dd_cap_out = 0, dd_cap_flags = 0;
     // row-level AF compaction of the fixed-effects path (af_wrap): its own buffers, because the wrapped call may de-duplicate
     int *af_rep = nullptr, *af_slot = nullptr, *af_cnt = nullptr, *h_af_cnt = nullptr; int64_t af_capV = 0;
     int *af_m = nullptr;                                          // [3][af_capV]: carrier count and the two case/control cells of each row
-    uint8_t *af_bits = nullptr; double *af_out = nullptr; uint32_t *af_flags = nullptr; int64_t af_cap_bits = 0, af_cap_out = 0;
+    uint8_t *af_bits = nullptr; double *af_out = nullptr; uint32_t *af_flags = nullptr; int64_t af_cap_bits = 0, af_cap_out = 0, af_cap_flags = 0;
     hipEvent_t af_ev = nullptr; bool af_pending = false; int64_t af_pending_V = 0; double af_hint = 0.0; int64_t af_last_rows = -1; unsigned af_tick = 0;
     // ---- similarity accumulation (sim_kernels.hip)
     unsigned long long *sim_K = nullptr; uint64_t *sim_S = nullptr, *sim_keep = nullptr; double *sim_out = nullptr; int64_t sim_capV = 0; int NS = 0;
     // ---- pipelined host-pointer batches (host_batch)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     uint8_t *hb_bits[2] = {nullptr, nullptr}; double *hb_out[2] = {nullptr, nullptr}; uint32_t *hb_flags[2] = {nullptr, nullptr};
-    int64_t hb_cap_bits = 0, hb_cap_out = 0;
+    int64_t hb_cap_bits = 0, hb_cap_out = 0, hb_cap_flags = 0;
     uint8_t *hp_bits[2] = {nullptr, nullptr}; int64_t hp_cap = 0;     // pinned host staging (pageable user rows are copied in by several threads)
     // ---- staging for the host-pointer entry points
-    int64_t cap_bits = 0, cap_out = 0;
+    int64_t cap_bits = 0, cap_out = 0, cap_flags = 0;
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
 };
 
@@ -100,6 +107,8 @@ static void free_ws(sh_ctx *c)
     c->d_xky = c->d_dg = c->d_rss = c->d_s1 = c->d_q1 = c->d_q = nullptr; c->capV = 0;
     hipFree(c->d_T2); hipFree(c->d_q2); hipFree(c->d_keep); hipFree(c->d_nkeep);
     c->d_T2 = nullptr; c->d_q2 = nullptr; c->d_keep = c->d_nkeep = nullptr; c->cap_keep = 0;
+    hipFree(c->d_flip); hipFree(c->d_T3); hipFree(c->d_q3); hipFree(c->d_rlist);
+    c->d_flip = nullptr; c->d_T3 = nullptr; c->d_q3 = nullptr; c->d_rlist = nullptr; c->cap_ref = 0;
 }
 
 static int ensure_ws(sh_ctx *c, int64_t Vpad)
@@ -118,10 +127,8 @@ static int ensure_ws(sh_ctx *c, int64_t Vpad)
 static int ensure_staging(sh_ctx *c, int64_t bits_bytes, int64_t out_doubles, int64_t V)
 {
     if (bits_bytes > c->cap_bits) { hipFree(c->d_bits); c->d_bits = nullptr; HIPCHK(hipMalloc((void **)&c->d_bits, bits_bytes)); c->cap_bits = bits_bytes; }
-    if (out_doubles > c->cap_out) {
-        hipFree(c->d_out); hipFree(c->d_flags); c->d_out = nullptr; c->d_flags = nullptr;
-        HIPCHK(dmalloc(&c->d_out, out_doubles)); HIPCHK(dmalloc(&c->d_flags, V)); c->cap_out = out_doubles;
-    }
+    if (out_doubles > c->cap_out) { hipFree(c->d_out); c->d_out = nullptr; HIPCHK(dmalloc(&c->d_out, out_doubles)); c->cap_out = out_doubles; }
+    if (V > c->cap_flags) { hipFree(c->d_flags); c->d_flags = nullptr; HIPCHK(dmalloc(&c->d_flags, V)); c->cap_flags = V; }   // its own capacity: rows, not rows x columns
     return SH_OK;
 }
 
@@ -154,13 +161,14 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int b = 0; b < 2; ++b) { HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming)); }
     }
-    if (cap * row_bytes > c->hb_cap_bits || cap * nrow > c->hb_cap_out) {
+    if (cap * row_bytes > c->hb_cap_bits || cap * nrow > c->hb_cap_out || cap > c->hb_cap_flags) {     // each buffer against its own capacity
+        const int64_t nb = std::max(cap * row_bytes, c->hb_cap_bits), no = std::max(cap * nrow, c->hb_cap_out), nf = std::max(cap, c->hb_cap_flags);
         for (int b = 0; b < 2; ++b) {
             hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]);
             c->hb_bits[b] = nullptr; c->hb_out[b] = nullptr; c->hb_flags[b] = nullptr;
-            HIPCHK(hipMalloc((void **)&c->hb_bits[b], cap * row_bytes)); HIPCHK(dmalloc(&c->hb_out[b], cap * nrow)); HIPCHK(dmalloc(&c->hb_flags[b], cap));
+            HIPCHK(hipMalloc((void **)&c->hb_bits[b], nb)); HIPCHK(dmalloc(&c->hb_out[b], no)); HIPCHK(dmalloc(&c->hb_flags[b], nf));
         }
-        c->hb_cap_bits = cap * row_bytes; c->hb_cap_out = cap * nrow;
+        c->hb_cap_bits = nb; c->hb_cap_out = no; c->hb_cap_flags = nf;
     }
     if (cap * row_bytes > c->hp_cap) {
         for (int b = 0; b < 2; ++b) { if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]); c->hp_bits[b] = nullptr; HIPCHK(hipHostMalloc((void **)&c->hp_bits[b], cap * row_bytes, hipHostMallocDefault)); }
@@ -225,11 +233,9 @@ static int dedup_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t 
         c->dd_cap = (int64_t)cap; c->dd_capV = V;
     }
     if (V * row_bytes > c->dd_cap_bits) { hipFree(c->dd_bits); c->dd_bits = nullptr; HIPCHK(hipMalloc((void **)&c->dd_bits, V * row_bytes)); c->dd_cap_bits = V * row_bytes; }
-    if (V * nrow > c->dd_cap_out) {
-        hipFree(c->dd_out); hipFree(c->dd_flags); c->dd_out = nullptr; c->dd_flags = nullptr;
-        HIPCHK(dmalloc(&c->dd_out, V * nrow)); HIPCHK(dmalloc(&c->dd_flags, V)); c->dd_cap_out = V * nrow;
-    }
-    HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
+    if (V * nrow > c->dd_cap_out) { hipFree(c->dd_out); c->dd_out = nullptr; HIPCHK(dmalloc(&c->dd_out, V * nrow)); c->dd_cap_out = V * nrow; }
+    if (V > c->dd_cap_flags) { hipFree(c->dd_flags); c->dd_flags = nullptr; HIPCHK(dmalloc(&c->dd_flags, V)); c->dd_cap_flags = V; }
+    HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T, nullptr));
     HIPCHK(shk_dd_find(st, c->d_T, Vpad, V, c->NB64, c->dd_h, (uint64_t)c->dd_cap, c->dd_keys, c->dd_idx, c->dd_rep, c->dd_slot, c->dd_n));
     int nu = 0;
     HIPCHK(hipMemcpyAsync(&nu, c->dd_n, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -290,10 +296,8 @@ static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, 
     const int64_t nu = (int64_t)nk + (R != 2147483647 ? 1 : 0);
     if (nu == 0) { c->af_last_rows = 0; return SH_OK; }            // every row's output was written by the classification kernel
     if (nu * row_bytes > c->af_cap_bits) { hipFree(c->af_bits); c->af_bits = nullptr; HIPCHK(hipMalloc((void **)&c->af_bits, nu * row_bytes)); c->af_cap_bits = nu * row_bytes; }
-    if (nu * nrow > c->af_cap_out) {
-        hipFree(c->af_out); hipFree(c->af_flags); c->af_out = nullptr; c->af_flags = nullptr;
-        HIPCHK(dmalloc(&c->af_out, nu * nrow)); HIPCHK(dmalloc(&c->af_flags, nu)); c->af_cap_out = nu * nrow;
-    }
+    if (nu * nrow > c->af_cap_out) { hipFree(c->af_out); c->af_out = nullptr; HIPCHK(dmalloc(&c->af_out, nu * nrow)); c->af_cap_out = nu * nrow; }
+    if (nu > c->af_cap_flags) { hipFree(c->af_flags); c->af_flags = nullptr; HIPCHK(dmalloc(&c->af_flags, nu)); c->af_cap_flags = nu; }
     HIPCHK(shk_af_rows(st, 1, nullptr, 0, V, 0, 0, 0, c->af_rep, c->af_slot, c->af_cnt));
     HIPCHK(shk_dd_gather(st, (const uint8_t *)d_bits, row_bytes, V, c->af_rep, c->af_slot, c->af_bits));
     c->af_last_rows = nu;
@@ -348,7 +352,7 @@ void sh_destroy(sh_ctx *c)
     hipFree(c->af_rep); hipFree(c->af_slot); hipFree(c->af_m); hipFree(c->af_cnt); hipFree(c->af_bits); hipFree(c->af_out); hipFree(c->af_flags);
     if (c->keep_ev) hipEventDestroy(c->keep_ev);
     hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_tab);
-    hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags);
+    hipFree(c->d_G); hipFree(c->d_bits); hipFree(c->d_out); hipFree(c->d_flags); hipFree(c->d_rcount); hipFree(c->d_bmax);
     for (int b = 0; b < 2; ++b) { hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]); if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     for (int b = 0; b < 2; ++b) if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]);
@@ -416,6 +420,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (h2 < 0.0 || h2 >= 1.0 || std::isnan(h2)) return fail(SH_EH2, "h2 outside [0,1): reference returns no 'beta' (KeyError)");
     if (n_limbs == 0) n_limbs = 5;
     if (n_limbs < 3 || n_limbs > 7) return fail(SH_EINVAL, "n_limbs must be 3..7");
+    if (c->N > 262143) return fail(SH_EINVAL, "more than 262143 samples: the int32 partial sums of k_lmm_quadform_i8 could overflow");
     HIPCHK(hipSetDevice(c->device));
     const int N = c->N, Np = c->Np;
     const int kp = (k + 3) & ~3;
@@ -442,6 +447,15 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
         ++r;
     }
     if (r < 1) return fail(SH_EINVAL, "covariate matrix has rank 0");
+    // Is the constant vector in the covariate span?  (pyseer always appends the intercept, lmm.py:95-99; a caller of the C ABI may not.)
+    // Only then U~^T 1 = 0 and a row may be stored complemented (k_repack_bits).
+    bool ones_in_span;
+    {
+        std::vector<double> one(N, 1.0);
+        for (int e = 0; e < r; ++e) { double dot = 0; for (int i = 0; i < N; ++i) dot += Qb[(size_t)i * D + e] * one[i]; for (int i = 0; i < N; ++i) one[i] -= dot * Qb[(size_t)i * D + e]; }
+        double res = 0; for (int i = 0; i < N; ++i) res += one[i] * one[i];
+        ones_in_span = res <= 1e-20 * (double)N;
+    }
     bool intercept_only = (r == 1);
     if (intercept_only) { const double q0 = Qb[0]; for (int i = 0; i < N; ++i) if (std::fabs(Qb[(size_t)i * D] - q0) > 1e-12 * std::fabs(q0)) intercept_only = false; }
     int DP = 0;
@@ -501,8 +515,15 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     c->d_vv = c->d_mdiag = c->d_yc = c->d_Qb = c->d_tab = nullptr; c->d_y1 = c->d_y0 = nullptr; c->d_G = nullptr;
     const int NT = c->NT, L = n_limbs;
     const int NR = 2 * NT;                                   // 128-sample row tiles
-    const size_t gbytes = (size_t)L * NR * (NR + 1) * 8192;
+    // E extra limbs below the L of the main pass (at most 7 in all: 0.49 * 256^7 is where fp64 itself ends); contracted only for the
+    // variants whose a-posteriori bound exceeds lmm_tol
+    int E = std::min(2, 7 - L);
+    if (const char *ev = std::getenv("SEERHIP_LMM_EXTRA")) E = std::max(0, std::min(E, std::atoi(ev)));
+    const int Lt = L + E;
+    const size_t gbytes = (size_t)Lt * NR * (NR + 1) * 8192;
     double *d_W = nullptr, *d_sgn = nullptr, *d_M = nullptr; unsigned long long *d_amax = nullptr;
+    float *d_Ef = nullptr; double *d_px = nullptr, *d_py = nullptr, *d_nrm = nullptr;
+    const int NPOW = 48;
     HIPCHK(dmalloc(&c->d_vv, N)); HIPCHK(dmalloc(&c->d_mdiag, N)); HIPCHK(dmalloc(&c->d_yc, N));
     HIPCHK(dmalloc(&c->d_y1, c->NB64p)); HIPCHK(dmalloc(&c->d_y0, c->NB64p));
     if (DP) HIPCHK(dmalloc(&c->d_Qb, (size_t)N * DP));
@@ -517,21 +538,34 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     HIPCHK(hipMemcpyAsync(c->d_y0, y0.data(), sizeof(uint64_t) * c->NB64p, hipMemcpyHostToDevice, st));
     if (DP) HIPCHK(hipMemcpyAsync(c->d_Qb, Qbp.data(), sizeof(double) * (size_t)N * DP, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_M, 0, sizeof(double) * (size_t)Np * Np, st));
-    HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NR, L, d_M, c->d_mdiag, d_amax, c->d_G));
+    HIPCHK(dmalloc(&d_Ef, (size_t)Np * Np)); HIPCHK(dmalloc(&d_px, Np)); HIPCHK(dmalloc(&d_py, Np)); HIPCHK(dmalloc(&d_nrm, NPOW));
+    HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NR, Lt, E, d_M, c->d_mdiag, d_amax, c->d_G, d_Ef, d_px, d_py, d_nrm, NPOW));
     HIPCHK(dmalloc(&c->d_tab, (size_t)c->NB64 * 256 * (2 + 2 + 8)));          // up to 12 doubles per nibble entry
     HIPCHK(shk_lmm_build_tab(st, c->d_vv, c->d_mdiag, c->d_yc, c->d_Qb, DP, continuous, N, c->NB64, c->d_tab));
     unsigned long long amax_bits = 0;
     HIPCHK(hipMemcpyAsync(&amax_bits, d_amax, sizeof(amax_bits), hipMemcpyDeviceToHost, st));
+    std::vector<double> nrm(NPOW, 0.0), mdiag_h(N, 0.0);
+    HIPCHK(hipMemcpyAsync(nrm.data(), d_nrm, sizeof(double) * NPOW, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(mdiag_h.data(), c->d_mdiag, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_W); hipFree(d_sgn); hipFree(d_M); hipFree(d_amax);
+    hipFree(d_W); hipFree(d_sgn); hipFree(d_M); hipFree(d_amax); hipFree(d_Ef); hipFree(d_px); hipFree(d_py); hipFree(d_nrm);
     double amax; std::memcpy(&amax, &amax_bits, sizeof(double));
     const double p256 = std::pow(256.0, L);
-    c->quant_scale = amax > 0 ? 0.49 * p256 / amax : 0.0;
+    c->quant_scale = amax > 0 ? 0.49 * p256 / amax : 0.0;                 // of the main pass (its top L limbs)
+    // |x^T (G - Gq/s) x| <= ||Esym||_2 |x|^2 = err_norm * (carriers of the stored row).  The power iteration approaches the norm from
+    // below (|A x| <= ||A|| for unit x); the last iterate x 1.25 is used (48 steps reach the edge of a Wigner-like spectrum within a few %).
+    c->err_norm_ulp = 1.25 * nrm[NPOW - 1];
+    double sumv = 0; for (int i = 0; i < N; ++i) sumv += vv[i];
+    c->trace_M = 0; for (int i = 0; i < N; ++i) c->trace_M += mdiag_h[i];
 
-    c->k = k; c->D = D; c->L = L; c->DP = DP;
+    c->k = k; c->D = D; c->L = L; c->DP = DP; c->E = E;
+    c->complement = ones_in_span && !std::getenv("SEERHIP_NO_COMPLEMENT");
+    if (const char *tv = std::getenv("SEERHIP_LMM_TOL")) c->lmm_tol = std::atof(tv);
     LmmFinParams &P = c->fin;
     P.N = N; P.D = D; P.continuous = continuous; P.n1 = n1; P.n0 = n0; P.yc_sum = ycs; P.yc_sq = ycq;
     P.yKy = yKy; P.inv_scale = amax > 0 ? 1.0 / c->quant_scale : 0.0; P.pret = pret; P.lrtt = lrtt;
+    P.sumv = sumv; P.err_norm = c->err_norm_ulp * P.inv_scale; P.tol = E > 0 ? c->lmm_tol : 0.0;
+    P.inv_scale_low = P.inv_scale / std::pow(256.0, E);
     c->lmm_ready = true;
     return SH_OK;
 }
@@ -543,6 +577,38 @@ int sh_lmm_info(sh_ctx *c, int *n_limbs, int64_t *macs, double *qscale)
     // executed int8 MACs per variant in k_lmm_quadform_i8: L * sum_I 2(I+1) tiles * (128 rows * 64), NR = 2*NT row tiles
     if (macs) *macs = (int64_t)c->L * (2 * c->NT) * (2 * c->NT + 1) * 128 * 64;
     if (qscale) *qscale = c->quant_scale;
+    return SH_OK;
+}
+
+int sh_set_lmm_tol(sh_ctx *c, double tol)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    if (!(tol >= 0.0)) return fail(SH_EINVAL, "tol must be >= 0 (0 = never refine)");
+    c->lmm_tol = tol;
+    if (c->lmm_ready) c->fin.tol = c->E > 0 ? tol : 0.0;
+    return SH_OK;
+}
+
+int sh_lmm_bound(sh_ctx *c, double *err_norm_ulp, double *ulp, double *tol, int *extra_limbs, double *bound_typical,
+                 double *bound_max_last, int64_t *refined_last)
+{
+    if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
+    HIPCHK(hipSetDevice(c->device));
+    if (err_norm_ulp) *err_norm_ulp = c->err_norm_ulp;
+    if (ulp) *ulp = c->fin.inv_scale;
+    if (tol) *tol = c->fin.tol;
+    if (extra_limbs) *extra_limbs = c->E;
+    // a variant carried by half of the samples, independent of the population structure: x^T M x ~ (N/4) * trace(M)/N
+    if (bound_typical) *bound_typical = c->trace_M > 0 ? c->fin.err_norm * (0.5 * c->N) / (0.25 * c->trace_M) : 0.0;
+    unsigned long long bm = 0; int nr = 0;
+    if (c->d_bmax) {
+        HIPCHK(hipMemcpyAsync(&bm, c->d_bmax, sizeof(bm), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&nr, c->d_rcount, sizeof(nr), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    double b; std::memcpy(&b, &bm, sizeof(double));
+    if (bound_max_last) *bound_max_last = b;
+    if (refined_last) *refined_last = nr;
     return SH_OK;
 }
 
@@ -565,13 +631,22 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     const int64_t Vpad = (V + 511) / 512 * 512;
     int rc = ensure_ws(c, Vpad); if (rc) return rc;
     hipStream_t st = c->stream;
-    LmmLinOut lo{c->d_t11, c->d_t01, c->d_m, c->d_xky, c->d_dg, c->d_rss, c->d_s1, c->d_q1};
-    HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
+    if (Vpad > c->cap_ref) {
+        hipFree(c->d_flip); hipFree(c->d_T3); hipFree(c->d_q3); hipFree(c->d_rlist);
+        c->d_flip = nullptr; c->d_T3 = nullptr; c->d_q3 = nullptr; c->d_rlist = nullptr;
+        HIPCHK(dmalloc(&c->d_flip, Vpad)); HIPCHK(dmalloc(&c->d_rlist, Vpad));
+        if (c->E > 0) { HIPCHK(dmalloc(&c->d_T3, (size_t)Vpad * c->NB64p)); HIPCHK(dmalloc(&c->d_q3, Vpad * 2)); }
+        c->cap_ref = Vpad;
+    }
+    if (!c->d_rcount) { HIPCHK(dmalloc(&c->d_rcount, 1)); HIPCHK(dmalloc(&c->d_bmax, 1)); }
+    LmmLinOut lo{c->d_t11, c->d_t01, c->d_m, c->d_xky, c->d_dg, c->d_rss, c->d_s1, c->d_q1, c->complement ? c->d_flip : nullptr};
+    HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T, c->complement ? c->d_flip : nullptr));
     HIPCHK(shk_lmm_linear(st, c->DP, c->d_T, Vpad, c->N, c->NB64, c->d_vv, c->d_mdiag, c->d_yc, c->d_Qb, c->d_y1, c->d_y0,
                           c->fin.continuous, c->lin_tab ? c->d_tab : nullptr, lo));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     const int lsplit = c->qf_split ? c->L : 1;
+    const int8_t *Gmain = c->d_G + (size_t)c->E * (2 * c->NT) * (2 * c->NT + 1) * 8192;                   // the main pass contracts the top L limbs
     // AF-filtered variants never read their quadratic form: contract only the kept columns when >= 3 % of the batch is filtered.
     // Knowing the count costs a host round trip, which would serialise back-to-back batches; so a stream whose last counted batch
     // had < 3 % filtered is only counted asynchronously (pinned counter + event, looked at when the next batch arrives) and runs the
@@ -607,14 +682,21 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     if (compact && nk > 0) {
         const int64_t Vpad2 = (nk + 511) / 512 * 512;
         HIPCHK(shk_af_compact(st, 1, V, lo, KP, c->d_keep, nullptr, c->d_T, Vpad, c->d_T2, Vpad2, c->NB64p, (int)nk, nullptr, nullptr));
-        HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T2, Vpad2, 2 * c->NT, c->L, lsplit, c->d_q2));
+        HIPCHK(shk_lmm_quadform(st, c->qf_variant, Gmain, c->d_T2, Vpad2, 2 * c->NT, c->L, lsplit, c->d_q2, nullptr));
         HIPCHK(shk_af_compact(st, 2, V, lo, KP, c->d_keep, nullptr, nullptr, Vpad, nullptr, Vpad2, lsplit, (int)nk, c->d_q2, c->d_q));
     } else if (!compact) {
-        HIPCHK(shk_lmm_quadform(st, c->qf_variant, c->d_G, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q));
+        HIPCHK(shk_lmm_quadform(st, c->qf_variant, Gmain, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q, nullptr));
     }
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->tev.emplace_back(e0, e1); }
     LmmFinParams P = c->fin; P.min_af = c->min_af; P.max_af = c->max_af; P.af_on = c->af_on;
-    HIPCHK(shk_lmm_finalize(st, V, Vpad, lsplit, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags));
+    const bool refine = c->E > 0 && P.tol > 0.0;
+    LmmRefine R{refine ? c->d_rlist : nullptr, c->d_rcount, c->d_bmax};
+    HIPCHK(hipMemsetAsync(c->d_rcount, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(c->d_bmax, 0, sizeof(unsigned long long), st));
+    HIPCHK(shk_lmm_finalize(st, V, Vpad, lsplit, lo, c->d_q, P, (double *)d_out, (uint32_t *)d_flags, R));
+    if (refine)
+        HIPCHK(shk_lmm_refine(st, V, Vpad, lsplit, c->E, 2 * c->NT, c->NB64p, c->d_G, c->d_T, c->d_T3, c->d_q3, lo, c->d_q, P, (double *)d_out,
+                              (uint32_t *)d_flags, R));
     return SH_OK;
 }
 
@@ -658,7 +740,7 @@ int sh_sim_accumulate_dev(sh_ctx *c, const void *d_bits, int64_t row_bytes, int6
         HIPCHK(dmalloc(&c->sim_S, (size_t)VWp * c->NS)); HIPCHK(dmalloc(&c->sim_keep, (size_t)VWp));
         c->sim_capV = Vpad;
     }
-    HIPCHK(shk_repack_bits(c->stream, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T));
+    HIPCHK(shk_repack_bits(c->stream, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T, nullptr));
     HIPCHK(shk_sim_accumulate(c->stream, c->d_T, Vpad, V, c->N, c->NB64, c->min_af, c->max_af, c->af_on, c->sim_keep, c->sim_S, c->NS, c->sim_K));
     return SH_OK;
 }

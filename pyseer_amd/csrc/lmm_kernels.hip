@@ -21,9 +21,29 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // bits (variant-major rows) -> T[sb][v] : one uint64 per (64-sample block, variant); coalesced for every consumer.
 // ---------------------------------------------------------------------------------------------
+// Complemented rows (LMM only): with the intercept in the covariate span, U~^T 1 = 0, so x and 1 - x have the same x^T M x and opposite
+// x . v.  A row with more than N/2 carriers is stored complemented (flip[v] = 1): at most half of the bytes of the variant operand are then
+// non-zero (less switching in the matrix pipe = higher sustained clock), and the quadratic form no longer cancels for allele
+// frequencies near 1 (sum_i x_i M_ii and x^T G x were both ~ m c for a result ~ (N - m) c).  k_lmm_finalize undoes the flip in the
+// counts and the sign of x^T K^-1 y.  flip == nullptr: rows are stored as given (fixed effects, de-duplication, similarity).
+
 // fallback for rows too long to stage 64 of them in 64 KB of LDS (more than 8192 samples): strided 8-byte gather per thread
+__global__ __launch_bounds__(256) void k_row_flip(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V, int N, uint8_t *__restrict__ flip)
+{
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wavefront per row
+    const int lane = threadIdx.x & 63;
+    if (v >= V) return;
+    const uint8_t *p = bits + v * row_bytes;
+    const int nb = N >> 3;
+    int m = 0;
+    for (int b = lane; b < nb; b += 64) m += __popc((unsigned)p[b]);
+    if (lane == 0 && (N & 7)) m += __popc((unsigned)p[nb] & ((1u << (N & 7)) - 1u));
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+    if (lane == 0) flip[v] = (2 * m > N) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_repack_bits_gather(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V,
-                                                            int64_t Vpad, int N, uint64_t *__restrict__ T)
+                                                            int64_t Vpad, int N, uint64_t *__restrict__ T, const uint8_t *__restrict__ flip)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int sb = blockIdx.y;
@@ -34,6 +54,7 @@ __global__ __launch_bounds__(256) void k_repack_bits_gather(const uint8_t *__res
         int64_t nbytes = row_bytes - off; if (nbytes > 8) nbytes = 8;
         if (nbytes == 8 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) w = *reinterpret_cast<const uint64_t *>(p);
         else for (int b = 0; b < nbytes; b++) w |= (uint64_t)p[b] << (8 * b);
+        if (flip && flip[v]) w = ~w;
         const int valid = N - sb * 64;
         if (valid <= 0) w = 0; else if (valid < 64) w &= ((1ull << valid) - 1ull);
     }
@@ -41,12 +62,13 @@ __global__ __launch_bounds__(256) void k_repack_bits_gather(const uint8_t *__res
 }
 
 __global__ __launch_bounds__(256) void k_repack_bits(const uint8_t *__restrict__ bits, int64_t row_bytes, int64_t V,
-                                                     int64_t Vpad, int N, int NB64p, uint64_t *__restrict__ T)
+                                                     int64_t Vpad, int N, int NB64p, uint64_t *__restrict__ T, uint8_t *__restrict__ flip)
 {
     // One block = 64 consecutive variants.  Their rows are one contiguous span of 64 * row_bytes bytes: it is copied to LDS
     // with coalesced 16-byte loads, then wave w writes the 64-sample words sb = w, w+4, ... (one variant per lane, 512 contiguous
     // bytes per store).  A per-thread strided 8-byte gather of the same data runs at a fifth of this.
     extern __shared__ __attribute__((aligned(16))) uint8_t rp_rows[];
+    __shared__ int rp_cnt[4][64];
     const int64_t v0 = (int64_t)blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t nrows = min((int64_t)64, V - v0);
@@ -60,7 +82,7 @@ __global__ __launch_bounds__(256) void k_repack_bits(const uint8_t *__restrict__
         for (int64_t i = tid; i < span; i += 256) rp_rows[i] = src[i];
     }
     __syncthreads();
-    for (int sb = wave; sb < NB64p; sb += 4) {
+    auto word = [&](int sb) -> uint64_t {
         uint64_t w = 0;
         const int64_t off = (int64_t)sb * 8;
         if (lane < nrows && off < row_bytes) {
@@ -69,6 +91,25 @@ __global__ __launch_bounds__(256) void k_repack_bits(const uint8_t *__restrict__
             if (nbytes == 8 && ((row_bytes & 7) == 0)) w = *reinterpret_cast<const uint64_t *>(p);
             else for (int b = 0; b < nbytes; b++) w |= (uint64_t)p[b] << (8 * b);
             const int valid = N - sb * 64;
+            if (valid <= 0) w = 0; else if (valid < 64) w &= ((1ull << valid) - 1ull);
+        }
+        return w;
+    };
+    bool fl = false;
+    if (flip) {                                                         // block-uniform
+        int m = 0;
+        for (int sb = wave; sb < NB64p; sb += 4) m += __popcll(word(sb));
+        rp_cnt[wave][lane] = m;
+        __syncthreads();
+        m = rp_cnt[0][lane] + rp_cnt[1][lane] + rp_cnt[2][lane] + rp_cnt[3][lane];
+        fl = lane < nrows && 2 * m > N;
+        if (wave == 0 && lane < nrows) flip[v0 + lane] = fl ? 1 : 0;
+    }
+    for (int sb = wave; sb < NB64p; sb += 4) {
+        uint64_t w = word(sb);
+        if (fl) {
+            const int valid = N - sb * 64;
+            w = ~w;
             if (valid <= 0) w = 0; else if (valid < 64) w &= ((1ull << valid) - 1ull);
         }
         T[(int64_t)sb * Vpad + v0 + lane] = w;
@@ -352,7 +393,8 @@ template <int N> __device__ __forceinline__ void qf_wait_vm() { asm volatile("s_
 // ABL: timing ablations (results meaningless): 1 = no DMA, 2 = no LDS fragment reads, 4 = no bit expansion
 template <int ABL>
 __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadform_i8(const int8_t *__restrict__ G, const uint64_t *__restrict__ T,
-                                                            int64_t Vpad, int NR, int L, int lsplit, double *__restrict__ qout)
+                                                            int64_t Vpad, int NR, int L, int lsplit, double *__restrict__ qout,
+                                                            const int *__restrict__ nlimit)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // QF_NST slots x 24 KB (the ONLY LDS object)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,6 +408,8 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
     else { tile = blockIdx.x / lsplit; lgrp = blockIdx.x % lsplit; }
     const int nl = (L - lgrp + lsplit - 1) / lsplit;                    // limbs handled here: lgrp, lgrp + lsplit, ...
     const int64_t v0 = (int64_t)tile * QF_BN;
+    if (nlimit && v0 >= (int64_t)*nlimit) return;                       // extra-limb pass: the launch is sized for the whole batch, the list is short
+    const bool big = NR * 128 > 65535;                                  // |acc| can reach 2^23: no 24-bit multiply in the epilogue
     const int64_t TL = (int64_t)NR * (NR + 1);                          // tiles per limb: sum_I 2(I+1)
     const int total = nl * (NR * (NR + 1) / 2);                         // stages in the flattened stream
     int aoff[4][2];
@@ -419,13 +463,19 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
             w[1][jt] = *reinterpret_cast<const uint64_t *>(base + boff + QF_BN * 8 + 256 * jt);
         }
     };
+    // Variant fragment of sub-step (tile tl, k-half kh): lane half lh owns samples 32 lh .. 32 lh + 31 of the tile's 64-sample word, and
+    // dword d of its fragment is ((half >> (4 kh + d)) & 0x01010101), i.e. byte b of dword d = sample 32 lh + 8 b + 4 kh + d.  The G tiles are
+    // stored with the same permutation of their 64 columns (k_lmm_quantize), so a fragment costs 7-8 VALU (shift + and) instead of the 13 of
+    // a nibble multiply ((bits4 * 0x00204081) & 0x01010101 per dword).
     auto expand = [&](const uint64_t (&w)[2][QF_JT], int sub, v4i (&b)[QF_JT]) {
-        const int tl = sub >> 1, ch = (sub & 1) * 2 + lh;
+        const int tl = sub >> 1, kh = sub & 1;
 #pragma unroll
         for (int jt = 0; jt < QF_JT; ++jt) {
+            const uint32_t h = lh ? (uint32_t)(w[tl][jt] >> 32) : (uint32_t)w[tl][jt];
             uint4 e;
-            if (ABL & 4) e = make_uint4((uint32_t)w[tl][jt], ch, jt, 1);
-            else e = qf_expand16((uint32_t)(w[tl][jt] >> (16 * ch)) & 0xFFFFu);
+            if (ABL & 4) e = make_uint4(h, kh, jt, 1);
+            else e = make_uint4((h >> (4 * kh)) & 0x01010101u, (h >> (4 * kh + 1)) & 0x01010101u,
+                                (h >> (4 * kh + 2)) & 0x01010101u, (h >> (4 * kh + 3)) & 0x01010101u);
             b[jt] = (v4i){(int)e.x, (int)e.y, (int)e.z, (int)e.w};
         }
     };
@@ -485,8 +535,9 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
         if (++slot == QF_NST) slot = 0;
         if (++cst == cI + 1) {
             // ---- segment epilogue: sum_i x_i * acc_i over the 128 rows of tile cI, per variant column.  The last stage of a
-            // segment spans exactly the row tile's own samples, so its bit words ARE the epilogue mask.  |acc| <= 127 * N < 2^23,
-            // so the masked sum is a chain of 24-bit multiply-adds by the 0/1 bit (v_bfe_u32 + v_mad_i32_i24 per register).
+            // segment spans exactly the row tile's own samples, so its bit words ARE the epilogue mask.  |acc| <= 128 * N < 2^23 for
+            // N <= 65535, so the masked sum is a chain of 24-bit multiply-adds by the 0/1 bit (v_bfe_u32 + v_mad_i32_i24 per register);
+            // the partial sum of 64 of them, |part| <= 2^29 (N <= 65535) or <= 64 * 128 * N < 2^31 for N < 2^18, stays in int32.
 #pragma unroll
             for (int jt = 0; jt < QF_JT; ++jt) {
                 int part[4];
@@ -494,11 +545,19 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
                 for (int it = 0; it < 4; ++it) {
                     const uint32_t w = (uint32_t)(wb[it >> 1][jt] >> ((it & 1) * 32 + 4 * lh));
                     part[it] = 0;
+                    if (!big) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2);                // C/D layout of the 32x32 MFMA (+ 4*lh, pre-shifted)
-                        const int bit = (int)__builtin_amdgcn_ubfe(w, row, 1);
-                        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(part[it]) : "v"(acc[it][jt][r]), "v"(bit));
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2);            // C/D layout of the 32x32 MFMA (+ 4*lh, pre-shifted)
+                            const int bit = (int)__builtin_amdgcn_ubfe(w, row, 1);
+                            asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(part[it]) : "v"(acc[it][jt][r]), "v"(bit));
+                        }
+                    } else {                                                   // more than 65535 samples: |acc| <= 128 N needs the full 32 bits
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2);
+                            part[it] += ((w >> row) & 1u) ? acc[it][jt][r] : 0;
+                        }
                     }
                 }
                 tot[jt] = fma((double)((part[0] + part[1]) + (part[2] + part[3])), scale_l, tot[jt]);
@@ -523,16 +582,33 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
 // Per-variant finalisation: a1 prefilter + A5 statistics + a7 filters (pyseer/lmm.py:160-217, 244-258).
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, int nq, LmmLinOut li, const double *__restrict__ q,
-                                                      LmmFinParams P, double *__restrict__ out, uint32_t *__restrict__ flags)
+// the linear terms of variant v with the complement of k_repack_bits undone: counts and Welch sums of the ORIGINAL row, x . v of the
+// original row (= sum v - x' . v); dg, rss and the quadratic form belong to the stored row (x'^T M x' = x^T M x when M 1 = 0)
+struct LinV { int m, t11, t01, mst; double xky, dg, rss, s1, q1; };
+__device__ __forceinline__ LinV lin_load(const LmmLinOut &li, const LmmFinParams &P, int64_t v)
 {
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= V) return;
+    LinV r;
+    r.mst = li.m[v]; r.m = r.mst; r.t11 = li.t11[v]; r.t01 = li.t01[v];
+    r.xky = li.xky[v]; r.dg = li.dg[v]; r.rss = li.rss[v]; r.s1 = li.s1[v]; r.q1 = li.q1[v];
+    if (li.flip && li.flip[v]) {
+        r.m = P.N - r.mst; r.t11 = P.n1 - r.t11; r.t01 = P.n0 - r.t01;
+        r.xky = P.sumv - r.xky; r.s1 = P.yc_sum - r.s1; r.q1 = P.yc_sq - r.q1;
+    }
+    return r;
+}
+
+// returns the relative bound on xKx of this variant (0 when it has no statistics); *want_refine: the bound exceeds P.tol
+__device__ __forceinline__ double lmm_fin_one(int64_t v, int64_t V, int64_t Vpad, int nq, const LmmLinOut &li, const double *__restrict__ q,
+                                              const LmmFinParams &P, double q_extra, bool refined, double *__restrict__ out,
+                                              uint32_t *__restrict__ flags, bool *want_refine)
+{
     const double nanv = NAN;
-    double prep = nanv, pval = nanv, beta = nanv, bse = nanv, frac = nanv;
+    double prep = nanv, pval = nanv, beta = nanv, bse = nanv, frac = nanv, bound = 0.0;
     uint32_t fl = 0;
-    const int m = li.m[v];
+    const LinV L = lin_load(li, P, v);
+    const int m = L.m;
     bool go = true;
+    *want_refine = false;
     if (P.af_on) {
         const double af = (double)m / (double)P.N;
         if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; go = false; }
@@ -541,10 +617,9 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, i
         bool bad = false;
         if (P.continuous) {
             const double n1 = (double)m, n0 = (double)(P.N - m);
-            prep = sh_prefilter_welch(n1, li.s1[v], li.q1[v], n0, P.yc_sum - li.s1[v], P.yc_sq - li.q1[v]);
+            prep = sh_prefilter_welch(n1, L.s1, L.q1, n0, P.yc_sum - L.s1, P.yc_sq - L.q1);
         } else {
-            const int t11 = li.t11[v], t01 = li.t01[v];
-            prep = sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, &bad);
+            prep = sh_prefilter_binary(L.t11, P.n1 - L.t11, L.t01, P.n0 - L.t01, &bad);
         }
         if (bad) fl |= SH_NOTE_BAD_CHISQ;
         if (prep >= P.pret || !isfinite(prep)) fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER;      // lmm.py:174 (>=)
@@ -553,11 +628,15 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, i
     // form is not even computed (k_af_keep).  Without one every AF-passing variant carries its statistics, as fit_lmm_block gives them; the
     // masking of the rows that only fail `prep >= 1` or have no finite prep is the caller's (lmm.py:176-217).
     if (go && !((fl & SH_FLAG_PREFILTER) && P.pret < 1.0)) {
-        const bool zeroed = sqrt(li.rss[v] / (double)P.N) <= 1e-10;                              // lmm_cov.py:179-181
+        const bool zeroed = sqrt(L.rss / (double)P.N) <= 1e-10;                                  // lmm_cov.py:179-181
         double qs = 0.0;
         for (int a = 0; a < nq; ++a) qs += q[(int64_t)a * Vpad + v];          // per-limb-group partial sums, fixed order
-        const double xKx = zeroed ? 0.0 : (li.dg[v] + qs * P.inv_scale);
-        const double xKy = zeroed ? 0.0 : li.xky[v];
+        const double xKx = zeroed ? 0.0 : (L.dg + (qs * P.inv_scale + q_extra));
+        const double xKy = zeroed ? 0.0 : L.xky;
+        if (!zeroed && xKx > 0.0) {
+            bound = (refined ? P.err_norm * (P.inv_scale_low / P.inv_scale) : P.err_norm) * (double)L.mst / xKx;
+            if (!refined && P.tol > 0.0 && bound > P.tol) *want_refine = true;
+        }
         double b = xKy / xKx;
         if (isnan(b) && xKy == 0.0) b = 0.0;                                                      // lmm_cov.py:802-805
         const double veb = xKy * b, r2 = P.yKy - veb;
@@ -571,6 +650,63 @@ __global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, i
     }
     out[v] = prep; out[V + v] = pval; out[2 * V + v] = beta; out[3 * V + v] = bse; out[4 * V + v] = frac;
     flags[v] = fl;
+    return bound;
+}
+
+__device__ __forceinline__ void lmm_bound_max(double bound, unsigned long long *bound_max)
+{
+    for (int o = 32; o > 0; o >>= 1) bound = fmax(bound, __shfl_xor(bound, o, 64));
+    if ((threadIdx.x & 63) == 0 && bound > 0.0 && bound_max) atomicMax(bound_max, (unsigned long long)__double_as_longlong(bound));
+}
+
+__global__ __launch_bounds__(256) void k_lmm_finalize(int64_t V, int64_t Vpad, int nq, LmmLinOut li, const double *__restrict__ q,
+                                                      LmmFinParams P, double *__restrict__ out, uint32_t *__restrict__ flags, LmmRefine R)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool ref = false;
+    double bound = 0.0;
+    if (v < V) bound = lmm_fin_one(v, V, Vpad, nq, li, q, P, 0.0, false, out, flags, &ref);
+    // variants whose bound exceeds the tolerance are listed for the extra-limb pass (one atomic per wavefront); their bound is
+    // recorded after that pass
+    const unsigned long long rm = __ballot(ref);
+    if (rm && R.list) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(R.count, __popcll(rm));
+        base = __shfl(base, 0);
+        if (ref) R.list[base + __popcll(rm & ((1ull << lane) - 1ull))] = (int)v;
+    }
+    lmm_bound_max((ref && R.list) ? 0.0 : bound, R.bound_max);
+}
+
+// the listed variants again, with the contribution of the extra limbs (q3: per-limb partial sums, column j of the gathered image)
+__global__ __launch_bounds__(256) void k_lmm_refine_fix(int64_t V, int64_t Vpad, int nq, int nq3, LmmLinOut li, const double *__restrict__ q,
+                                                        const double *__restrict__ q3, LmmFinParams P, double *__restrict__ out,
+                                                        uint32_t *__restrict__ flags, LmmRefine R)
+{
+    const int n = *R.count;
+    for (int64_t j0 = (int64_t)blockIdx.x * 256; j0 < n; j0 += (int64_t)gridDim.x * 256) {
+        const int64_t j = j0 + threadIdx.x;
+        double bound = 0.0;
+        if (j < n) {
+            const int64_t v = R.list[j];
+            double qe = 0.0;
+            for (int a = 0; a < nq3; ++a) qe += q3[(int64_t)a * Vpad + j];
+            bool dummy;
+            bound = lmm_fin_one(v, V, Vpad, nq, li, q, P, qe * P.inv_scale_low, true, out, flags, &dummy);
+        }
+        lmm_bound_max(bound, R.bound_max);
+    }
+}
+
+// columns R.list[0 .. *R.count) of T -> dense image T3 (same column stride), zero columns up to the next multiple of 512
+__global__ __launch_bounds__(256) void k_gather_T_list(const uint64_t *__restrict__ T, int64_t Vpad, uint64_t *__restrict__ T3, LmmRefine R)
+{
+    const int n = *R.count;
+    const int64_t npad = ((int64_t)n + 511) / 512 * 512;
+    const int64_t sb = blockIdx.y;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < npad; j += (int64_t)gridDim.x * 256)
+        T3[sb * Vpad + j] = j < n ? T[sb * Vpad + R.list[j]] : 0ull;
 }
 
 // ---- AF compaction: the quadratic form is the whole cost of a variant and an AF-filtered variant never reads it (k_lmm_finalize),
@@ -581,13 +717,14 @@ __global__ __launch_bounds__(256) void k_af_keep(int64_t V, LmmLinOut li, LmmFin
     const int lane = threadIdx.x & 63;
     bool keep = false;
     if (v < V) {                                                   // the decisions of k_lmm_finalize, on the same numbers
-        const int m = li.m[v];
+        const LinV L = lin_load(li, P, v);
+        const int m = L.m;
         keep = true;
         if (P.af_on) { const double af = (double)m / (double)P.N; keep = (P.min_af <= af && af <= P.max_af); }
         if (keep && P.pret < 1.0) {
             bool bad = false; double prep;
-            if (P.continuous) prep = sh_prefilter_welch((double)m, li.s1[v], li.q1[v], (double)(P.N - m), P.yc_sum - li.s1[v], P.yc_sq - li.q1[v]);
-            else { const int t11 = li.t11[v], t01 = li.t01[v]; prep = sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, &bad); }
+            if (P.continuous) prep = sh_prefilter_welch((double)m, L.s1, L.q1, (double)(P.N - m), P.yc_sum - L.s1, P.yc_sq - L.q1);
+            else prep = sh_prefilter_binary(L.t11, P.n1 - L.t11, L.t01, P.n0 - L.t01, &bad);
             keep = !(prep >= P.pret || !isfinite(prep));
         }
     }
@@ -687,9 +824,13 @@ __global__ void k_extract_diag(const double *__restrict__ M, int N, int Np, doub
 }
 
 // fixed-point limbs in LDS-image order.  grid = (tile index within a limb), block = 128 threads (one tile row each).
-__global__ __launch_bounds__(128) void k_lmm_quantize(const double *__restrict__ M, int N, int Np, int NR, int L,
+// Lt limbs are stored (the main pass contracts the top L = Lt - E of them, the extra-limb pass the E lowest).  The 64 columns of a tile
+// are stored in the order the kernel's variant fragments are built in (see `expand` in k_lmm_quadform_i8): byte c of 16-byte chunk ch
+// holds column 32 (ch & 1) + 8 (c & 3) + 4 (ch >> 1) + (c >> 2).  Ef (optional): the quantisation error of the MAIN pass, e/2 at (i,j)
+// and (j,i) in units of the main pass' ulp -- the symmetric matrix whose spectral norm bounds |x^T (G - Gq/s) x| / |x|^2.
+__global__ __launch_bounds__(128) void k_lmm_quantize(const double *__restrict__ M, int N, int Np, int NR, int Lt, int E,
                                                       const unsigned long long *__restrict__ amax_bits,
-                                                      int8_t *__restrict__ G)
+                                                      int8_t *__restrict__ G, float *__restrict__ Ef)
 {
     // decode (I, ks) from the linear tile id: tiles of 128-row tile I start at I*(I+1) and there are 2(I+1) of them
     int t = blockIdx.x, I = 0;
@@ -699,24 +840,39 @@ __global__ __launch_bounds__(128) void k_lmm_quantize(const double *__restrict__
     const int i = I * 128 + r;
     const double amax = __longlong_as_double((long long)*amax_bits);
     double p256 = 1.0;
-    for (int l = 0; l < L; ++l) p256 *= 256.0;
+    for (int l = 0; l < Lt; ++l) p256 *= 256.0;
     const double scale = amax > 0 ? 0.49 * p256 / amax : 0.0;
     const int64_t TL = (int64_t)NR * (NR + 1);
     for (int ch = 0; ch < 4; ++ch) {
         long long qv[16];
+        double fr[16];
+        int jj[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const int j = ks * 64 + ch * 16 + c;
+            const int j = ks * 64 + 32 * (ch & 1) + 8 * (c & 3) + 4 * (ch >> 1) + (c >> 2);
             double g = 0.0;
             if (i < N && j < i) g = 2.0 * M[(int64_t)i * Np + j];
-            qv[c] = llrint(g * scale);
+            const double gs = g * scale;
+            qv[c] = llrint(gs); fr[c] = gs - (double)qv[c]; jj[c] = j;
         }
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; l < Lt; ++l) {
+            if (l == E && Ef) {                                         // what the main pass drops: low digits + rounding, in its own ulp
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    // after E digit extractions qv[c] * 256^E + (digits so far) = the full fixed-point number
+                    const int j = jj[c];
+                    if (i < N && j < i) {
+                        const float e = (float)(fr[c] * 0.5);           // fr now holds (low digits + rounding) / 256^E
+                        Ef[(int64_t)i * Np + j] = e; Ef[(int64_t)j * Np + i] = e;
+                    }
+                }
+            }
             uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 long long d = ((qv[c] + 128) & 255) - 128;          // balanced digit in [-128, 127]
                 qv[c] = (qv[c] - d) >> 8;
+                if (l < E) fr[c] = (fr[c] + (double)d) * (1.0 / 256.0);   // Horner from the lowest digit up: sum_{l<E} d_l 256^l / 256^E
                 pk[c >> 2] |= ((uint32_t)(d & 255)) << (8 * (c & 3));
             }
             uint4 o; o.x = pk[0]; o.y = pk[1]; o.z = pk[2]; o.w = pk[3];
@@ -725,23 +881,59 @@ __global__ __launch_bounds__(128) void k_lmm_quantize(const double *__restrict__
     }
 }
 
+// ---- spectral norm of the symmetric error matrix by power iteration (set-up, once per run)
+__global__ __launch_bounds__(256) void k_symv_f32(const float *__restrict__ A, int N, int Np, const double *__restrict__ x, double *__restrict__ y)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) s = fma((double)A[(int64_t)i * Np + j], x[j], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) y[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// nrm[it] = |y| ; x = y / |y|     (one block)
+__global__ __launch_bounds__(1024) void k_pow_norm(const double *__restrict__ y, double *__restrict__ x, int N, double *__restrict__ nrm, int it)
+{
+    __shared__ double red[16];
+    __shared__ double tot;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < N; j += 1024) s = fma(y[j], y[j], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < 16; ++w) t += red[w]; tot = sqrt(t); nrm[it] = tot; }
+    __syncthreads();
+    const double inv = tot > 0.0 ? 1.0 / tot : 0.0;
+    for (int j = threadIdx.x; j < N; j += 1024) x[j] = y[j] * inv;
+}
+
+__global__ void k_pow_init(double *__restrict__ x, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; x[i] = ((double)(h & 0xFFFF) - 32767.5) / 32768.0; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-callable launch wrappers (called from api.cpp)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
 hipError_t shk_repack_bits(hipStream_t st, const uint8_t *bits, int64_t row_bytes, int64_t V, int64_t Vpad, int N,
-                           int NB64, uint64_t *T)
+                           int NB64, uint64_t *T, uint8_t *flip)
 {
     const size_t lds = (size_t)64 * row_bytes;
     if (lds > 64 * 1024) {                                                   // more than 8192 samples: per-thread gather (needs Vpad % 256 == 0)
         if (Vpad & 255) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_repack_bits_gather, dim3((unsigned)(Vpad / 256), (unsigned)NB64), dim3(256), 0, st, bits, row_bytes, V, Vpad, N, T);
+        if (flip) hipLaunchKernelGGL(k_row_flip, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, bits, row_bytes, V, N, flip);
+        hipLaunchKernelGGL(k_repack_bits_gather, dim3((unsigned)(Vpad / 256), (unsigned)NB64), dim3(256), 0, st, bits, row_bytes, V, Vpad, N, T, flip);
         return hipGetLastError();
     }
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void *>(k_repack_bits), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k_repack_bits, dim3((unsigned)(Vpad / 64)), dim3(256), lds, st, bits, row_bytes, V, Vpad, N, NB64, T);
+    hipLaunchKernelGGL(k_repack_bits, dim3((unsigned)(Vpad / 64)), dim3(256), lds, st, bits, row_bytes, V, Vpad, N, NB64, T, flip);
     return hipGetLastError();
 }
 
@@ -793,7 +985,8 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q)
+hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q,
+                            const int *nlimit)
 {
     const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(64 * QF_WAVES);
     const size_t lds = QF_NST * QF_STAGE_BYTES;
@@ -807,37 +1000,61 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    switch (variant) {          // 30 + mask = timing ablations (results meaningless)
-    case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    case 53: hipLaunchKernelGGL(k_lmm_quadform_i8<23>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    case 46: hipLaunchKernelGGL(k_lmm_quadform_i8<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    case 38: hipLaunchKernelGGL(k_lmm_quadform_i8<8>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
-    default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q); break;
+    switch (variant) {          // 30 + mask = timing ablations (results meaningless); 64 = the extra-limb pass (same code, its own name in profiles)
+    case 31: hipLaunchKernelGGL(k_lmm_quadform_i8<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 32: hipLaunchKernelGGL(k_lmm_quadform_i8<2>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 34: hipLaunchKernelGGL(k_lmm_quadform_i8<4>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 53: hipLaunchKernelGGL(k_lmm_quadform_i8<23>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 46: hipLaunchKernelGGL(k_lmm_quadform_i8<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 38: hipLaunchKernelGGL(k_lmm_quadform_i8<8>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 64: hipLaunchKernelGGL(k_lmm_quadform_i8<64>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
     }
     return hipGetLastError();
 }
 
 hipError_t shk_lmm_finalize(hipStream_t st, int64_t V, int64_t Vpad, int nq, LmmLinOut li, const double *q, LmmFinParams P, double *out,
-                            uint32_t *flags)
+                            uint32_t *flags, LmmRefine R)
 {
-    hipLaunchKernelGGL(k_lmm_finalize, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, Vpad, nq, li, q, P, out, flags);
+    hipLaunchKernelGGL(k_lmm_finalize, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, Vpad, nq, li, q, P, out, flags, R);
     return hipGetLastError();
 }
 
-hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, int N, int Np, int kp, int NR, int L,
-                           double *M, double *mdiag, unsigned long long *amax, int8_t *G)
+// The extra-limb pass over the variants k_lmm_finalize listed: every launch is sized for the whole batch and reads the list length on the
+// device (no host round trip); with an empty list the three kernels return at once.
+hipError_t shk_lmm_refine(hipStream_t st, int64_t V, int64_t Vpad, int nq, int E, int NR, int NB64p, const int8_t *Glow, const uint64_t *T,
+                          uint64_t *T3, double *q3, LmmLinOut li, const double *q, LmmFinParams P, double *out, uint32_t *flags, LmmRefine R)
+{
+    hipLaunchKernelGGL(k_gather_T_list, dim3(64, (unsigned)NB64p), dim3(256), 0, st, T, Vpad, T3, R);
+    hipError_t e = shk_lmm_quadform(st, 64, Glow, T3, Vpad, NR, E, E, q3, R.count);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lmm_refine_fix, dim3(64), dim3(256), 0, st, V, Vpad, nq, E, li, q, q3, P, out, flags, R);
+    return hipGetLastError();
+}
+
+// M = W sgn W^T, its diagonal, max |G|, the Lt limbs, and (Ef != null) the spectral norm of the main pass' quantisation error:
+// nrm[0 .. npow) = |A x_k| of the power iteration on Ef (in units of the main pass' ulp; nrm[npow-1] is the estimate)
+hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, int N, int Np, int kp, int NR, int Lt, int E,
+                           double *M, double *mdiag, unsigned long long *amax, int8_t *G, float *Ef, double *px, double *py, double *nrm, int npow)
 {
     const int nb = Np / 128;
     hipMemsetAsync(amax, 0, sizeof(unsigned long long), st);
     hipLaunchKernelGGL(k_syrk_f64, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, st, W, sgn, Np, kp, M);
     hipLaunchKernelGGL(k_lower_absmax, dim3((unsigned)N), dim3(256), 0, st, M, N, Np, amax);
     hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, M, N, Np, mdiag);
-    hipLaunchKernelGGL(k_lmm_quantize, dim3((unsigned)(NR * (NR + 1))), dim3(128), 0, st, M, N, Np, NR, L, amax, G);
+    if (Ef) hipMemsetAsync(Ef, 0, sizeof(float) * (size_t)Np * Np, st);
+    hipLaunchKernelGGL(k_lmm_quantize, dim3((unsigned)(NR * (NR + 1))), dim3(128), 0, st, M, N, Np, NR, Lt, E, amax, G, Ef);
+    if (Ef) {
+        hipLaunchKernelGGL(k_pow_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, px, N);
+        for (int it = 0; it < npow; ++it) {
+            hipLaunchKernelGGL(k_symv_f32, dim3((unsigned)N), dim3(256), 0, st, Ef, N, Np, px, py);
+            hipLaunchKernelGGL(k_pow_norm, dim3(1), dim3(1024), 0, st, py, px, N, nrm, it);
+        }
+    }
     return hipGetLastError();
 }
 

@@ -95,7 +95,16 @@ class Engine(object):
     def lmm_info(self):
         nl = C.c_int(); macs = C.c_int64(); qs = C.c_double()
         _abi.check(self._lib.sh_lmm_info(self._h, C.byref(nl), C.byref(macs), C.byref(qs)))
-        return dict(n_limbs=nl.value, int8_macs_per_variant=macs.value, quant_scale=qs.value)
+        en = C.c_double(); ulp = C.c_double(); tol = C.c_double(); ex = C.c_int(); bt = C.c_double(); bm = C.c_double(); nr = C.c_int64()
+        _abi.check(self._lib.sh_lmm_bound(self._h, C.byref(en), C.byref(ulp), C.byref(tol), C.byref(ex), C.byref(bt), C.byref(bm),
+                                          C.byref(nr)))
+        return dict(n_limbs=nl.value, int8_macs_per_variant=macs.value, quant_scale=qs.value, quant_err_norm=en.value, ulp=ulp.value,
+                    refine_tol=tol.value, extra_limbs=ex.value, bound_rel_typical=bt.value, bound_rel_max_last_batch=bm.value,
+                    refined_last_batch=nr.value)
+
+    def set_lmm_tol(self, tol):
+        """Relative bound on x^T K^-1 x above which a variant is contracted again with the extra limbs (include/seerhip.h)."""
+        _abi.check(self._lib.sh_set_lmm_tol(self._h, float(tol)))
 
     def lmm_batch(self, bits):
         """bits: (V, row_bytes) uint8 host array -> dict of host arrays (raw statistics + flags)."""

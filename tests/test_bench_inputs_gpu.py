@@ -1,0 +1,192 @@
+"""The oracle on the benchmarked inputs themselves.
+
+bench.py times synthetic workloads C3 (LMM, N = 5000, lineage-structured kinship) and C4 / C2N5000 (fixed effects at N = 5000,
+10 covariates).  These tests build exactly those inputs (bench.synth_lmm_inputs / synth_glm_inputs / synth_bits) and compare the
+HIP path with the CPU oracle on them, including the rows where the int8-limb contraction is weakest: allele frequencies
+0.95-0.99 and 0.01-0.05, and lineage markers cut from the top eigenvectors of the kinship.
+
+Tolerances: LMM statistics 1e-9 relative against the fp64 oracle (north_star asks for 1e-6; the measured deviation is
+printed); Firth rows 1e-6 relative + the 3e-7 absolute slack of tests/test_glm_gpu.py (step-halving ties).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def rel(a, b, floor=1e-300):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    ok = np.isfinite(a) & np.isfinite(b)
+    assert (np.isfinite(a) == np.isfinite(b)).all(), "finite pattern differs"
+    return float(np.max(np.abs(a[ok] - b[ok]) / np.maximum(np.abs(b[ok]), floor))) if ok.any() else 0.0
+
+
+@pytest.fixture(scope="module")
+def c3():
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    N = bench.N_SAMPLES
+    U, S, h2, C, y, lin = bench.synth_lmm_inputs(N, 1003, dev)
+    return dict(N=N, U=U, S=S, h2=h2, C=C, y=y, lin=lin, dev=dev)
+
+
+def _c3_rows(c3):
+    """256 rows of the bench's own generator + 32 at AF 0.95-0.99 + 32 at AF 0.01-0.05 + 32 lineage markers (top eigenvectors)."""
+    import bench
+    from pyseer_amd.engine import row_bytes_for
+    N = c3["N"]
+    rng = np.random.default_rng(5)
+    bits = bench.synth_bits(256, N, row_bytes_for(N), 1003, c3["dev"]).cpu().numpy()
+    rows = [bench.unpack_rows(bits, N)]
+    rows.append((rng.random((32, N)) < rng.uniform(0.95, 0.99, 32)[:, None]).astype(np.float64))
+    rows.append((rng.random((32, N)) < rng.uniform(0.01, 0.05, 32)[:, None]).astype(np.float64))
+    top = np.argsort(c3["S"])[::-1][:16]                       # the 16 largest eigenvalues: two cuts of each eigenvector
+    mk = []
+    for j in top:
+        u = c3["U"][:, j]
+        mk.append((u > np.median(u)).astype(np.float64))
+        mk.append((u > np.quantile(u, 0.9)).astype(np.float64))
+    rows.append(np.array(mk))
+    Kv = np.concatenate(rows)
+    af = Kv.mean(axis=1)
+    return Kv[(af > 0.002) & (af < 0.998)]
+
+
+@pytest.mark.parametrize("limbs", [0, 6])
+def test_c3_bench_inputs_vs_oracle(c3, limbs):
+    """(a) of VERDICT item 1: >= 256 variants of the C3 workload + the hard rows, default limb count and L = 6."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    Kv = _c3_rows(c3)
+    assert Kv.shape[0] >= 340
+    e = Engine(c3["N"])
+    e.lmm_setup(c3["U"], c3["S"], c3["y"], c3["C"], c3["h2"], n_limbs=limbs)
+    r = e.lmm_batch(pack_variants(Kv.astype(np.uint8)))
+    info = e.lmm_info()
+    e.close()
+    wb, ws, wf, wp = orc.LmmOracle(c3["U"], c3["S"], c3["y"], c3["C"]).block(c3["h2"], Kv)
+    d = dict(beta=rel(r["beta"], wb), bse=rel(r["bse"], ws), frac_h2=rel(r["frac_h2"], wf, 1e-12), p=rel(r["pvalue"], wp))
+    print("C3 inputs, limbs=%d (%s): max rel dev vs oracle %s" % (info["n_limbs"], info, d))
+    tol = 1e-9
+    assert d["beta"] < tol and d["bse"] < tol and d["p"] < 10 * tol and d["frac_h2"] < 1e-8, d
+    # the a-posteriori bound the engine reports must cover what was measured on xKx (bse^2 ~ 1/xKx)
+    if "bound_rel_max_last_batch" in info:
+        assert 2 * d["bse"] <= max(info["bound_rel_max_last_batch"], 1e-13) * 1.01 + 1e-13, (d, info)
+
+
+def test_c3_complement_symmetry_full_batch(c3):
+    """A size-independent property on a full bench batch: x and 1-x give the same xKx, so beta flips sign and bse, p, frac_h2 agree."""
+    import torch
+    import bench
+    from pyseer_amd.engine import Engine, row_bytes_for
+    N = c3["N"]; V = 1 << 15
+    bits = bench.synth_bits(V, N, row_bytes_for(N), 2024, c3["dev"])
+    comp = (~bits).clone()
+    nb = (N + 7) // 8
+    comp[:, nb:] = 0
+    if N % 8:
+        comp[:, nb - 1] &= (1 << (N % 8)) - 1
+    e = Engine(N); e.use_torch_stream()
+    e.lmm_setup(c3["U"], c3["S"], c3["y"], c3["C"], c3["h2"])
+    o1, _ = e.lmm_batch_dev(bits); o1 = o1.cpu().numpy()
+    o2, _ = e.lmm_batch_dev(comp); o2 = o2.cpu().numpy()
+    e.close()
+    assert rel(o2[2], -o1[2], 1e-12) < 1e-9 and rel(o2[3], o1[3]) < 1e-9 and rel(o2[1], o1[1]) < 1e-8
+
+
+def test_c4_forced_firth_bench_inputs_vs_oracle():
+    """(b): force_firth at N = 5000, q = 10 on >= 128 variants of the C4 workload vs orc_firth_batch (the S = 8 sample-split rounds
+    and the hand-off to k_firth_blk at the size the bench times)."""
+    import torch
+    import bench
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, row_bytes_for
+    N, q, V = 5000, 10, 160
+    y, W, nl, nf = bench.synth_glm_inputs(N, q)
+    dev = torch.device("cuda", 0)
+    bits_t = bench.synth_bits(V, N, row_bytes_for(N), 4242, dev)
+    bits = bits_t.cpu().numpy()
+    Kv = bench.unpack_rows(bits, N)
+    af = Kv.mean(axis=1); keep = (af >= 0.01) & (af <= 0.99)
+    e = Engine(N); e.set_af_filter(0.01, 0.99)
+    e.glm_setup(y, W, False, nl, nf, force_firth=True)
+    r = e.glm_batch(bits)
+    e.close()
+    w = orc.firth_batch(y, Kv, W)
+    ok = keep & (w["status"] == 0)
+    assert ok.sum() >= 128
+    FA = 3e-7
+    for f in ("kbeta", "bse", "intercept"):
+        assert np.allclose(r[f][ok], w[f][ok], rtol=1e-6, atol=FA), (f, rel(r[f][ok], w[f][ok]))
+    assert np.allclose(r["betas"][ok], w["betas"][ok], rtol=1e-6, atol=FA)
+    lr = -2.0 * (nf - w["fitll"][ok])
+    wp = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
+    assert np.allclose(r["pvalue"][ok], wp, rtol=2e-6, atol=1e-300), rel(r["pvalue"][ok], wp)
+    assert (((r["flags"][ok] >> 6) & 1) == 0).all()               # no firth-fail where the reference converges
+    print("C4 inputs: max rel dev kbeta %.2e bse %.2e p %.2e on %d variants" % (
+        rel(r["kbeta"][ok], w["kbeta"][ok]), rel(r["bse"][ok], w["bse"][ok]), rel(r["pvalue"][ok], wp), ok.sum()))
+
+
+def test_c2n5000_logistic_bench_inputs_vs_oracle():
+    """The logistic half at N = 5000, q = 10 on the bench's own rows (incl. its 2 % rare variants, which route to Firth)."""
+    import torch
+    import bench
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, row_bytes_for
+    N, q, V = 5000, 10, 256
+    y, W, nl, nf = bench.synth_glm_inputs(N, q)
+    bits = bench.synth_bits(V, N, row_bytes_for(N), 4242, torch.device("cuda", 0)).cpu().numpy()
+    Kv = bench.unpack_rows(bits, N)
+    af = Kv.mean(axis=1); keep = (af >= 0.01) & (af <= 0.99)
+    e = Engine(N); e.set_af_filter(0.01, 0.99)
+    e.glm_setup(y, W, False, nl, nf)
+    r = e.glm_batch(bits)
+    e.close()
+    w = orc.fixed_effects_batch(y, Kv[keep], W, False, 1.0, 1.0, nl, nf)
+    firth = (w["notes"] & 0x7C) != 0
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        g = r[f][keep]
+        assert np.allclose(g[~firth], w[f][~firth], rtol=1e-6, atol=1e-300, equal_nan=True), f
+        assert np.allclose(g[firth], w[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, equal_nan=True), f
+    assert ((r["flags"][keep] & 0x1FF) == w["notes"]).all()
+    assert (r["flags"][~keep] & 1).all()                           # af-filter note outside the window
+
+
+@pytest.mark.parametrize("h2_force", [None, 0.9, 0.99])
+def test_limb_accuracy_stress(h2_force):
+    """(c): the stress case of tools/gpu_limb_accuracy.py in the suite -- six deep lineages (top eigenvalue ~ N/12), h2 forced up to
+    0.99 (Sd_max/Sd_min ~ 1e4), half of the variants lineage markers whose projection lives in the top eigenvectors."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.lmm import initialise_lmm_arrays
+    rng = np.random.default_rng(0)
+    N, nl = 1200, 6
+    lin = rng.integers(0, nl, N)
+    G = np.concatenate([(lin[None, :] == rng.integers(0, nl, 400)[:, None]).astype(float), (rng.random((300, N)) < 0.3).astype(float)])
+    K = G.T @ G
+    y = ((lin < 3).astype(float) * 0.8 + rng.standard_normal(N) * 0.6 > 0.4).astype(float)
+    U, S, h2, nll, C = initialise_lmm_arrays(K, y)
+    if h2_force is not None:
+        h2 = h2_force
+    V = 400
+    Kv = np.concatenate([(lin[None, :] == rng.integers(0, nl, V // 2)[:, None]).astype(np.uint8),
+                         (rng.random((V // 2, N)) < rng.uniform(0.05, 0.95, V // 2)[:, None]).astype(np.uint8)])
+    flip = rng.random(Kv.shape) < 0.01
+    Kv = np.where(flip, 1 - Kv, Kv).astype(np.uint8)
+    af = Kv.mean(axis=1); Kv = Kv[(af > 0.01) & (af < 0.99)]
+    wb, ws, wf, wp = orc.LmmOracle(U, S, y, C).block(h2, Kv.astype(float))
+    ok = np.isfinite(ws) & (ws > 1e-7)
+    for L, tol in ((0, 2e-10), (6, 2e-11)):
+        e = Engine(N); e.lmm_setup(U, S, y, C, h2, n_limbs=L)
+        r = e.lmm_batch(pack_variants(Kv)); info = e.lmm_info(); e.close()
+        d = (rel(r["beta"][ok], wb[ok]), rel(r["bse"][ok], ws[ok]), rel(r["pvalue"][ok], wp[ok]))
+        print("stress h2=%.4f L=%d: beta %.2e bse %.2e p %.2e  %s" % (h2, info["n_limbs"], d[0], d[1], d[2], info))
+        assert d[0] < tol and d[1] < tol and d[2] < 10 * tol, (L, d)
