@@ -457,3 +457,103 @@ def test_prefilter_compaction_changes_nothing(engine_mod, monkeypatch):
         close(r[f], want[g], atol=1e-12 if f in ("beta", "frac_h2") else 1e-300, what=f)
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
     assert (((r["flags"] >> 16) & 1) == want["prefilter"]).all() and (((r["flags"] >> 17) & 1) == want["filter"]).all()
+
+
+def _dev(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    ok = np.isfinite(a) & np.isfinite(b) & (np.abs(b) > 1e-200)
+    return float(np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok]))) if ok.any() else 0.0
+
+
+def test_extra_limb_pass_is_as_good_as_more_limbs(engine_mod):
+    """The a-posteriori bound and the extra-limb pass (include/seerhip.h sh_lmm_bound): with 4 limbs and the pass switched off the
+    statistics carry the 4-limb quantisation (~1e-9); with a tolerance below every variant's bound all of them are contracted again with
+    the two extra limbs and land where 6 limbs land; the reported bound always covers the measured deviation of xKx (~ 2 x that of bse)."""
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    N, D, V = 1000, 1, 384
+    U, S, covar, y, Kv = _random_lmm(N, D, 77, V)
+    wb, ws, wf, wp = orc.LmmOracle(U, S, y, covar).block(0.37, Kv.astype(float))
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.37, n_limbs=4)
+    e.set_lmm_tol(0.0)                                             # never refine
+    r0 = e.lmm_batch(pack(Kv)); i0 = e.lmm_info()
+    assert i0["refined_last_batch"] == 0 and i0["extra_limbs"] == 2
+    d0 = _dev(r0["bse"], ws)
+    assert 1e-12 < d0 < 1e-7, d0                                   # the 4-limb error is visible ...
+    assert 2 * d0 <= i0["bound_rel_max_last_batch"] * 1.01         # ... and inside the bound
+    e.set_lmm_tol(1e-13)                                           # below every bound: every fitted variant is refined
+    r1 = e.lmm_batch(pack(Kv)); i1 = e.lmm_info()
+    assert i1["refined_last_batch"] == V, i1
+    d1 = max(_dev(r1["bse"], ws), _dev(r1["beta"], wb), _dev(r1["pvalue"], wp))
+    assert d1 < 2e-12, d1
+    assert i1["bound_rel_max_last_batch"] < i0["bound_rel_max_last_batch"] / 6e4
+    # a tolerance in between refines only the variants above it, and those are exactly the ones whose 4-limb bound exceeded it
+    tol = float(np.median([i0["bound_rel_max_last_batch"], i0["bound_rel_typical"]]))
+    e.set_lmm_tol(tol)
+    r2 = e.lmm_batch(pack(Kv)); i2 = e.lmm_info()
+    assert 0 < i2["refined_last_batch"] < V, (tol, i2)
+    same = r2["bse"] == r0["bse"]; refined = r2["bse"] == r1["bse"]
+    assert (same | refined).all() and refined.sum() >= i2["refined_last_batch"]
+    e.close()
+
+
+def test_complemented_rows_change_nothing_but_rounding(engine_mod, monkeypatch):
+    """Rows with more than N/2 carriers are stored complemented (k_repack_bits); SEERHIP_NO_COMPLEMENT=1 (read by sh_lmm_setup) stores
+    them as given.  Same statistics up to the quantisation of G, counts / prefilter / flags identical, with covariates and a continuous
+    phenotype as well."""
+    Engine, pack = engine_mod
+    for N, D, cont in ((300, 1, False), (515, 3, False), (200, 2, True)):
+        U, S, covar, y, Kv = _random_lmm(N, D, 5 + N, 256)
+        if cont:
+            y = np.random.default_rng(1).standard_normal(N)
+        Kv[:64] = (np.random.default_rng(2).random((64, N)) < 0.97).astype(np.uint8)      # majority-carrier rows
+        e = Engine(N); e.set_af_filter(0.01, 0.99)
+        e.lmm_setup(U, S, y, covar, 0.41, continuous=cont, filter_pvalue=0.7)
+        a = e.lmm_batch(pack(Kv))
+        monkeypatch.setenv("SEERHIP_NO_COMPLEMENT", "1")
+        e.lmm_setup(U, S, y, covar, 0.41, continuous=cont, filter_pvalue=0.7)
+        b = e.lmm_batch(pack(Kv))
+        monkeypatch.delenv("SEERHIP_NO_COMPLEMENT")
+        e.close()
+        assert np.array_equal(a["flags"], b["flags"]) and np.array_equal(np.isnan(a["prep"]), np.isnan(b["prep"]))
+        assert _dev(a["prep"], b["prep"]) < (1e-12 if cont else 1e-300)    # binary: integer counts, identical; Welch sums: by subtraction
+        for f in ("beta", "bse", "pvalue", "frac_h2"):
+            assert np.array_equal(np.isnan(a[f]), np.isnan(b[f]))
+            assert _dev(a[f], b[f]) < 1e-9, (N, f, _dev(a[f], b[f]))
+
+
+def test_covariates_without_intercept_through_the_abi(engine_mod):
+    """pyseer always appends the intercept (lmm.py:95-99); the C ABI does not require it.  Without it U~^T 1 != 0, rows must not be
+    complemented, and the statistics still follow the oracle."""
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    N, V = 400, 200
+    U, S, _, y, Kv = _random_lmm(N, 1, 91, V)
+    covar = np.random.default_rng(3).standard_normal((N, 2))       # no constant column
+    Kv[:50] = (np.random.default_rng(4).random((50, N)) < 0.9).astype(np.uint8)
+    wb, ws, wf, wp = orc.LmmOracle(U, S, y, covar).block(0.3, Kv.astype(float))
+    e = Engine(N); e.lmm_setup(U, S, y, covar, 0.3)
+    r = e.lmm_batch(pack(Kv)); e.close()
+    close(r["beta"], wb, atol=1e-12); close(r["bse"], ws); close(r["pvalue"], wp, atol=1e-300)
+
+
+def test_more_than_8192_samples_repack_fallback(engine_mod):
+    """Rows longer than 1 KB take the gather form of the bit repack (k_repack_bits_gather + k_row_flip): low-rank U keeps the oracle cheap."""
+    Engine, pack = engine_mod
+    from oracle import oracle as orc
+    N, k, V = 8300, 48, 96
+    rng = np.random.default_rng(12)
+    U = np.linalg.qr(rng.standard_normal((N, k + 1)))[0]
+    one = np.ones(N) / np.sqrt(N)
+    U = U - np.outer(one, one @ U); U = np.linalg.qr(U)[0][:, :k]  # orthogonal to the intercept, as a fresh decomposition is
+    S = np.sort(rng.gamma(0.5, 2.0, k))[::-1].copy()
+    y = (rng.random(N) < 0.4).astype(float); covar = np.ones((N, 1))
+    Kv = (rng.random((V, N)) < rng.uniform(0.02, 0.98, V)[:, None]).astype(np.uint8)
+    wb, ws, wf, wp = orc.LmmOracle(U, S, y, covar).block(0.3, Kv.astype(float))
+    e = Engine(N); e.lmm_setup(U, S, y, covar, 0.3)
+    r = e.lmm_batch(pack(Kv)); e.close()
+    close(r["beta"], wb, atol=1e-12); close(r["bse"], ws); close(r["pvalue"], wp, atol=1e-300)
+    for v in range(0, V, 13):
+        pr, bad = orc.pre_filtering(y, Kv[v].astype(float), False)
+        close(r["prep"][v], pr)
