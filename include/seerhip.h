@@ -154,10 +154,15 @@ typedef struct sh_reader sh_reader;
 sh_reader  *sh_reader_open(const char *path, const char *const *sample_names, int n_samples);
 void        sh_reader_close(sh_reader *r);
 const char *sh_reader_error(void);
-/* parses up to max_variants lines; returns how many (0 = end of file, -1 = error).  bits: max_variants*row_bytes;
+/* parses up to max_variants lines; returns how many (0 = end of file, -1 = error, -2 = the variant names of this block need more
+ * than names_cap bytes: nothing was consumed, sh_reader_names_needed() gives the size to retry with -- the reference has no limit on
+ * name length, and unitig names run to tens of kilobases).  bits: max_variants*row_bytes;
  * names: concatenated variant names, name_off[v] .. name_off[v+1] (max_variants+1 offsets). */
 int64_t     sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_t row_bytes, int32_t *counts,
                            char *names, int64_t names_cap, int64_t *name_off);
+int64_t     sh_reader_names_needed(sh_reader *r);
+/* bytes of inflated text currently buffered (bounded by one block of lines + one read slab; for tests) */
+int64_t     sh_reader_buffered(sh_reader *r);
 
 /* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */
 int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);

@@ -49,6 +49,8 @@ SIGNATURES = {
     "sh_reader_error": (C.c_char_p, []),
     "sh_reader_next": (C.c_int64, [C.c_void_p, C.c_int64, c_u8p, C.c_int64, C.POINTER(C.c_int32), C.c_char_p, C.c_int64,
                                    C.POINTER(C.c_int64)]),
+    "sh_reader_names_needed": (C.c_int64, [C.c_void_p]),
+    "sh_reader_buffered": (C.c_int64, [C.c_void_p]),
     "sh_format_rows": (C.c_int64, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.POINTER(c_dp), C.c_int, c_dp,
                                    C.c_int, c_u8p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.c_int, c_u32p, C.c_char_p,
                                    C.c_int64]),

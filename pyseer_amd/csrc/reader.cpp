@@ -53,6 +53,7 @@ struct sh_reader {
     std::vector<char> buf;               // unconsumed text
     size_t pos = 0;                      // first unconsumed byte of buf
     bool eof = false;
+    int64_t names_needed = 0;            // bytes of variant names the last refused call (-2) would have written
     std::string err;
 };
 
@@ -90,6 +91,10 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     if (!r || !bits || !counts || !names || !name_off || max_variants < 1) { g_rerr = "bad argument"; return -1; }
     if (row_bytes * 8 < r->n) { g_rerr = "row_bytes too small"; return -1; }
     auto t0 = std::chrono::steady_clock::now();
+    // release the text handed out by earlier calls: line offsets are only recorded from here on, so compacting is safe, and the buffer
+    // never holds more than one call's lines plus one slab (the reference streams line by line; a k-mer file is tens of GB inflated)
+    if (r->pos > 0) { r->buf.erase(r->buf.begin(), r->buf.begin() + r->pos); r->pos = 0; }
+    const size_t pos0 = r->pos;
     // ---- collect up to max_variants complete lines in the buffer
     std::vector<std::pair<size_t, size_t>> lines;            // [begin, end) without the newline
     size_t scan = r->pos;
@@ -103,8 +108,7 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
             r->pos = scan = e + 1;
         }
         if ((int64_t)lines.size() >= max_variants || r->eof) break;
-        // refill: compact, then read another slab
-        if (r->pos > 0 && lines.empty()) { r->buf.erase(r->buf.begin(), r->buf.begin() + r->pos); scan -= r->pos; r->pos = 0; }
+        // refill: read another slab behind what is buffered
         const size_t old = r->buf.size();
         const size_t slab = 8u << 20;
         r->buf.resize(old + slab);
@@ -122,18 +126,22 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     const int64_t nv = (int64_t)lines.size();
     if (nv == 0) return 0;
     auto t1 = std::chrono::steady_clock::now();
-    memset(bits, 0, (size_t)nv * row_bytes);
-    // ---- names (serial: offsets), presence (parallel)
+    // ---- names (serial: offsets), presence (parallel).  Unitig names run to tens of kilobases: the total is measured BEFORE anything is
+    // written, and a call that does not fit is refused without consuming its lines (-2; sh_reader_names_needed() says how much to bring)
     const char *base = r->buf.data();
-    int64_t off = 0;
+    std::vector<std::pair<const char *, const char *>> nm((size_t)nv);
+    int64_t need = 0;
     for (int64_t v = 0; v < nv; ++v) {
         const char *p = base + lines[v].first, *e = base + lines[v].second;
         while (p < e && (*p == ' ' || *p == '\t')) ++p;
         const char *q = p;
         while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
-        if (off + (q - p) > names_cap) { g_rerr = "names buffer too small"; return -1; }
-        name_off[v] = off; memcpy(names + off, p, q - p); off += q - p;
+        nm[v] = {p, q}; need += q - p;
     }
+    if (need > names_cap) { r->names_needed = need; r->pos = pos0; g_rerr = "names buffer too small"; return -2; }
+    memset(bits, 0, (size_t)nv * row_bytes);
+    int64_t off = 0;
+    for (int64_t v = 0; v < nv; ++v) { name_off[v] = off; memcpy(names + off, nm[v].first, nm[v].second - nm[v].first); off += nm[v].second - nm[v].first; }
     name_off[nv] = off;
     const auto &index = r->index;
 #pragma omp parallel
@@ -170,9 +178,10 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
         fprintf(stderr, "[reader] %lld lines: read+split %.3fs parse %.3fs\n", (long long)nv,
                 std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
     }
-    // release consumed text when everything buffered has been handed out
-    if (r->pos == r->buf.size()) { r->buf.clear(); r->pos = 0; }
     return nv;
 }
+
+int64_t sh_reader_names_needed(sh_reader *r) { return r ? r->names_needed : 0; }
+int64_t sh_reader_buffered(sh_reader *r) { return r ? (int64_t)r->buf.size() : 0; }
 
 }  // extern "C"

@@ -354,6 +354,9 @@ class NativeKmerReader(object):
             nv = self._lib.sh_reader_next(self._h, self.block_size, bits.ctypes.data_as(abi.c_u8p), self.row_bytes,
                                           counts.ctypes.data_as(C.POINTER(C.c_int32)), self._names, len(self._names),
                                           self._off.ctypes.data_as(C.POINTER(C.c_int64)))
+            if nv == -2:                                   # long names (unitigs): nothing was consumed, retry with room for them
+                self._names = C.create_string_buffer(int(self._lib.sh_reader_names_needed(self._h)) * 2 + 1024)
+                continue
             if nv < 0:
                 raise IOError(self._lib.sh_reader_error().decode())
             if nv == 0:

@@ -86,3 +86,43 @@ def test_packed_cache_round_trip(tmp_path):
             assert [b.names_blob[b.name_off[i]:b.name_off[i + 1]].decode() for i in range(len(b.names))] == b.names
     with pytest.raises(ValueError):
         list(iter_packed_blocks_cached(p.iloc[::-1], path, 0.01, 0.99, 64))
+
+
+def test_buffer_stays_bounded_over_many_blocks(tmp_path):
+    """The reader releases consumed text: whatever the file size, it buffers at most one block of lines plus one 8 MB read slab (it used
+    to keep the whole inflated file; the reference streams line by line, pyseer/input.py:301-454)."""
+    samples = ["sample%04d" % i for i in range(400)]
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "big.txt")
+    nlines = 6000
+    with open(path, "w") as fh:
+        for v in range(nlines):
+            carriers = np.nonzero(rng.random(400) < 0.5)[0]
+            fh.write("K%06d | %s\n" % (v, " ".join("%s:1" % samples[i] for i in carriers)))
+    size = os.path.getsize(path)
+    assert size > 12 << 20                                       # more than one read slab, so a leak would show
+    r = NativeKmerReader(path, samples, 100)
+    peak, total = 0, 0
+    for bits, counts, blob, off in r.raw_blocks():
+        total += counts.shape[0]
+        peak = max(peak, int(r._lib.sh_reader_buffered(r._h)))
+    assert total == nlines
+    assert peak <= (8 << 20) + 2 * (100 * (size // nlines + 64)) + (1 << 16), (peak, size)
+
+
+def test_long_variant_names_grow_the_names_buffer(tmp_path):
+    """Unitig input: names of tens of kilobases.  A block whose names exceed the buffer is refused without being consumed (-2) and
+    retried with a larger buffer; nothing is lost or reordered."""
+    samples = ["s%d" % i for i in range(20)]
+    rng = np.random.default_rng(4)
+    names = ["".join(rng.choice(list("ACGT"), int(n))) for n in (5, 40000, 7, 90000, 31, 12, 65000)]
+    path = str(tmp_path / "unitigs.gz")
+    with gzip.open(path, "wt") as fh:
+        for i, nm in enumerate(names):
+            fh.write("%s | s%d:1 s%d:1\n" % (nm, i, i + 1))
+    r = NativeKmerReader(path, samples, 3, max_name=16)          # 48 bytes of names buffer to start with
+    got = []
+    for nm, bits, counts in r:
+        got += nm
+        assert (counts == 2).all()
+    assert got == names
