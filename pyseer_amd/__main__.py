@@ -220,7 +220,10 @@ def main(argv=None):
         return ShardedEngine(n, devs)
     if options.lmm:
         sys.stderr.write("Setting up LMM\n")
+        # lineage_samples = p.index as the reference passes it (__main__.py:403, 455-456): a similarity matrix over another set of
+        # samples is refused here, before p is cut down to it and the lineage design goes out of step with the phenotype
         p, lmm, h2 = initialise_lmm(p, cov, options.similarity, options.load_lmm, options.save_lmm,
+                                    lineage_samples=(p.index if options.lineage else None),
                                     use_gpu=not options.cpu_eigh, device=options.gpu)
         sys.stderr.write("h^2 = " + '{0:.2f}'.format(h2) + "\n")
         eng = make_engine(len(p))

@@ -154,7 +154,12 @@ class Engine(object):
     # ---- lineage effect ------------------------------------------------------------------------
     def lineage_setup(self, lin, cov=None):
         """lin (n, l): MDS components or cluster indicators; cov (n, j) or None (model.py:151-199)."""
-        lin = np.ascontiguousarray(np.asarray(lin, dtype=np.float64).reshape(self.n, -1))
+        lin = np.asarray(lin, dtype=np.float64)
+        if lin.ndim == 1:
+            lin = lin.reshape(-1, 1)
+        if lin.ndim != 2 or lin.shape[0] != self.n:                # never reshape a design of another sample count into this one
+            raise AssertionError("lineage design has %s rows, the engine %d samples" % (lin.shape[0] if lin.ndim else 0, self.n))
+        lin = np.ascontiguousarray(lin)
         j = 0
         covp = None
         if cov is not None and np.size(cov) and np.asarray(cov).shape[0] == self.n:

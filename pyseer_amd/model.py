@@ -241,17 +241,26 @@ def fixed_effects_regression(variant, p, k, m, c, af, pattern, lineage_effects, 
     if p is None:                                                         # model.py:255-260
         return Seer(variant, pattern, af, np.nan, np.nan, np.nan, np.nan, np.nan, np.array([]), None,
                     kstrains, nkstrains, {'af-filter'}, True, False)
+    k = np.asarray(k)
+    if np.isnan(k.astype(float)).any():
+        # missing calls never reach the GPU.  The reference prefilters first (model.py:262-271: NaN falls in no cell of the 2x2
+        # table / in neither Welch group) and only then meets statsmodels' MissingDataError (model.py:371-377)
+        pv = np.asarray(getattr(p, "values", p), dtype=float).reshape(-1)
+        prep, bad = host_pre_filtering(pv, k.astype(float).reshape(-1), continuous)
+        notes = {'bad-chisq'} if bad else set()
+        if prep > pret or not np.isfinite(prep):
+            notes.add('pre-filtering-failed')
+            return Seer(variant, pattern, af, prep, np.nan, np.nan, np.nan, np.nan, np.array([]), None, kstrains, nkstrains,
+                        notes, True, False)
+        notes.add('missing-data-error')
+        return Seer(variant, pattern, af, prep, np.nan, np.nan, np.nan, np.nan, np.array([]), None, kstrains, nkstrains,
+                    notes, False, True)
     key = (id(p), id(m), id(c), bool(continuous), float(pret), float(lrtt), id(null_res), repr(null_firth))
     fe = _cache.get(key)
     if fe is None:
         _cache.clear()
         fe = FixedEffects(p, m, c, continuous, pret, lrtt, null_res, null_firth)
         _cache[key] = fe
-    k = np.asarray(k)
-    if np.isnan(k.astype(float)).any():                                   # statsmodels MissingDataError, model.py:371-377
-        prep = np.nan
-        return Seer(variant, pattern, af, prep, np.nan, np.nan, np.nan, np.nan, np.array([]), None, kstrains, nkstrains,
-                    {'missing-data-error'}, False, True)
     bits = pack_variants(k.reshape(1, -1))
     r = fe.batch(bits)
     s = seer_from_row(r, 0, variant, pattern, af, kstrains, nkstrains)

@@ -52,3 +52,22 @@ def test_fit_null_degenerate_designs_match_reference():
         assert r is not None and abs(r.llf - float(d["llf_" + name])) < 1e-8, name
     assert fit_null(p, m, e, False, firth=True) == pytest.approx(float(d["firth_ok"]), rel=1e-9)
     assert fit_null(p, np.c_[m, np.ones(n)], e, False, firth=True) == -np.inf
+
+
+def test_missing_calls_follow_the_reference_order_of_checks():
+    """A variant with missing calls (NaN in k) through the by-name drop-in: prefilter first, then the MissingDataError return
+    (pyseer/model.py:262-271, 371-377).  Expected values recorded from the reference (tests/golden/make_missing_golden.py).  No GPU:
+    such variants never reach the engine."""
+    import json
+    import os
+    import pandas as pd
+    from pyseer_amd.model import fixed_effects_regression
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "missing_data.json")))
+    assert len(d["cases"]) == 8
+    for c in d["cases"]:
+        p = np.array(c["p"]); k = np.array([np.nan if x is None else x for x in c["k"]]); m = np.array(c["m"])
+        cov = pd.DataFrame(np.zeros((len(p), 0)))
+        s = fixed_effects_regression("v", p, k, m, cov, 0.4, b"x", False, None, c["pret"], 1.0, None, None, [], [], c["continuous"])
+        assert sorted(s.notes) == c["notes"] and s.prefilter == c["prefilter"] and s.filter == c["filter"]
+        assert abs(s.prep - c["prep"]) <= 1e-12 * abs(c["prep"])
+        assert np.isnan(s.pvalue) and np.isnan(s.kbeta) and s.max_lineage is None
