@@ -7,10 +7,7 @@ __host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + 
 
 #include "glm_params.h"
 
-// Firth step halving (model.py:467-474): an increase of F within four ulp of F is evaluation noise (F sums N terms), and halving on it is a
-// coin flip in the reference too -- the step is ~1e-7 or smaller by then.  It is not treated as an increase, which saves the rounds that
-// only serviced such flips (case 1).
-#define FIRTH_F_NOISE 8.9e-16
+// Firth step halving: the two noise rules of the default mode are GlmParams.firth_noise / firth_accept (glm_params.h)
 
 __device__ __forceinline__ double logit_cdf(double x) { return 1.0 / (1.0 + exp(-x)); }    // SM Logit.cdf
 

@@ -715,9 +715,9 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
             // F(new) > F(old) is decided by rounding noise once the step is ~1e-7 (|dF| ~ step^2 << ulp(F)); the reference then
             // flips coins until one lands (moving beta by < 1e-10) or, rarely, exhausts step_limit on a 1-ulp tie.  Accept such
             // steps outright: same result to 1e-10, no spurious 'firth-fail', no 50-pass stalls of the whole wavefront.
-            const bool noise_step = stepmax < 1e-10;
+            const bool noise_step = stepmax < P.firth_accept;
             if (state == 3) {
-            } else if (Fcand > Fcur + FIRTH_F_NOISE * fabs(Fcur) && !noise_step) {    // step halving, model.py:467-474
+            } else if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !noise_step) {    // step halving, model.py:467-474
 #pragma unroll
                 for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
                 if (++halvings > 1000) { failed = true; state = 3; }
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
             stepmax = fmax(stepmax, fabs(d)); sn = fma(d, d, sn);
         }
         // see k_glm_firth: steps below 1e-10 are accepted outright (F(new) > F(old) is rounding noise there)
-        if (Fcand > Fcur + FIRTH_F_NOISE * fabs(Fcur) && !(stepmax < 1e-10)) {   // step halving, model.py:467-474
+        if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !(stepmax < P.firth_accept)) {   // step halving, model.py:467-474
             accept = false;
             const int h = fw.halv[s] + 1;
             fw.halv[s] = h;
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
                         double stepmax = 0.0, sn = 0.0;
                         for (int a = 0; a < PC; ++a) { const double d = s_cand[a] - s_beta[a]; stepmax = fmax(stepmax, fabs(d)); sn = fma(d, d, sn); }
                         bool failed = false, conv = false;
-                        if (Fcand > Fcur + FIRTH_F_NOISE * fabs(Fcur) && !(stepmax < 1e-10)) {   // step halving, model.py:467-474
+                        if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !(stepmax < P.firth_accept)) {   // step halving, model.py:467-474
                             if (++halv > 1000) failed = true;
                             else { for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); s_ctl = 0; }
                         } else {
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_glm_firth_pinv(const uint64_t *__restri
                 blk_info<PC>(T, Vpad, v, N, y, W, s_cand, I, &ll, s_red, tid);
                 if (tid == 0) {
                     Fcand = -(ll + 0.5 * log(slow_det<PC>(I)));
-                    if (!(Fcand > Fcur + FIRTH_F_NOISE * fabs(Fcur))) s_ctl = 1;
+                    if (!(Fcand > Fcur + P.firth_noise * fabs(Fcur))) s_ctl = 1;
                     else if (++halvings > 1000) { failed = true; s_ctl = 2; }
                     else { for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); s_ctl = 0; }
                 }

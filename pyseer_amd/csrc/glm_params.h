@@ -16,4 +16,10 @@ struct GlmParams {
     const double *ztz, *zty;      // Z^T Z (packed lower, (q+1) x (q+1)) and Z^T y for Z = [1, W]: the variant-independent part of the OLS normal equations
     int firth_handoff;            // accepted Firth steps after which a variant leaves the rounds for k_firth_blk (SEERHIP_FIRTH_HANDOFF)
     int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
+    // Firth step halving (model.py:465-474).  Default: an increase of F within firth_noise * |F| (4 ulp) is evaluation noise, and a step
+    // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_FIRTH_STRICT=1 sets both to 0: the reference's
+    // literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
+    double firth_noise, firth_accept;
 };
+#define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
+#define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */

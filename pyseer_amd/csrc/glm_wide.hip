@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_firth_blk(const uint64_t *__re
                 Fcand = -(ll + 0.5 * logdet());
                 double stepmax = 0.0;
                 for (int a = 0; a < pc; ++a) stepmax = fmax(stepmax, fabs(s_cand[a] - s_beta[a]));
-                if (!(Fcand > Fcur + FIRTH_F_NOISE * fabs(Fcur)) || stepmax < 1e-10) break;   // noise steps accepted outright, see k_glm_firth
+                if (!(Fcand > Fcur + P.firth_noise * fabs(Fcur)) || stepmax < P.firth_accept) break;   // noise steps accepted outright, see k_glm_firth
                 __syncthreads();
                 if (tid < pc) s_cand[tid] = s_beta[tid] + 0.5 * (s_cand[tid] - s_beta[tid]);
                 __syncthreads();
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(64) void k_glm_wide_firth(const uint64_t *__restric
 #pragma unroll 1
             for (int a = 0; a < pc; ++a) stepmax = fmax(stepmax, fabs(cand[a] - beta[a]));
             // steps below 1e-10 are accepted outright: F(new) > F(old) is rounding noise there (see k_glm_firth)
-            if (!(Fcand > Fcur + FIRTH_F_NOISE * fabs(Fcur)) || stepmax < 1e-10) break;       // step halving, model.py:467-474
+            if (!(Fcand > Fcur + P.firth_noise * fabs(Fcur)) || stepmax < P.firth_accept) break;       // step halving, model.py:467-474
 #pragma unroll 1
             for (int a = 0; a < pc; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
             if (++halvings > 1000) { failed = true; break; }
