@@ -90,6 +90,10 @@ int     sh_set_af_filter(sh_ctx *ctx, double min_af, double max_af);
  * ------------------------------------------------------------------------------------------- */
 int sh_lmm_setup(sh_ctx *ctx, const double *U, const double *S, int k, const double *y,
                  const double *C, int D, double h2, int continuous, double pret, double lrtt, int n_limbs);
+/* Multi-GPU (the counterpart of the reference's --cpu N workers sharing one LMM object, pyseer/__main__.py:541-568):
+ * copy the per-run LMM state of `src` (after sh_lmm_setup) device-to-device into `dst`, a context on another (or the same) device with
+ * the same n_samples.  One set-up per run instead of one per GPU; the per-variant path has no inter-GPU traffic at all. */
+int sh_lmm_share(sh_ctx *dst, sh_ctx *src);
 /* per variant: prep, pvalue, beta, bse, frac_h2 (each V doubles) + flags.  Statistics are written for every
  * variant that passes the AF filter (the caller applies the NaN masking implied by flags, lmm.py:176-217). */
 int sh_lmm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,

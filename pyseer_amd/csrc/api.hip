@@ -57,6 +57,7 @@ struct sh_ctx {
     uint64_t *d_y1 = nullptr, *d_y0 = nullptr;
     int8_t *d_G = nullptr;
     double quant_scale = 0.0;
+    size_t g_bytes = 0, tab_doubles = 0;
     int E = 0;                    // extra (low) limbs stored below the L of the main pass; contracted only for variants whose bound exceeds lmm_tol
     bool complement = false;      // rows with more than N/2 carriers are stored complemented (needs the intercept in the covariate span)
     double err_norm_ulp = 0.0, lmm_tol = 1e-8, trace_M = 0.0;
@@ -540,7 +541,8 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     HIPCHK(hipMemsetAsync(d_M, 0, sizeof(double) * (size_t)Np * Np, st));
     HIPCHK(dmalloc(&d_Ef, (size_t)Np * Np)); HIPCHK(dmalloc(&d_px, Np)); HIPCHK(dmalloc(&d_py, Np)); HIPCHK(dmalloc(&d_nrm, NPOW));
     HIPCHK(shk_lmm_build_G(st, d_W, d_sgn, N, Np, kp, NR, Lt, E, d_M, c->d_mdiag, d_amax, c->d_G, d_Ef, d_px, d_py, d_nrm, NPOW));
-    HIPCHK(dmalloc(&c->d_tab, (size_t)c->NB64 * 256 * (2 + 2 + 8)));          // up to 12 doubles per nibble entry
+    c->tab_doubles = (size_t)c->NB64 * 256 * (2 + 2 + 8); c->g_bytes = gbytes;
+    HIPCHK(dmalloc(&c->d_tab, c->tab_doubles));                                // up to 12 doubles per nibble entry
     HIPCHK(shk_lmm_build_tab(st, c->d_vv, c->d_mdiag, c->d_yc, c->d_Qb, DP, continuous, N, c->NB64, c->d_tab));
     unsigned long long amax_bits = 0;
     HIPCHK(hipMemcpyAsync(&amax_bits, d_amax, sizeof(amax_bits), hipMemcpyDeviceToHost, st));
@@ -577,6 +579,39 @@ int sh_lmm_info(sh_ctx *c, int *n_limbs, int64_t *macs, double *qscale)
     // executed int8 MACs per variant in k_lmm_quadform_i8: L * sum_I 2(I+1) tiles * (128 rows * 64), NR = 2*NT row tiles
     if (macs) *macs = (int64_t)c->L * (2 * c->NT) * (2 * c->NT + 1) * 128 * 64;
     if (qscale) *qscale = c->quant_scale;
+    return SH_OK;
+}
+
+// The per-run LMM state of `src` (limbs of G, v, diag M, nibble tables, covariate basis, phenotype masks and every scalar) copied device
+// to device into `dst`: one sh_lmm_setup per run instead of one per GPU ("optional set-up time broadcast").  94 MB at
+// N = 5000 over xGMI or within one device; no collective, nothing on the data path.
+int sh_lmm_share(sh_ctx *dst, sh_ctx *src)
+{
+    if (!dst || !src || !src->lmm_ready) return fail(SH_EINVAL, "sh_lmm_share: the source context has no LMM set-up");
+    if (dst == src) return SH_OK;
+    if (dst->N != src->N) return fail(SH_ESHAPE, "sh_lmm_share: contexts of different sample counts");
+    HIPCHK(hipSetDevice(src->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    HIPCHK(hipSetDevice(dst->device));
+    sh_ctx *c = dst;
+    const int N = c->N;
+    hipFree(c->d_vv); hipFree(c->d_mdiag); hipFree(c->d_yc); hipFree(c->d_Qb); hipFree(c->d_y1); hipFree(c->d_y0); hipFree(c->d_G); hipFree(c->d_tab);
+    c->d_vv = c->d_mdiag = c->d_yc = c->d_Qb = c->d_tab = nullptr; c->d_y1 = c->d_y0 = nullptr; c->d_G = nullptr; c->lmm_ready = false;
+    HIPCHK(dmalloc(&c->d_vv, N)); HIPCHK(dmalloc(&c->d_mdiag, N)); HIPCHK(dmalloc(&c->d_yc, N));
+    HIPCHK(dmalloc(&c->d_y1, c->NB64p)); HIPCHK(dmalloc(&c->d_y0, c->NB64p));
+    if (src->DP) HIPCHK(dmalloc(&c->d_Qb, (size_t)N * src->DP));
+    HIPCHK(hipMalloc((void **)&c->d_G, src->g_bytes)); HIPCHK(dmalloc(&c->d_tab, src->tab_doubles));
+    auto cp = [&](void *d, const void *s_, size_t n) { return hipMemcpyPeerAsync(d, dst->device, s_, src->device, n, dst->stream); };
+    HIPCHK(cp(c->d_vv, src->d_vv, sizeof(double) * N)); HIPCHK(cp(c->d_mdiag, src->d_mdiag, sizeof(double) * N));
+    HIPCHK(cp(c->d_yc, src->d_yc, sizeof(double) * N));
+    HIPCHK(cp(c->d_y1, src->d_y1, sizeof(uint64_t) * c->NB64p)); HIPCHK(cp(c->d_y0, src->d_y0, sizeof(uint64_t) * c->NB64p));
+    if (src->DP) HIPCHK(cp(c->d_Qb, src->d_Qb, sizeof(double) * (size_t)N * src->DP));
+    HIPCHK(cp(c->d_G, src->d_G, src->g_bytes)); HIPCHK(cp(c->d_tab, src->d_tab, sizeof(double) * src->tab_doubles));
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    c->k = src->k; c->D = src->D; c->L = src->L; c->DP = src->DP; c->E = src->E; c->complement = src->complement;
+    c->quant_scale = src->quant_scale; c->err_norm_ulp = src->err_norm_ulp; c->trace_M = src->trace_M; c->lmm_tol = src->lmm_tol;
+    c->g_bytes = src->g_bytes; c->tab_doubles = src->tab_doubles; c->fin = src->fin;
+    c->lmm_ready = true;
     return SH_OK;
 }
 

@@ -92,6 +92,10 @@ class Engine(object):
             raise KeyError("beta")                                           # lmm_test.py:416-417
         _abi.check(rc)
 
+    def lmm_share_from(self, other):
+        """Take the per-run LMM state of `other` (an Engine after lmm_setup, any device) by a device-to-device copy."""
+        _abi.check(self._lib.sh_lmm_share(self._h, other._h))
+
     def lmm_info(self):
         nl = C.c_int(); macs = C.c_int64(); qs = C.c_double()
         _abi.check(self._lib.sh_lmm_info(self._h, C.byref(nl), C.byref(macs), C.byref(qs)))

@@ -557,3 +557,41 @@ def test_more_than_8192_samples_repack_fallback(engine_mod):
     for v in range(0, V, 13):
         pr, bad = orc.pre_filtering(y, Kv[v].astype(float), False)
         close(r["prep"][v], pr)
+
+
+def test_lmm_state_shared_between_contexts(engine_mod):
+    """sh_lmm_share: a second context that received the per-run state device-to-device gives bit-identical results (covariates,
+    complemented rows and the extra-limb pass included); sharing before set-up is refused."""
+    Engine, pack = engine_mod
+    from pyseer_amd import _abi
+    U, S, covar, y, Kv = _random_lmm(515, 3, 61, 300)
+    a = Engine(515); b = Engine(515)
+    with pytest.raises(_abi.SeerHipError):
+        b.lmm_share_from(a)
+    a.set_af_filter(0.01, 0.99); b.set_af_filter(0.01, 0.99)
+    a.lmm_setup(U, S, y, covar, 0.41, n_limbs=4); a.set_lmm_tol(1e-10)
+    b.lmm_share_from(a)
+    ra = a.lmm_batch(pack(Kv)); rb = b.lmm_batch(pack(Kv))
+    assert a.lmm_info()["refined_last_batch"] == b.lmm_info()["refined_last_batch"] > 0
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k], equal_nan=True), k
+    a.close(); b.close()
+
+
+def test_sharded_engine_across_real_devices(engine_mod):
+    """ShardedEngine over every visible GPU (skipped on a one-GPU box): same numbers as one context, input order kept."""
+    Engine, pack = engine_mod
+    import torch
+    from pyseer_amd.parallel import ShardedEngine
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("one GPU visible")
+    d = np.load(os.path.join(G, "lmm_N300_D3.npz"))
+    bits = pack(np.tile(d["Kv"], (40, 1))[:2001])
+    e = Engine(300); e.lmm_setup(d["U"], d["S"], d["y"], d["covar"], float(d["h2"]))
+    want = e.lmm_batch(bits); e.close()
+    s = ShardedEngine(300, list(range(nd)))
+    s.lmm_setup(d["U"], d["S"], d["y"], d["covar"], float(d["h2"]))
+    got = s.lmm_batch(bits); s.close()
+    for k in want:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
