@@ -337,7 +337,14 @@ __device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, i
         double eta = beta[0] + (xb ? beta[1] : 0.0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], W[(int64_t)i * Q + j], eta);
+        // eta and the score sums in fp64, the logistic function itself in fp32 (v_exp_f32 + v_rcp_f32 instead of ~45 fp64 operations): each mu
+        // carries an independent ~6e-8 relative rounding, the score its sum over N (~5e-6 against a Hessian ~N/5): beta to ~1e-8, which the
+        // final pass' exact fp64 Newton step absorbs.  -DGLM_MU64 builds the fp64 evaluation instead (A/B).
+#ifdef GLM_MU64
         const double mu = 1.0 / (1.0 + exp(-eta));
+#else
+        const double mu = (double)(1.0f / (1.0f + __expf(-(float)eta)));
+#endif
         const double r = y[i] - mu;
         maxdev = fmax(maxdev, fabs(r));
         g[0] += r; g[1] += xb ? r : 0.0;
@@ -415,7 +422,7 @@ __device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, i
 }
 
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
-struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; };
+struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *tile_list; int *tile_count; };
 
 // ---- kernel 1: a1 prefilter + routing + phase A (fast Newton) ---------------------------------------------------------------
 template <int Q>
@@ -451,8 +458,23 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
 #pragma unroll
     for (int a = 0; a < PC; ++a) beta[a] = 0.0;
     beta[0] = P.ymean_logit;
+    if (P.warm_on) {                                                 // null-model MLE (glm_params.h): [b0, 0, bz] in this phase's coordinates
+        beta[0] = P.warm[0];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) beta[2 + j] = P.warm[1 + j];
+    }
     bool need_slow = want_fit && (P.newton_mode == 1);
     bool active = want_fit && !need_slow;
+    // tile mode (glm_tile.hip): this kernel only classifies; the fits run 16 variants per wavefront on the matrix pipe, from a dense list
+    const bool to_tile = active && P.tile_mode;
+    if (P.tile_mode) {
+        active = false;
+        const unsigned long long tm = __ballot(to_tile);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && tm) base = atomicAdd(wk.tile_count, __popcll(tm));
+        base = __shfl(base, 0);
+        if (to_tile) wk.tile_list[base + __popcll(tm & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)v;
+    }
     int it = 0, pass = 0;
     // Newton's iteration is affine invariant, so this phase runs on covariates standardised per column (Wf and the products table
     // are built from them too): a column like "year of isolation" (2000 +- 10) would otherwise defeat the fp32 Hessian and send every
@@ -486,22 +508,33 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
                     ldl_solve<PC>(A, g);
                     bool moving = false, finite = true;
 #pragma unroll
-                    for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); finite = finite && isfinite(beta[a]); }
+                    for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > P.fast_tol); finite = finite && isfinite(beta[a]); }
                     ++it;
                     if (!finite) { need_slow = true; active = false; }
-                    else if (!moving && !(f32 && P.zz)) active = false;                             // converged (fp64 score only)
+                    else if (f32 && P.zz) {                                                         // single-precision pass: its own stopping rule
+                        double stp = 0.0;
+#pragma unroll
+                        for (int a = 0; a < PC; ++a) stp = fmax(stp, fabs(g[a]));
+                        if (stp <= P.f32_tol) active = false;
+                        else if (it >= 12) { need_slow = true; active = false; }
+                    }
+                    else if (!moving) active = false;                                               // converged (fp64 score)
                     else if (it >= 12) { need_slow = true; active = false; }
                 }
             }
         }
+    }
+    if (P.dbg) {
+        if (threadIdx.x == 0) { atomicAdd(&P.dbg[0], pass); atomicAdd(&P.dbg[1], 1); }
+        if (want_fit && live) { atomicAdd(&P.dbg[2], it); atomicAdd(&P.dbg[3], 1); }
     }
     if (!live) return;
     out[v] = prep; out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
 #pragma unroll
     for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
     flags[v] = fl;
-    wk.state[v] = (want_fit && !need_slow) ? 1 : 0;
-    if (want_fit && !need_slow) {
+    wk.state[v] = (want_fit && !need_slow && !to_tile) ? 1 : 0;
+    if (want_fit && !need_slow && !to_tile) {
         if (P.ws) {                                                  // z' = (z - mean) / scale  =>  b = b' / scale, b0 = b0' - sum b' mean / scale
 #pragma unroll
             for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
@@ -591,23 +624,42 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     for (int a = 0; a < PC; ++a) beta[a] = fin ? wk.bw[(int64_t)a * Vpad + vr] : 0.0;
     int status = 0;
     double llf = NAN, bse1 = NAN;
-    if (fin) {
-        double H[PC * (PC + 1) / 2], dummy[PC], ll, maxdev;
-        info_pass<Q, false, true>(T, Vpad, vr, N, NB64, y, W, beta, H, dummy, ll, maxdev, true);
-        if (maxdev <= 1e-8) status = 1;                                                          // callback after the last update
-        else {
-            llf = ll;
-            // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534); only bse[1] is used (model.py:332)
-#pragma unroll
-            for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
-            double det;
-            if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
+    // The fast phase hands over a beta whose last step was <= P.fast_tol.  This pass evaluates llf, the separation callback and the
+    // information matrix there in fp64 AND the score, and takes the exact Newton step (no ridge, fp64 Hessian): quadratic from ~1e-7, i.e.
+    // the fixed point itself.  Should that step exceed 5e-7 (llf and bse[1] are evaluated BEFORE the step: at 5e-7 they are still good to
+    // ~5e-7 relative), the pass is repeated at the stepped beta, so what is reported always satisfies the reference's stopping rule.
+    bool redo = fin;
+    for (int rep = 0; rep < 6 && __any(redo); ++rep) {
+        if (redo) {
+            double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
+            info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev, true);
+            redo = false;
+            status = 0;
+            if (maxdev <= 1e-8) status = 1;                                                      // callback after the last update
             else {
-                double e[PC];
+                llf = ll;
+                // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534); only bse[1] is used (model.py:332)
 #pragma unroll
-                for (int a = 0; a < PC; ++a) e[a] = (a == 1) ? 1.0 : 0.0;
-                ldl_solve<PC>(H, e);
-                bse1 = sqrt(e[1] / nobs);
+                for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
+                double det;
+                if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
+                else {
+                    double e[PC];
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) { e[a] = (a == 1) ? 1.0 : 0.0; g[a] = g[a] / nobs; }
+                    ldl_solve<PC>(H, e);
+                    bse1 = sqrt(e[1] / nobs);
+                    ldl_solve<PC>(H, g);
+                    double smax = 0.0; bool finite = true;
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) { smax = fmax(smax, fabs(g[a])); finite = finite && isfinite(g[a]); }
+                    if (finite) {
+#pragma unroll
+                        for (int a = 0; a < PC; ++a) beta[a] += g[a];
+                        redo = smax > 5e-7;
+                        if (redo && P.dbg) atomicAdd(&P.dbg[4], 1);
+                    }
+                }
             }
         }
     }
@@ -1814,9 +1866,9 @@ extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uin
                                      const double *y, const double *W, const float *Wf, const uint64_t *y1, const uint64_t *y0,
                                      const double *yc, const double *ZtZ, const double *Zty, GlmParams P, double *out,
                                      uint32_t *flags, int *flist, int *fcount, int *plist, int *pcount, double *bw, int *state,
-                                     int *slow_list, int *slow_count)
+                                     int *slow_list, int *slow_count, int *tile_list, int *tile_count)
 {
-    GlmWork wk{bw, state, slow_list, slow_count};
+    GlmWork wk{bw, state, slow_list, slow_count, tile_list, tile_count};
 #define GLM_CASE(q) case q: return launch_glm<q>(st, which, T, Vpad, V, y, W, Wf, y1, y0, yc, ZtZ, Zty, P, out, flags, flist, fcount, plist, pcount, wk);
     switch (Q) {
         GLM_CASE(0) GLM_CASE(1) GLM_CASE(2) GLM_CASE(3) GLM_CASE(4) GLM_CASE(5) GLM_CASE(6) GLM_CASE(7)

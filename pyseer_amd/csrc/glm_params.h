@@ -20,6 +20,16 @@ struct GlmParams {
     // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_FIRTH_STRICT=1 sets both to 0: the reference's
     // literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
     double firth_noise, firth_accept;
+    // Warm start of the fast Newton phase: the maximum-likelihood fit WITHOUT the variant column, [b0, bz...] in the coordinates that phase
+    // iterates in (standardised covariates), computed once per run (sh_glm_setup).  The likelihood is concave, so the iteration reaches the
+    // same fixed point as from the reference's start vector (model.py:323-324) in about half the steps; anything that does not converge
+    // cleanly is restarted by k_glm_slow from the reference's start vector on the reference's trajectory, as before.  warm_on = 0: off.
+    int warm_on;
+    double warm[16];
+    int tile_mode;                // 1: k_glm_fast only classifies and lists; the Newton fits run in k_glm_tile (glm_tile.hip)
+    int *dbg;                     // development counters (SEERHIP_GLM_DEBUG): [0] wave passes, [1] waves, [2] lane steps, [3] fitted lanes, [4] final-pass repeats
+    double f32_tol;               // a single-precision pass whose step is <= f32_tol ends the fast phase (the fp32 score's noise floor is ~1e-7)
+    double fast_tol;              // largest step (any coordinate) at which the fast phase hands over to the final pass' exact Newton step
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
 #define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */
