@@ -849,14 +849,20 @@ __global__ __launch_bounds__(64) void k_firth_init(const int *__restrict__ firth
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s == 0) *eval_count = cnt;
     if (s >= cnt) return;
+    // Start vector: the reference's (model.py:323-324), or -- Firth on every variant (force_firth) -- the null-model fit (GlmParams.fwarm).
+    // fit_firth stops one iteration AFTER a step below 1e-4 (model.py:477-479) and contracts by ~p/N per iteration, so at large N (the only
+    // case that sets firth_warm, see sh_glm_setup) the start shows in the result below 1e-7.  Where it converges slowly the path matters
+    // more: a variant still iterating FIRTH_WARM_LIMIT accepted steps after a warm start is restarted from the reference's vector.
+    // A warm slot is marked by the complemented variant index in fw.var.
+    const bool warm = P.firth_warm != 0;
 #pragma unroll
     for (int a = 0; a < PC; ++a) {
-        const double b0 = (a == 0) ? P.ymean_logit : 0.0;                    // start vector, model.py:323-324
+        const double b0 = warm ? ((a == 0) ? P.fwarm[0] : (a == 1) ? 0.0 : P.fwarm[a - 1]) : ((a == 0) ? P.ymean_logit : 0.0);
         fw.st[(int64_t)(fw_beta<PC>() + a) * fw.cap + s] = b0;
         fw.st[(int64_t)(fw_cand<PC>() + a) * fw.cap + s] = b0;
     }
     fw.st[(int64_t)fw_snp<PC>() * fw.cap + s] = INFINITY;
-    fw.iter[s] = -1; fw.halv[s] = 0; fw.var[s] = firth_list[s];
+    fw.iter[s] = -1; fw.halv[s] = 0; fw.var[s] = warm ? ~firth_list[s] : firth_list[s];
     eval_list[s] = s;
 }
 
@@ -878,7 +884,9 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
     const int li = blockIdx.x * 64 + xw.lane;
     const bool live = li < cnt;
     const int s = eval_list[live ? li : 0];
-    const int64_t v = fw.var[s];
+    const int vraw = fw.var[s];
+    const bool warm = vraw < 0;
+    const int64_t v = warm ? ~vraw : vraw;
     const int64_t cap = fw.cap;
     double cand[PC], A[PC * (PC + 1) / 2], dummy[PC];
 #pragma unroll
@@ -930,6 +938,18 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
             if (!conv && iter >= 1000) failed = true;                // step_limit exhausted, model.py:482-484
         }
     }
+    if (accept && !failed && !conv && warm && iter >= FIRTH_WARM_LIMIT) {   // not a quadratic convergence: the reference's own path decides
+#pragma unroll
+        for (int a = 0; a < PC; ++a) {
+            const double b0 = (a == 0) ? P.ymean_logit : 0.0;
+            fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s] = b0;
+            fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = b0;
+        }
+        fw.st[(int64_t)fw_snp<PC>() * cap + s] = INFINITY;
+        fw.iter[s] = -1; fw.halv[s] = 0; fw.var[s] = (int)v;
+        next_eval[atomicAdd(next_eval_count, 1)] = s;
+        return;
+    }
     if (accept && !failed && !conv) {                                // beta <- cand; keep the factor for the score pass
 #pragma unroll
         for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s] = cand[a];
@@ -974,7 +994,7 @@ __global__ __launch_bounds__(512) void k_firth_step(const uint64_t *__restrict__
     const int li = blockIdx.x * 64 + xw.lane;
     const bool live = li < cnt;
     const int s = step_list[live ? li : 0];
-    const int64_t v = fw.var[s];
+    const int64_t v = fw.var[s] < 0 ? ~fw.var[s] : fw.var[s];
     const int64_t cap = fw.cap;
     const int N = P.N, NB64 = P.NB64;
     double beta[PC], A[PC * (PC + 1) / 2], U[PC], dinv[PC];
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
     const int64_t cap = fw.cap;
     for (int idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int s = fw.blk_list[idx];
-        const int64_t v = fw.var[s];
+        const int64_t v = fw.var[s] < 0 ? ~fw.var[s] : fw.var[s];
         double acc[NH + 1];
         // thread-0 state
         double Fcur = 0.0, snp = 0.0;

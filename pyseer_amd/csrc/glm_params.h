@@ -26,6 +26,8 @@ struct GlmParams {
     // cleanly is restarted by k_glm_slow from the reference's start vector on the reference's trajectory, as before.  warm_on = 0: off.
     int warm_on;
     double warm[16];
+    int firth_warm;               // 1: Firth rounds start at fwarm = the null-model fit [b0, bz...] in the ORIGINAL covariate coordinates (force_firth only)
+    double fwarm[16];
     int tile_mode;                // 1: k_glm_fast only classifies and lists; the Newton fits run in k_glm_tile (glm_tile.hip)
     int *dbg;                     // development counters (SEERHIP_GLM_DEBUG): [0] wave passes, [1] waves, [2] lane steps, [3] fitted lanes, [4] final-pass repeats
     double f32_tol;               // a single-precision pass whose step is <= f32_tol ends the fast phase (the fp32 score's noise floor is ~1e-7)
@@ -33,3 +35,4 @@ struct GlmParams {
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
 #define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */
+#define FIRTH_WARM_LIMIT 7         /* accepted steps after which a warm-started Firth fit is restarted from the reference's start vector */
