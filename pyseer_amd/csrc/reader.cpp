@@ -4,7 +4,7 @@
 // Replaces the per-line Python of pyseer/input.py:301-454 (read_variant, k-mer branch) for the GPU feed:
 //   var_name = first whitespace token;  strains = segment between the first and the second '|', whitespace-split,
 //   each token cut at ':' (input.py:377-388);  presence over the phenotyped samples in phenotype order (input.py:438-452).
-// One thread inflates (gzip is sequential), lines of a chunk are parsed in parallel (OpenMP).
+// A producer thread decodes the file a few slabs ahead (inflate_fast.h; BGZF member-parallel), lines of a block are parsed in parallel (OpenMP).
 #include <zlib.h>
 #include <cstdio>
 #include <cstdint>
@@ -15,7 +15,16 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include "../../include/seerhip.h"
+#include "inflate_fast.h"
 
 // open-addressing table keyed by the sample name bytes (no per-token allocation; FNV-1a)
 struct NameTable {
@@ -46,18 +55,219 @@ struct NameTable {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Text source: the (memory-mapped) file decoded by a producer thread into slabs, a few slabs ahead of the parser.
+//   plain text      -> slabs are windows of the mapping itself (no copy)
+//   gzip            -> inflate_fast.h on one thread (the format is sequential), ~4x zlib on k-mer text, straight into the slab
+//   BGZF (bgzip)    -> members are independent and announce their compressed size: a slab's worth of members is decoded by an OpenMP
+//                      team, each member by one thread (raw deflate + its own CRC)
+// Every slab is preceded, in the same allocation, by the tail of the text before it (PAD bytes: the decoder's 32 KB history lives there
+// anyway), so a line that straddles two slabs is contiguous in the second one and the parser never copies text.  The CRC-32 of every
+// gzip member is verified by the consumer's OpenMP team over whole slabs (zlib's crc32 + crc32_combine), not by the decoding thread.
+// SEERHIP_READER=zlib selects zlib's gzread instead (A/B, and a fallback should a stream ever disagree).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct MemberEndAt { size_t at; uint32_t crc; };
+struct Slab {
+    const char *data = nullptr; size_t len = 0, pad = 0;       // data[-pad .. len): pad bytes of the preceding text, then this slab's
+    char *mem = nullptr;                                        // owned buffer to recycle (nullptr: a window of the mapping)
+    bool last = false; std::string err;
+    std::vector<MemberEndAt> ends;                              // gzip members that end inside this slab: offset, CRC-32 of the trailer
+};
+
 struct sh_reader {
-    gzFile gz = nullptr;                 // zlib reads plain files transparently as well
+    int fd = -1; const uint8_t *map = nullptr; size_t map_len = 0;
+    gzFile gz = nullptr;                 // SEERHIP_READER=zlib
+    std::vector<char> zbuf;              //   its text (unconsumed part), as in round 1
+    size_t zpos = 0;
     int n = 0;
     NameTable index;
-    std::vector<char> buf;               // unconsumed text
-    size_t pos = 0;                      // first unconsumed byte of buf
     bool eof = false;
     int64_t names_needed = 0;            // bytes of variant names the last refused call (-2) would have written
-    std::string err;
+    // producer
+    std::thread producer;
+    std::mutex mu; std::condition_variable cv_put, cv_get, cv_free;
+    std::deque<Slab> queue; std::vector<char *> free_bufs; std::vector<char *> all_bufs; bool stop = false;
+    size_t slab_bytes = 16u << 20, pad_bytes = 1u << 20, depth = 3;
+    int mode = 0;                        // 0 plain, 1 gzip, 2 BGZF
+    // consumer
+    std::deque<Slab> held; size_t cur = 0; const char *ptr = nullptr;     // slabs in hand, the one being read, next unread byte
+    std::vector<char> bridge;            // a line longer than the pad that straddles two slabs (copied, rare)
+    uint32_t crc_run = 0;
+    ~sh_reader() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_put.notify_all(); cv_get.notify_all(); cv_free.notify_all();
+        if (producer.joinable()) producer.join();
+        for (char *b : all_bufs) free(b);
+        if (map && map_len) munmap((void *)map, map_len);
+        if (fd >= 0) close(fd);
+        if (gz) gzclose(gz);
+    }
 };
 
 static thread_local std::string g_rerr;
+
+static bool put_slab(sh_reader *r, Slab &&sl)
+{
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv_put.wait(lk, [&] { return r->stop || r->queue.size() < r->depth; });
+    if (r->stop) return false;
+    r->queue.push_back(std::move(sl));
+    lk.unlock(); r->cv_get.notify_one();
+    return true;
+}
+
+static char *get_buf(sh_reader *r)                                // nullptr when the reader is being closed
+{
+    std::unique_lock<std::mutex> lk(r->mu);
+    if (r->free_bufs.empty() && r->all_bufs.size() < 64) {        // the consumer may hold many slabs for one large block: grow on demand
+        char *b = (char *)malloc(r->pad_bytes + r->slab_bytes + 1024);
+        if (b) { r->all_bufs.push_back(b); return b; }
+    }
+    r->cv_free.wait(lk, [&] { return r->stop || !r->free_bufs.empty(); });
+    if (r->stop) return nullptr;
+    char *b = r->free_bufs.back(); r->free_bufs.pop_back();
+    return b;
+}
+
+static void release_slab(sh_reader *r, Slab &sl)
+{
+    if (!sl.mem) return;
+    { std::lock_guard<std::mutex> lk(r->mu); r->free_bufs.push_back(sl.mem); }
+    sl.mem = nullptr;
+    r->cv_free.notify_one();
+}
+
+// CRC-32 of [p, p + n) with the caller's OpenMP team: 1 MB pieces, combined in order
+static uint32_t crc_parallel(uint32_t crc, const uint8_t *p, size_t n)
+{
+    const size_t CH = 1u << 20;
+    if (n <= 2 * CH) return (uint32_t)crc32(crc, p, (uInt)n);
+    const int64_t nch = (int64_t)((n + CH - 1) / CH);
+    std::vector<uint32_t> part((size_t)nch);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nch; ++i) {
+        const size_t lo = (size_t)i * CH, len = std::min(CH, n - lo);
+        part[(size_t)i] = (uint32_t)crc32(0L, p + lo, (uInt)len);
+    }
+    for (int64_t i = 0; i < nch; ++i) {
+        const size_t lo = (size_t)i * CH, len = std::min(CH, n - lo);
+        crc = (uint32_t)crc32_combine(crc, part[(size_t)i], (z_off_t)len);
+    }
+    return crc;
+}
+
+static void produce_plain(sh_reader *r)
+{
+    size_t off = 0;
+    for (;;) {
+        Slab sl;
+        sl.len = std::min(r->slab_bytes, r->map_len - off);
+        sl.data = (const char *)r->map + off; sl.pad = std::min(r->pad_bytes, off);
+        off += sl.len; sl.last = off >= r->map_len;
+        const bool last = sl.last;
+        if (!put_slab(r, std::move(sl)) || last) return;
+    }
+}
+
+// tail <- the last (at most cap) bytes of (tail + data)
+static void keep_tail(std::vector<char> &tail, size_t cap, const char *data, size_t len)
+{
+    if (len >= cap) { tail.assign(data + len - cap, data + len); return; }
+    const size_t keep = std::min(tail.size(), cap - len);
+    tail.erase(tail.begin(), tail.end() - keep);
+    tail.insert(tail.end(), data, data + len);
+}
+
+static void produce_gzip(sh_reader *r)
+{
+    const size_t PAD = r->pad_bytes;                               // >= 32 KB: also the decoder's history
+    shinf::Decoder d; d.begin(r->map, r->map + r->map_len);
+    std::vector<char> tail;
+    for (;;) {
+        char *buf = get_buf(r);
+        if (!buf) return;
+        memcpy(buf + PAD - tail.size(), tail.data(), tail.size());
+        uint8_t *const start = (uint8_t *)buf + PAD, *out = start, *const lim = start + r->slab_bytes;
+        const uint8_t *hist = start - tail.size();
+        Slab sl; sl.mem = buf; sl.data = buf + PAD; sl.pad = tail.size();
+        for (;;) {
+            out = d.run(out, lim, hist);
+            for (int i = 0; i < d.n_ends; ++i) sl.ends.push_back(MemberEndAt{(size_t)(d.ends[i].at - start), d.ends[i].crc});
+            d.n_ends = 0;
+            if (d.state == shinf::Decoder::DONE || d.state == shinf::Decoder::ERROR) break;
+            if ((size_t)(lim - out) < 300) break;
+        }
+        if (d.state == shinf::Decoder::ERROR) sl.err = std::string("gzip: ") + (d.err ? d.err : "error");
+        sl.len = (size_t)(out - start);
+        sl.last = d.state == shinf::Decoder::DONE || !sl.err.empty();
+        keep_tail(tail, PAD, sl.data, sl.len);
+        const bool last = sl.last;
+        if (!put_slab(r, std::move(sl)) || last) return;
+    }
+}
+
+// BGZF member at p: total compressed size, or 0 if p is not a BGZF member header
+static size_t bgzf_member(const uint8_t *p, const uint8_t *end)
+{
+    if (end - p < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const int xlen = p[10] | (p[11] << 8);
+    const uint8_t *x = p + 12, *xe = x + xlen;
+    if (xe > end) return 0;
+    while (x + 4 <= xe) {
+        const int slen = x[2] | (x[3] << 8);
+        if (x[0] == 'B' && x[1] == 'C' && slen == 2 && x + 6 <= xe) return (size_t)(x[4] | (x[5] << 8)) + 1;
+        x += 4 + slen;
+    }
+    return 0;
+}
+
+static void produce_bgzf(sh_reader *r)
+{
+    const size_t PAD = r->pad_bytes;
+    const uint8_t *p = r->map, *end = r->map + r->map_len;
+    std::vector<char> tail;
+    for (;;) {
+        struct Mem { const uint8_t *cdata; size_t clen; uint32_t isize, crc; size_t off; };
+        std::vector<Mem> mem;
+        size_t total = 0;
+        std::string err;
+        while (p < end && total + 65536 <= r->slab_bytes) {
+            const size_t bs = bgzf_member(p, end);
+            if (bs < 26 || p + bs > end) { err = "BGZF: bad member header"; break; }
+            const int xlen = p[10] | (p[11] << 8);
+            const uint8_t *cd = p + 12 + xlen, *tr = p + bs - 8;
+            Mem m{cd, (size_t)(tr - cd), (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24),
+                  (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24), total};
+            if (m.isize > 65536) { err = "BGZF: member larger than 64 KB"; break; }
+            total += m.isize; mem.push_back(m); p += bs;
+        }
+        char *buf = get_buf(r);
+        if (!buf) return;
+        memcpy(buf + PAD - tail.size(), tail.data(), tail.size());
+        Slab sl; sl.mem = buf; sl.data = buf + PAD; sl.pad = tail.size(); sl.len = total;
+        int bad = 0;
+#pragma omp parallel
+        {
+            std::vector<uint8_t> tmp(65536 + 512);
+            shinf::Decoder d;
+#pragma omp for schedule(dynamic, 8)
+            for (int64_t i = 0; i < (int64_t)mem.size(); ++i) {
+                const Mem &m = mem[(size_t)i];
+                d.begin(m.cdata, m.cdata + m.clen, true);
+                uint8_t *o = d.run(tmp.data(), tmp.data() + tmp.size(), tmp.data());
+                if (d.state != shinf::Decoder::DONE || (size_t)(o - tmp.data()) != m.isize || (uint32_t)crc32(0L, tmp.data(), m.isize) != m.crc) {
+#pragma omp atomic
+                    ++bad;
+                } else memcpy(buf + PAD + m.off, tmp.data(), m.isize);
+            }
+        }
+        if (bad && err.empty()) err = "BGZF: a member failed to decode or its CRC-32 check";
+        sl.err = err; sl.last = p >= end || !err.empty();
+        keep_tail(tail, PAD, sl.data, sl.len);
+        const bool last = sl.last;
+        if (!put_slab(r, std::move(sl)) || last) return;
+    }
+}
 
 extern "C" {
 
@@ -67,19 +277,62 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
 {
     if (!path || !sample_names || n_samples < 1) { g_rerr = "bad argument"; return nullptr; }
     sh_reader *r = new sh_reader();
-    r->gz = gzopen(path, "rb");
-    if (!r->gz) { g_rerr = std::string("cannot open ") + path; delete r; return nullptr; }
-    gzbuffer(r->gz, 1 << 20);
     r->n = n_samples;
     r->index.build(sample_names, n_samples);
+    const char *sel = std::getenv("SEERHIP_READER");
+    if (sel && std::string(sel) == "zlib") {
+        r->gz = gzopen(path, "rb");
+        if (!r->gz) { g_rerr = std::string("cannot open ") + path; delete r; return nullptr; }
+        gzbuffer(r->gz, 1 << 20);
+        return r;
+    }
+    r->fd = open(path, O_RDONLY);
+    struct stat stt;
+    if (r->fd < 0 || fstat(r->fd, &stt) != 0) { g_rerr = std::string("cannot open ") + path; delete r; return nullptr; }
+    r->map_len = (size_t)stt.st_size;
+    if (r->map_len) {
+        void *m = mmap(nullptr, r->map_len, PROT_READ, MAP_PRIVATE, r->fd, 0);
+        if (m == MAP_FAILED) { g_rerr = std::string("cannot map ") + path; r->map_len = 0; delete r; return nullptr; }
+        r->map = (const uint8_t *)m;
+        madvise(m, r->map_len, MADV_SEQUENTIAL);
+    }
+    if (const char *sb = std::getenv("SEERHIP_READER_SLAB")) r->slab_bytes = std::max<size_t>(70000, (size_t)std::atoll(sb));
+    if (const char *pb = std::getenv("SEERHIP_READER_PAD")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
+    if (r->map_len == 0) { r->eof = true; return r; }
+    r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
+    r->producer = std::thread([r] {
+        if (r->mode == 0) produce_plain(r); else if (r->mode == 1) produce_gzip(r); else produce_bgzf(r);
+    });
     return r;
 }
 
-void sh_reader_close(sh_reader *r)
+void sh_reader_close(sh_reader *r) { delete r; }
+
+// the next slab from the producer, CRCs of the gzip members that end in it verified; false at the end of the text or on error
+static bool next_slab(sh_reader *r, bool *failed)
 {
-    if (!r) return;
-    if (r->gz) gzclose(r->gz);
-    delete r;
+    *failed = false;
+    if (r->eof) return false;
+    Slab sl;
+    {
+        std::unique_lock<std::mutex> lk(r->mu);
+        r->cv_get.wait(lk, [&] { return !r->queue.empty(); });
+        sl = std::move(r->queue.front()); r->queue.pop_front();
+    }
+    r->cv_put.notify_one();
+    if (r->mode == 1 && sl.err.empty()) {
+        size_t p = 0;
+        for (const auto &e : sl.ends) {
+            r->crc_run = crc_parallel(r->crc_run, (const uint8_t *)sl.data + p, e.at - p);
+            if (r->crc_run != e.crc) { sl.err = "gzip: CRC-32 check failed"; break; }
+            r->crc_run = 0; p = e.at;
+        }
+        if (sl.err.empty()) r->crc_run = crc_parallel(r->crc_run, (const uint8_t *)sl.data + p, sl.len - p);
+    }
+    if (!sl.err.empty()) { g_rerr = sl.err; *failed = true; r->eof = true; release_slab(r, sl); return false; }
+    if (sl.last) r->eof = true;
+    r->held.push_back(std::move(sl));
+    return true;
 }
 
 // Parses up to max_variants lines.  bits: max_variants * row_bytes (zeroed here); counts[v] = carriers among the phenotyped
@@ -91,54 +344,94 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     if (!r || !bits || !counts || !names || !name_off || max_variants < 1) { g_rerr = "bad argument"; return -1; }
     if (row_bytes * 8 < r->n) { g_rerr = "row_bytes too small"; return -1; }
     auto t0 = std::chrono::steady_clock::now();
-    // release the text handed out by earlier calls: line offsets are only recorded from here on, so compacting is safe, and the buffer
-    // never holds more than one call's lines plus one slab (the reference streams line by line; a k-mer file is tens of GB inflated)
-    if (r->pos > 0) { r->buf.erase(r->buf.begin(), r->buf.begin() + r->pos); r->pos = 0; }
-    const size_t pos0 = r->pos;
-    // ---- collect up to max_variants complete lines in the buffer
-    std::vector<std::pair<size_t, size_t>> lines;            // [begin, end) without the newline
-    size_t scan = r->pos;
-    for (;;) {
-        while ((int64_t)lines.size() < max_variants) {
-            const char *base = r->buf.data();
-            const void *nl = scan < r->buf.size() ? memchr(base + scan, '\n', r->buf.size() - scan) : nullptr;
-            if (!nl) break;
-            const size_t e = (const char *)nl - base;
-            lines.emplace_back(r->pos, e);
-            r->pos = scan = e + 1;
+    std::vector<std::pair<const char *, const char *>> lines;   // [begin, end) without the newline; they point into slabs held until the end of the call
+    const char *ptr0 = nullptr;
+    if (r->gz) {
+        // ---- zlib path (SEERHIP_READER=zlib): one growing buffer, as in round 1
+        if (r->zpos > 0) { r->zbuf.erase(r->zbuf.begin(), r->zbuf.begin() + r->zpos); r->zpos = 0; }
+        size_t scan = 0, lstart = 0;
+        std::vector<std::pair<size_t, size_t>> lo;
+        for (;;) {
+            while ((int64_t)lo.size() < max_variants) {
+                const char *base = r->zbuf.data();
+                const void *nl = scan < r->zbuf.size() ? memchr(base + scan, '\n', r->zbuf.size() - scan) : nullptr;
+                if (!nl) { scan = r->zbuf.size(); break; }
+                const size_t e = (const char *)nl - base;
+                lo.emplace_back(lstart, e); lstart = scan = e + 1;
+            }
+            if ((int64_t)lo.size() >= max_variants || r->eof) break;
+            const size_t old = r->zbuf.size(), slab = 8u << 20;
+            r->zbuf.resize(old + slab);
+            const int got = gzread(r->gz, r->zbuf.data() + old, (unsigned)slab);
+            if (got < 0) { int en; g_rerr = gzerror(r->gz, &en); return -1; }
+            r->zbuf.resize(old + (size_t)got);
+            if (got == 0) r->eof = true;
         }
-        if ((int64_t)lines.size() >= max_variants || r->eof) break;
-        // refill: read another slab behind what is buffered
-        const size_t old = r->buf.size();
-        const size_t slab = 8u << 20;
-        r->buf.resize(old + slab);
-        const int got = gzread(r->gz, r->buf.data() + old, (unsigned)slab);
-        if (got < 0) { int en; g_rerr = gzerror(r->gz, &en); return -1; }
-        r->buf.resize(old + (size_t)got);
-        if (got == 0) r->eof = true;
-        scan = std::max(scan, r->pos);
-        // re-scan from where we stopped (lines found so far keep their offsets because we only compact when none are pending)
+        if (r->eof && lstart < r->zbuf.size() && (int64_t)lo.size() < max_variants) { lo.emplace_back(lstart, r->zbuf.size()); lstart = r->zbuf.size(); }
+        for (auto &l : lo) lines.emplace_back(r->zbuf.data() + l.first, r->zbuf.data() + l.second);
+        r->zpos = lstart;                                             // committed below unless the call is refused
+    } else {
+        // ---- slabs: drop the ones read completely by earlier calls, then walk
+        while (r->cur > 0) { release_slab(r, r->held.front()); r->held.pop_front(); --r->cur; }
+        bool failed = false;
+        if (r->held.empty()) { if (!next_slab(r, &failed)) { if (failed) return -1; return 0; } r->cur = 0; r->ptr = r->held[0].data; }
+        ptr0 = r->ptr;
+        r->bridge.clear();
+        const char *lstart = r->ptr;                                   // start of the line being scanned (may lie in the pad of held[cur])
+        const char *scan = r->ptr;
+        while ((int64_t)lines.size() < max_variants) {
+            const Slab &s = r->held[r->cur];
+            const char *send = s.data + s.len;
+            const void *nl = scan < send ? memchr(scan, '\n', (size_t)(send - scan)) : nullptr;
+            if (nl) { lines.emplace_back(lstart, (const char *)nl); lstart = scan = (const char *)nl + 1; continue; }
+            // the slab is exhausted with `part` bytes of an unfinished line
+            const size_t part = (size_t)(send - lstart);
+            if (r->cur + 1 >= r->held.size()) {
+                if (r->eof) { if (part) { lines.emplace_back(lstart, send); lstart = send; } break; }
+                if (!next_slab(r, &failed)) {
+                    if (failed) return -1;
+                    if (part) { lines.emplace_back(lstart, send); lstart = send; }      // the text ended without a newline
+                    break;
+                }
+            }
+            const Slab &nx = r->held[r->cur + 1];
+            ++r->cur;
+            if (part <= nx.pad) { lstart = nx.data - part; scan = nx.data; }            // the unfinished line is contiguous in the next slab's pad
+            else {
+                // longer than the pad (a unitig name of megabases): copy it out.  One such line per call at most keeps `bridge` stable.
+                if (!r->bridge.empty()) { --r->cur; break; }                             // finish this call here; the next one bridges again
+                const char *nsend = nx.data + nx.len;
+                const void *nl2 = memchr(nx.data, '\n', nx.len);
+                if (!nl2 && !(nx.last)) { g_rerr = "a line longer than a whole read slab: raise SEERHIP_READER_SLAB"; return -1; }
+                const char *le = nl2 ? (const char *)nl2 : nsend;
+                r->bridge.assign(lstart, send); r->bridge.insert(r->bridge.end(), nx.data, le);
+                lines.emplace_back(r->bridge.data(), r->bridge.data() + r->bridge.size());
+                lstart = scan = nl2 ? le + 1 : le;
+            }
+        }
+        r->ptr = lstart;
     }
-    if (r->eof && r->pos < r->buf.size() && (int64_t)lines.size() < max_variants) {   // last line without a trailing newline
-        lines.emplace_back(r->pos, r->buf.size());
-        r->pos = r->buf.size();
-    }
+    const size_t cur_after = r->cur;
+    (void)cur_after;
     const int64_t nv = (int64_t)lines.size();
     if (nv == 0) return 0;
     auto t1 = std::chrono::steady_clock::now();
     // ---- names (serial: offsets), presence (parallel).  Unitig names run to tens of kilobases: the total is measured BEFORE anything is
     // written, and a call that does not fit is refused without consuming its lines (-2; sh_reader_names_needed() says how much to bring)
-    const char *base = r->buf.data();
     std::vector<std::pair<const char *, const char *>> nm((size_t)nv);
     int64_t need = 0;
     for (int64_t v = 0; v < nv; ++v) {
-        const char *p = base + lines[v].first, *e = base + lines[v].second;
+        const char *p = lines[v].first, *e = lines[v].second;
         while (p < e && (*p == ' ' || *p == '\t')) ++p;
         const char *q = p;
         while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
         nm[v] = {p, q}; need += q - p;
     }
-    if (need > names_cap) { r->names_needed = need; r->pos = pos0; g_rerr = "names buffer too small"; return -2; }
+    if (need > names_cap) {                                           // nothing is consumed: the slabs of this call stay in hand
+        r->names_needed = need; g_rerr = "names buffer too small";
+        if (r->gz) r->zpos = 0; else { r->cur = 0; r->ptr = ptr0; }
+        return -2;
+    }
     memset(bits, 0, (size_t)nv * row_bytes);
     int64_t off = 0;
     for (int64_t v = 0; v < nv; ++v) { name_off[v] = off; memcpy(names + off, nm[v].first, nm[v].second - nm[v].first); off += nm[v].second - nm[v].first; }
@@ -148,7 +441,7 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     {
 #pragma omp for schedule(dynamic, 16)
         for (int64_t v = 0; v < nv; ++v) {
-            const char *p = base + lines[v].first, *e = base + lines[v].second;
+            const char *p = lines[v].first, *e = lines[v].second;
             const char *bar = (const char *)memchr(p, '|', e - p);
             uint8_t *row = bits + v * row_bytes;
             int cnt = 0;
@@ -182,6 +475,12 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
 }
 
 int64_t sh_reader_names_needed(sh_reader *r) { return r ? r->names_needed : 0; }
-int64_t sh_reader_buffered(sh_reader *r) { return r ? (int64_t)r->buf.size() : 0; }
+int64_t sh_reader_buffered(sh_reader *r)
+{
+    if (!r) return 0;
+    if (r->gz) return (int64_t)r->zbuf.size();
+    std::lock_guard<std::mutex> lk(r->mu);
+    return (int64_t)(r->all_bufs.size() * (r->pad_bytes + r->slab_bytes));     // every slab buffer ever allocated (they are recycled)
+}
 
 }  // extern "C"

@@ -88,26 +88,30 @@ def test_packed_cache_round_trip(tmp_path):
         list(iter_packed_blocks_cached(p.iloc[::-1], path, 0.01, 0.99, 64))
 
 
-def test_buffer_stays_bounded_over_many_blocks(tmp_path):
-    """The reader releases consumed text: whatever the file size, it buffers at most one block of lines plus one 8 MB read slab (it used
-    to keep the whole inflated file; the reference streams line by line, pyseer/input.py:301-454)."""
+def test_buffer_stays_bounded_over_many_blocks(tmp_path, monkeypatch):
+    """The reader holds a fixed number of recycled slab buffers whatever the file size (round 1 kept the whole inflated file; the
+    reference streams line by line, pyseer/input.py:301-454): ~50 MB of text through 1 MB slabs never allocates more than 8 of them."""
     samples = ["sample%04d" % i for i in range(400)]
     rng = np.random.default_rng(3)
-    path = str(tmp_path / "big.txt")
-    nlines = 6000
-    with open(path, "w") as fh:
-        for v in range(nlines):
-            carriers = np.nonzero(rng.random(400) < 0.5)[0]
-            fh.write("K%06d | %s\n" % (v, " ".join("%s:1" % samples[i] for i in carriers)))
-    size = os.path.getsize(path)
-    assert size > 12 << 20                                       # more than one read slab, so a leak would show
-    r = NativeKmerReader(path, samples, 100)
-    peak, total = 0, 0
-    for bits, counts, blob, off in r.raw_blocks():
-        total += counts.shape[0]
-        peak = max(peak, int(r._lib.sh_reader_buffered(r._h)))
-    assert total == nlines
-    assert peak <= (8 << 20) + 2 * (100 * (size // nlines + 64)) + (1 << 16), (peak, size)
+    nlines = 24000
+    lines = []
+    for v in range(nlines):
+        carriers = np.nonzero(rng.random(400) < 0.5)[0]
+        lines.append("K%06d | %s\n" % (v, " ".join("%s:1" % samples[i] for i in carriers)))
+    text = "".join(lines).encode()
+    assert len(text) > 40 << 20
+    monkeypatch.setenv("SEERHIP_READER_SLAB", str(1 << 20))
+    monkeypatch.setenv("SEERHIP_READER_PAD", str(1 << 18))
+    for name, blob in (("big.gz", gzip.compress(text, 1)), ("big.txt", text)):
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        r = NativeKmerReader(path, samples, 100)
+        peak, total = 0, 0
+        for bits, counts, blob2, off in r.raw_blocks():
+            total += counts.shape[0]
+            peak = max(peak, int(r._lib.sh_reader_buffered(r._h)))
+        assert total == nlines
+        assert peak <= 8 * ((1 << 20) + (1 << 18)), (name, peak)
 
 
 def test_long_variant_names_grow_the_names_buffer(tmp_path):
@@ -126,3 +130,110 @@ def test_long_variant_names_grow_the_names_buffer(tmp_path):
         got += nm
         assert (counts == 2).all()
     assert got == names
+
+
+def _bgzf(data, member=40000):
+    """BGZF as bgzip writes it: independent gzip members of <= 64 KB, each with the BC extra subfield (its compressed size - 1)."""
+    import struct
+    import zlib
+    out = b""
+    for i in range(0, max(len(data), 1), member):
+        chunk = data[i:i + member]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk) & 0xFFFFFFFF)
+    return out + b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00"
+
+
+def _kmer_text(samples, nlines, seed):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for v in range(nlines):
+        carriers = np.nonzero(rng.random(len(samples)) < rng.uniform(0.05, 0.95))[0]
+        rows.append("K%05d | %s" % (v, " ".join("%s:%d" % (samples[i], 1 + i % 3) for i in carriers)))
+    return ("\n".join(rows) + "\n").encode()
+
+
+def test_every_container_gives_the_same_blocks(tmp_path, monkeypatch):
+    """Plain text, single-member gzip (levels 1/6/9, stored blocks), concatenated members, BGZF, and zlib's own gzread as the yardstick:
+    the in-tree inflate (csrc/inflate_fast.h) and the member-parallel BGZF path hand the parser the same bytes."""
+    import zlib
+    samples = ["iso%03d" % i for i in range(150)]
+    text = _kmer_text(samples, 1200, 5)
+    files = {"plain.txt": text, "l1.gz": gzip.compress(text, 1), "l6.gz": gzip.compress(text, 6), "l9.gz": gzip.compress(text, 9),
+             "stored.gz": gzip.compress(text, 0),
+             "multi.gz": gzip.compress(text[:70001], 6) + gzip.compress(b"", 6) + gzip.compress(text[70001:], 9),
+             "bgzf.gz": _bgzf(text)}
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    files["fixed.gz"] = co.compress(text) + co.flush()
+    monkeypatch.setenv("SEERHIP_READER_SLAB", "50000")             # many slabs, member and block boundaries inside them
+    want = None
+    for name, blob in files.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        for sel in ("", "zlib"):
+            if sel:
+                if name == "plain.txt":
+                    continue
+                monkeypatch.setenv("SEERHIP_READER", sel)
+            got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples, 97)]
+            monkeypatch.delenv("SEERHIP_READER", raising=False)
+            names = sum((g[0] for g in got), [])
+            bits = np.concatenate([g[1] for g in got]); counts = np.concatenate([g[2] for g in got])
+            if want is None:
+                want = (names, bits, counts)
+                assert len(names) == 1200
+            assert names == want[0] and np.array_equal(bits, want[1]) and np.array_equal(counts, want[2]), (name, sel)
+
+
+def test_corrupt_gzip_is_reported(tmp_path):
+    """A flipped bit inside the deflate data: the stream either stops decoding or fails its CRC-32 -- never a silent wrong block."""
+    import pytest
+    samples = ["iso%03d" % i for i in range(60)]
+    text = _kmer_text(samples, 400, 9)
+    good = gzip.compress(text, 6)
+    for k, blob in enumerate((good[:len(good) // 2] + bytes([good[len(good) // 2] ^ 0x10]) + good[len(good) // 2 + 1:],
+                              good[:-6] + bytes([good[-6] ^ 1]) + good[-5:],          # CRC field itself
+                              good[:len(good) - 40],                                  # truncated
+                              _bgzf(text)[:300] + b"\x00" + _bgzf(text)[301:])):
+        path = str(tmp_path / ("bad%d.gz" % k))
+        open(path, "wb").write(blob)
+        with pytest.raises(IOError):
+            for _ in NativeKmerReader(path, samples, 50):
+                pass
+
+
+def test_lines_longer_than_the_pad_and_blocks_spanning_many_slabs(tmp_path, monkeypatch):
+    """Slab geometry must not show: lines longer than the pad (copied across the boundary), blocks that span many slabs, a file without
+    a trailing newline -- same rows as with one big slab."""
+    samples = ["iso%03d" % i for i in range(300)]
+    text = _kmer_text(samples, 700, 21)[:-1]                       # no trailing newline
+    want = None
+    for slab, pad, bs in ((1 << 24, 1 << 20, 97), (70000, 32768, 97), (70000, 32768, 5000), (200000, 32768, 1)):
+        monkeypatch.setenv("SEERHIP_READER_SLAB", str(slab)); monkeypatch.setenv("SEERHIP_READER_PAD", str(pad))
+        for name, blob in (("t.txt", text), ("t.gz", gzip.compress(text, 6)), ("t.bgzf.gz", _bgzf(text))):
+            path = str(tmp_path / name)
+            open(path, "wb").write(blob)
+            got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples, bs)]
+            names = sum((g[0] for g in got), [])
+            bits = np.concatenate([g[1] for g in got]); counts = np.concatenate([g[2] for g in got])
+            if want is None:
+                want = (names, bits, counts); assert len(names) == 700
+            assert names == want[0] and np.array_equal(bits, want[1]) and np.array_equal(counts, want[2]), (slab, pad, bs, name)
+    # lines of ~45 KB against a 32 KB pad: the bridge
+    samples2 = ["s%05d" % i for i in range(6000)]
+    text2 = _kmer_text(samples2, 60, 22)
+    monkeypatch.setenv("SEERHIP_READER_SLAB", "100000"); monkeypatch.setenv("SEERHIP_READER_PAD", "32768")
+    ref = None
+    for name, blob in (("u.txt", text2), ("u.gz", gzip.compress(text2, 6))):
+        path = str(tmp_path / name); open(path, "wb").write(blob)
+        got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples2, 7)]
+        cur = (sum((g[0] for g in got), []), np.concatenate([g[1] for g in got]))
+        if ref is None:
+            ref = cur; assert len(cur[0]) == 60
+        assert cur[0] == ref[0] and np.array_equal(cur[1], ref[1])
+    monkeypatch.setenv("SEERHIP_READER_SLAB", str(1 << 24)); monkeypatch.setenv("SEERHIP_READER_PAD", str(1 << 20))
+    big = [(n, b.copy()) for n, b, c in NativeKmerReader(str(tmp_path / "u.gz"), samples2, 7)]
+    assert sum((g[0] for g in big), []) == ref[0] and np.array_equal(np.concatenate([g[1] for g in big]), ref[1])

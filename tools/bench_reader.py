@@ -1,0 +1,51 @@
+"""Throughput of the native k-mer reader (csrc/reader.cpp) on a synthetic k-mer file, N samples x V k-mers, by container:
+plain text, gzip through zlib's gzread (SEERHIP_READER=zlib, the round-1 path), gzip through the in-tree inflate, BGZF (member-parallel).
+No GPU involved; run it on the GPU host to see what feeds the engine there.  Prints one JSON line."""
+import gzip, json, os, struct, sys, time, zlib
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pyseer_amd.input import NativeKmerReader
+
+N = int(os.environ.get("N", 5000)); V = int(os.environ.get("V", 12000)); BS = int(os.environ.get("BLOCK", 4096))
+d = os.environ.get("OUT", "/tmp/rb"); os.makedirs(d, exist_ok=True)
+rng = np.random.default_rng(0)
+names = ["sample_%05d" % i for i in range(N)]
+tok = np.array([n + ":1" for n in names], dtype=object)
+t0 = time.time()
+parts = []
+for v in range(V):
+    af = rng.uniform(0.02, 0.98)
+    idx = np.nonzero(rng.random(N) < af)[0]
+    parts.append("".join(rng.choice(list("ACGT"), 31)) + " | " + " ".join(tok[idx]) + "\n")
+text = "".join(parts).encode(); del parts
+open(d + "/k.txt", "wb").write(text)
+co = zlib.compressobj(6, zlib.DEFLATED, 31)
+with open(d + "/k.gz", "wb") as f:
+    for i in range(0, len(text), 1 << 24):
+        f.write(co.compress(text[i:i + (1 << 24)]))
+    f.write(co.flush())
+with open(d + "/k.bgzf.gz", "wb") as f:
+    for i in range(0, len(text), 65280):
+        ch = text[i:i + 65280]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15); comp = c.compress(ch) + c.flush()
+        f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1))
+        f.write(comp + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))
+gen = time.time() - t0
+res = {"n_samples": N, "kmers": V, "text_MB": len(text) / 1e6, "gz_MB": os.path.getsize(d + "/k.gz") / 1e6, "cores": os.cpu_count(), "generate_s": gen}
+want = None
+for tag, path, env in (("plain", "k.txt", None), ("gzip_zlib", "k.gz", "zlib"), ("gzip_fast", "k.gz", None), ("bgzf", "k.bgzf.gz", None)):
+    if env: os.environ["SEERHIP_READER"] = env
+    else: os.environ.pop("SEERHIP_READER", None)
+    best = 0.0
+    for rep in range(2):
+        t0 = time.time(); tot = 0; cs = 0
+        for bits, counts, blob, off in NativeKmerReader(d + "/" + path, names, BS).raw_blocks():
+            tot += counts.shape[0]; cs += int(counts.sum())
+        dt = time.time() - t0
+        best = max(best, tot / dt)
+        assert tot == V
+        if want is None: want = cs
+        assert cs == want, (tag, cs, want)
+    res[tag + "_kmers_per_s"] = best; res[tag + "_text_MBps"] = best * len(text) / V / 1e6
+print(json.dumps(res))
