@@ -80,6 +80,9 @@ def get_options(argv=None):
                     'split into contiguous shards, one per GPU, results keep the input order [Default: the single --gpu]')
     ot.add_argument('--save-packed', default=None,
                     help='Also write the parsed k-mer file as packed bit rows (for --load-packed in later runs over the same samples)')
+    ot.add_argument('--packed-cache', action='store_true', default=False,
+                    help='Keep a packed cache next to the k-mer file (<kmers>.seerpack): written by the first run, read by later runs '
+                         'over the same samples while the k-mer file is unchanged (size and modification time); ignored with a warning otherwise')
     ot.add_argument('--load-packed', default=None,
                     help='Read variants from a packed cache written by --save-packed instead of parsing --kmers again')
     ot.add_argument('--cpu-eigh', action='store_true', default=False,
@@ -291,6 +294,31 @@ def main(argv=None):
         out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
 
     cache_out = None
+    if options.packed_cache and native and not options.load_packed and not options.save_packed:
+        # the automatic form of --save-packed / --load-packed: one file next to the input, tied to it by size + mtime (a sidecar stamp),
+        # and to the run by the sample list the cache itself stores
+        import os as _os
+        side = var_file + ".seerpack"
+        st = _os.stat(var_file)
+        stamp = "%d %d" % (st.st_size, int(st.st_mtime))
+        fresh = False
+        try:
+            fresh = _os.path.exists(side) and open(side + ".stamp").read().strip() == stamp
+        except (IOError, OSError):
+            fresh = False
+        if fresh:
+            try:
+                next(iter(iter_packed_blocks_cached(p, side, options.min_af, options.max_af, 1)), None)    # header + sample list check
+                options.load_packed = side
+            except (ValueError, IOError):
+                sys.stderr.write("Packed cache %s was written for other samples; parsing %s again\n" % (side, var_file))
+                fresh = False
+        if not fresh:
+            try:
+                open(side + ".stamp", "w").write(stamp + "\n")
+                options.save_packed = side
+            except (IOError, OSError):
+                sys.stderr.write("Cannot write a packed cache next to %s; continuing without\n" % var_file)
     if options.load_packed:
         blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples)

@@ -19,6 +19,9 @@
 #include <mutex>
 #include <condition_variable>
 #include <deque>
+#include <atomic>
+#include <functional>
+#include <memory>
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
@@ -59,13 +62,42 @@ struct NameTable {
 // Text source: the (memory-mapped) file decoded by a producer thread into slabs, a few slabs ahead of the parser.
 //   plain text      -> slabs are windows of the mapping itself (no copy)
 //   gzip            -> inflate_fast.h on one thread (the format is sequential), ~4x zlib on k-mer text, straight into the slab
-//   BGZF (bgzip)    -> members are independent and announce their compressed size: a slab's worth of members is decoded by an OpenMP
-//                      team, each member by one thread (raw deflate + its own CRC)
+//   BGZF (bgzip)    -> members are independent and announce their compressed size: a slab's worth of members is decoded by a pool of
+//                      workers, each member by one of them (raw deflate + its own CRC)
 // Every slab is preceded, in the same allocation, by the tail of the text before it (PAD bytes: the decoder's 32 KB history lives there
 // anyway), so a line that straddles two slabs is contiguous in the second one and the parser never copies text.  The CRC-32 of every
-// gzip member is verified by the consumer's OpenMP team over whole slabs (zlib's crc32 + crc32_combine), not by the decoding thread.
+// gzip member is verified by the consumer's worker pool over whole slabs (zlib's crc32 + crc32_combine), not by the decoding thread.
 // SEERHIP_READER=zlib selects zlib's gzread instead (A/B, and a fallback should a stream ever disagree).
 // ---------------------------------------------------------------------------------------------------------------------------------
+// A small pool of SLEEPING workers (condition variables) instead of an OpenMP team: libgomp's workers spin after every parallel region,
+// and on the 256-thread GPU host 128-256 spinning threads starve the decoding thread (measured: gzip 10.5 k k-mers/s with 128 OpenMP
+// threads, 27.5 k with 32, plain text 48 k vs 226 k).  run(n, fn) calls fn(i) for i in [0, n) with dynamic scheduling and returns when done.
+struct ParPool {
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::function<void(int64_t)> fn; int64_t n = 0, chunk = 1; std::atomic<int64_t> next{0}; int busy = 0; uint64_t gen = 0; bool quit = false;
+    explicit ParPool(int nthreads) {
+        for (int t = 0; t < nthreads; ++t) th.emplace_back([this] {
+            uint64_t seen = 0;
+            for (;;) {
+                { std::unique_lock<std::mutex> lk(mu); cv_work.wait(lk, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
+                work();
+                { std::lock_guard<std::mutex> lk(mu); if (--busy == 0) cv_done.notify_all(); }
+            }
+        });
+    }
+    void work() { for (;;) { const int64_t i0 = next.fetch_add(chunk); if (i0 >= n) return; const int64_t i1 = std::min(n, i0 + chunk); for (int64_t i = i0; i < i1; ++i) fn(i); } }
+    void run(int64_t count, int64_t chunk_, std::function<void(int64_t)> f) {
+        if (count <= 0) return;
+        if (th.empty() || count == 1) { for (int64_t i = 0; i < count; ++i) f(i); return; }
+        { std::lock_guard<std::mutex> lk(mu); fn = std::move(f); n = count; chunk = std::max<int64_t>(1, chunk_); next = 0; busy = (int)th.size(); ++gen; }
+        cv_work.notify_all();
+        work();                                                       // the caller works too
+        std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return busy == 0; });
+    }
+    ~ParPool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv_work.notify_all(); for (auto &t : th) t.join(); }
+};
+
 struct MemberEndAt { size_t at; uint32_t crc; };
 struct Slab {
     const char *data = nullptr; size_t len = 0, pad = 0;       // data[-pad .. len): pad bytes of the preceding text, then this slab's
@@ -89,6 +121,7 @@ struct sh_reader {
     std::deque<Slab> queue; std::vector<char *> free_bufs; std::vector<char *> all_bufs; bool stop = false;
     size_t slab_bytes = 16u << 20, pad_bytes = 1u << 20, depth = 3;
     int mode = 0;                        // 0 plain, 1 gzip, 2 BGZF
+    std::unique_ptr<ParPool> pool, pool_bgzf;   // parser / CRC workers; member-parallel BGZF decoding (the producer's)
     // consumer
     std::deque<Slab> held; size_t cur = 0; const char *ptr = nullptr;     // slabs in hand, the one being read, next unread byte
     std::vector<char> bridge;            // a line longer than the pad that straddles two slabs (copied, rare)
@@ -137,18 +170,17 @@ static void release_slab(sh_reader *r, Slab &sl)
     r->cv_free.notify_one();
 }
 
-// CRC-32 of [p, p + n) with the caller's OpenMP team: 1 MB pieces, combined in order
-static uint32_t crc_parallel(uint32_t crc, const uint8_t *p, size_t n)
+// CRC-32 of [p, p + n) by the worker pool: 1 MB pieces, combined in order
+static uint32_t crc_parallel(ParPool *pool, uint32_t crc, const uint8_t *p, size_t n)
 {
     const size_t CH = 1u << 20;
-    if (n <= 2 * CH) return (uint32_t)crc32(crc, p, (uInt)n);
+    if (n <= 2 * CH || !pool) return (uint32_t)crc32(crc, p, (uInt)n);
     const int64_t nch = (int64_t)((n + CH - 1) / CH);
     std::vector<uint32_t> part((size_t)nch);
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < nch; ++i) {
+    pool->run(nch, 1, [&](int64_t i) {
         const size_t lo = (size_t)i * CH, len = std::min(CH, n - lo);
         part[(size_t)i] = (uint32_t)crc32(0L, p + lo, (uInt)len);
-    }
+    });
     for (int64_t i = 0; i < nch; ++i) {
         const size_t lo = (size_t)i * CH, len = std::min(CH, n - lo);
         crc = (uint32_t)crc32_combine(crc, part[(size_t)i], (z_off_t)len);
@@ -245,22 +277,16 @@ static void produce_bgzf(sh_reader *r)
         if (!buf) return;
         memcpy(buf + PAD - tail.size(), tail.data(), tail.size());
         Slab sl; sl.mem = buf; sl.data = buf + PAD; sl.pad = tail.size(); sl.len = total;
-        int bad = 0;
-#pragma omp parallel
-        {
-            std::vector<uint8_t> tmp(65536 + 512);
-            shinf::Decoder d;
-#pragma omp for schedule(dynamic, 8)
-            for (int64_t i = 0; i < (int64_t)mem.size(); ++i) {
-                const Mem &m = mem[(size_t)i];
-                d.begin(m.cdata, m.cdata + m.clen, true);
-                uint8_t *o = d.run(tmp.data(), tmp.data() + tmp.size(), tmp.data());
-                if (d.state != shinf::Decoder::DONE || (size_t)(o - tmp.data()) != m.isize || (uint32_t)crc32(0L, tmp.data(), m.isize) != m.crc) {
-#pragma omp atomic
-                    ++bad;
-                } else memcpy(buf + PAD + m.off, tmp.data(), m.isize);
-            }
-        }
+        std::atomic<int> bad{0};
+        r->pool_bgzf->run((int64_t)mem.size(), 4, [&](int64_t i) {
+            static thread_local std::vector<uint8_t> tmp(65536 + 512);
+            static thread_local shinf::Decoder d;
+            const Mem &m = mem[(size_t)i];
+            d.begin(m.cdata, m.cdata + m.clen, true);
+            uint8_t *o = d.run(tmp.data(), tmp.data() + tmp.size(), tmp.data());
+            if (d.state != shinf::Decoder::DONE || (size_t)(o - tmp.data()) != m.isize || (uint32_t)crc32(0L, tmp.data(), m.isize) != m.crc) ++bad;
+            else memcpy(buf + PAD + m.off, tmp.data(), m.isize);
+        });
         if (bad && err.empty()) err = "BGZF: a member failed to decode or its CRC-32 check";
         sl.err = err; sl.last = p >= end || !err.empty();
         keep_tail(tail, PAD, sl.data, sl.len);
@@ -279,6 +305,10 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     sh_reader *r = new sh_reader();
     r->n = n_samples;
     r->index.build(sample_names, n_samples);
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    int nt = std::min(48, hw);
+    if (const char *te = std::getenv("SEERHIP_READER_THREADS")) nt = std::max(1, std::atoi(te));
+    r->pool.reset(new ParPool(nt - 1));
     const char *sel = std::getenv("SEERHIP_READER");
     if (sel && std::string(sel) == "zlib") {
         r->gz = gzopen(path, "rb");
@@ -300,6 +330,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     if (const char *pb = std::getenv("SEERHIP_READER_PAD")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
+    if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, hw / 2) - 1)));
     r->producer = std::thread([r] {
         if (r->mode == 0) produce_plain(r); else if (r->mode == 1) produce_gzip(r); else produce_bgzf(r);
     });
@@ -323,11 +354,11 @@ static bool next_slab(sh_reader *r, bool *failed)
     if (r->mode == 1 && sl.err.empty()) {
         size_t p = 0;
         for (const auto &e : sl.ends) {
-            r->crc_run = crc_parallel(r->crc_run, (const uint8_t *)sl.data + p, e.at - p);
+            r->crc_run = crc_parallel(r->pool.get(), r->crc_run, (const uint8_t *)sl.data + p, e.at - p);
             if (r->crc_run != e.crc) { sl.err = "gzip: CRC-32 check failed"; break; }
             r->crc_run = 0; p = e.at;
         }
-        if (sl.err.empty()) r->crc_run = crc_parallel(r->crc_run, (const uint8_t *)sl.data + p, sl.len - p);
+        if (sl.err.empty()) r->crc_run = crc_parallel(r->pool.get(), r->crc_run, (const uint8_t *)sl.data + p, sl.len - p);
     }
     if (!sl.err.empty()) { g_rerr = sl.err; *failed = true; r->eof = true; release_slab(r, sl); return false; }
     if (sl.last) r->eof = true;
@@ -437,35 +468,31 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     for (int64_t v = 0; v < nv; ++v) { name_off[v] = off; memcpy(names + off, nm[v].first, nm[v].second - nm[v].first); off += nm[v].second - nm[v].first; }
     name_off[nv] = off;
     const auto &index = r->index;
-#pragma omp parallel
-    {
-#pragma omp for schedule(dynamic, 16)
-        for (int64_t v = 0; v < nv; ++v) {
-            const char *p = lines[v].first, *e = lines[v].second;
-            const char *bar = (const char *)memchr(p, '|', e - p);
-            uint8_t *row = bits + v * row_bytes;
-            int cnt = 0;
-            if (bar) {
-                const char *s = bar + 1;
-                const char *bar2 = (const char *)memchr(s, '|', e - s);
-                const char *end = bar2 ? bar2 : e;
-                while (s < end) {
-                    while (s < end && (*s == ' ' || *s == '\t' || *s == '\r')) ++s;
-                    const char *t = s;
-                    while (t < end && *t != ' ' && *t != '\t' && *t != '\r') ++t;
-                    if (t > s) {
-                        const char *colon = (const char *)memchr(s, ':', t - s);
-                        const int i = index.find(s, (colon ? colon : t) - s);
-                        if (i >= 0) {
-                            if (!((row[i >> 3] >> (i & 7)) & 1)) { row[i >> 3] |= (uint8_t)(1u << (i & 7)); ++cnt; }
-                        }
+    r->pool->run(nv, 8, [&](int64_t v) {
+        const char *p = lines[v].first, *e = lines[v].second;
+        const char *bar = (const char *)memchr(p, '|', e - p);
+        uint8_t *row = bits + v * row_bytes;
+        int cnt = 0;
+        if (bar) {
+            const char *s = bar + 1;
+            const char *bar2 = (const char *)memchr(s, '|', e - s);
+            const char *end = bar2 ? bar2 : e;
+            while (s < end) {
+                while (s < end && (*s == ' ' || *s == '\t' || *s == '\r')) ++s;
+                const char *t = s;
+                while (t < end && *t != ' ' && *t != '\t' && *t != '\r') ++t;
+                if (t > s) {
+                    const char *colon = (const char *)memchr(s, ':', t - s);
+                    const int i = index.find(s, (colon ? colon : t) - s);
+                    if (i >= 0) {
+                        if (!((row[i >> 3] >> (i & 7)) & 1)) { row[i >> 3] |= (uint8_t)(1u << (i & 7)); ++cnt; }
                     }
-                    s = t;
                 }
+                s = t;
             }
-            counts[v] = cnt;
         }
-    }
+        counts[v] = cnt;
+    });
     if (std::getenv("SEERHIP_READER_DEBUG")) {
         auto t2 = std::chrono::steady_clock::now();
         fprintf(stderr, "[reader] %lld lines: read+split %.3fs parse %.3fs\n", (long long)nv,
