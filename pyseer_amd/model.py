@@ -192,12 +192,6 @@ def covariate_block(n, m, c):
     return np.ascontiguousarray(np.concatenate(cols, axis=1))
 
 
-def mask_like_reference(r):
-    """NaN masking of fixed_effects_regression's early returns (model.py:255-272, 357-362): already applied by the
-    kernels, kept here as the single place that defines it for the host-side object builders."""
-    return r
-
-
 def seer_from_row(r, i, variant, pattern, af, kstrains, nkstrains, max_lineage=None):
     fl = int(r["flags"][i])
     notes = notes_from_flags(fl)
@@ -278,9 +272,28 @@ def fixed_effects_regression(variant, p, k, m, c, af, pattern, lineage_effects, 
 # ---------------------------------------------------------------------------------------------------------------
 # The remaining names of pyseer/model.py's per-variant surface, with the reference's signatures
 # ---------------------------------------------------------------------------------------------------------------
+_prefilter_engine = {}
+
+
 def pre_filtering(p, k, continuous):
-    """pyseer/model.py:31-70 -> (prep, bad_chisq), on the host (the kernels compute it from packed bits for whole batches)."""
-    return host_pre_filtering(np.asarray(p, dtype=float), np.asarray(k, dtype=float), continuous)
+    """pyseer/model.py:31-70 -> (prep, bad_chisq).  Same kernel code as every batch (the 2x2 table / Welch sums from the packed bits,
+    csrc/common.h): the variant goes through the fixed-effects entry point with a filter threshold below any p-value, so the engine
+    classifies it as pre-filtered and returns prep and the bad-chisq note without fitting anything.  A variant with missing calls never
+    reaches the engine (host_pre_filtering, as in the driver)."""
+    from .engine import Engine
+    p = np.ascontiguousarray(np.asarray(getattr(p, "values", p), dtype=float).reshape(-1))
+    k = np.asarray(k, dtype=float).reshape(-1)
+    if np.isnan(k).any() or np.isnan(p).any():
+        return host_pre_filtering(p, k, continuous)
+    key = (p.shape[0], bool(continuous), p.tobytes())
+    e = _prefilter_engine.get(key)
+    if e is None:
+        _prefilter_engine.clear()
+        e = Engine(p.shape[0])
+        e.glm_setup(p, None, bool(continuous), 0.0, None, pret=-1.0, lrtt=1.0)
+        _prefilter_engine[key] = e
+    r = e.glm_batch(pack_variants(k.reshape(1, -1)))
+    return float(r["prep"][0]), bool(r["flags"][0] & 4)
 
 
 _lineage_engine = {}
