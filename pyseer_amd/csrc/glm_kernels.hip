@@ -421,6 +421,105 @@ __device__ __forceinline__ void fast_pass_mfma(const uint64_t *__restrict__ T, i
     }
 }
 
+// ---- the final pass with the covariate block of the information matrix as a CORRECTION to the null model's -------------------
+// k_glm_final needs X^T W X in double precision at the final beta: 78 fp64 accumulators per lane at q = 10, which do not fit beside the
+// score and spill (468-708 bytes of scratch per lane, 11-14 ms per 262 144 variants at N = 5000).  But the [1, z] x [1, z] part of it
+// differs from the NULL model's -- a per-run constant, A0 = sum_i w0_i zz_i, summed once on the host in fp64 -- only through
+// w_i - w0_i, which is small (the variant's effect) and whose sum tolerates single precision:  sum_i (w_i - w0_i) z_ij z_ik  carries a
+// relative rounding of ~1e-7 of a term that is itself a few per cent of A0.  So the z x z block is accumulated exactly as in the fast
+// passes (v_mfma_f32_32x32x2_f32 against the per-run products table) with A operand (float)(w_i - w0_i), and only the intercept and
+// variant rows (2 + 2q entries) stay fp64 accumulators next to the score.  Works in the standardised coordinates of the fast phase.
+template <int Q>
+__device__ __forceinline__ void final_pass_mfma(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N,
+                                                const double *__restrict__ y, const double *__restrict__ Ws, const float *__restrict__ ZZ,
+                                                const double *__restrict__ w0, const double *__restrict__ a0, const double (&beta)[Q + 2],
+                                                double (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], double &ll, double &maxdev, float *tr)
+{
+    constexpr int P = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE;
+    const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
+    v16f acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][h][r] = 0.0f;
+    double h00 = 0.0, h10 = 0.0, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0[j] = 0.0; hz1[j] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < P; ++a) g[a] = 0.0;
+    ll = 0.0; maxdev = 0.0;
+    auto sample = [&](int i, bool xb) -> float {
+        double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], Ws[(int64_t)i * Q + j], eta);
+        const double yi = y[i];
+        const double mu = 1.0 / (1.0 + exp(-eta));                            // SM Logit.cdf
+        const double r = yi - mu;
+        maxdev = fmax(maxdev, fabs(r));
+        const double lm = log(mu);                                            // SM Logit.loglike, as info_pass
+        ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+        g[0] += r; g[1] += xb ? r : 0.0;
+        const double wgt = mu * (1.0 - mu), wx = xb ? wgt : 0.0;
+        h00 += wgt; h10 += wx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const double zj = Ws[(int64_t)i * Q + j];
+            g[2 + j] = fma(r, zj, g[2 + j]); hz0[j] = fma(wgt, zj, hz0[j]); hz1[j] = fma(wx, zj, hz1[j]);
+        }
+        return (float)(wgt - w0[i]);
+    };
+    const int nfull = N >> 1;
+    for (int pr = 0; pr < nfull; ++pr) {
+        const int i = 2 * pr, b = i & 63;
+        const float *zrow = ZZ + (int64_t)(i + lh) * STRIDE + l31;
+        float bz[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) bz[cb] = zrow[cb * 32];
+        const uint64_t w = T[(int64_t)(i >> 6) * Vpad + v];
+        const float d0 = sample(i, (w >> b) & 1ull);
+        const float d1 = sample(i + 1, (w >> (b + 1)) & 1ull);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d1), false, false);
+        const float a0f = __uint_as_float(sw[0]), a1f = __uint_as_float(sw[1]);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0f, bz[cb], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1f, bz[cb], acc[cb][1], 0, 0, 0);
+        }
+    }
+    if (N & 1) {
+        const int i = N - 1;
+        const float *zrow = ZZ + (int64_t)i * STRIDE + l31;
+        const float d0 = sample(i, (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), 0u, false, false);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[0]), zrow[cb * 32], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[1]), zrow[cb * 32], acc[cb][1], 0, 0, 0);
+        }
+    }
+    H[sidx(0, 0)] = h00; H[sidx(1, 0)] = h10; H[sidx(1, 1)] = h10;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0[j]; H[sidx(2 + j, 1)] = hz1[j]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * (STRIDE + 1) + cb * 32 + l31] = acc[cb][h][r];
+        __syncthreads();
+        if (lh == h) {
+            const float *row = tr + l31 * (STRIDE + 1);
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = a0[j * (j + 1) / 2 + k] + (double)row[j * (j + 1) / 2 + k];
+        }
+    }
+}
+
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
 struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *tile_list; int *tile_count; };
 
@@ -606,7 +705,7 @@ __global__ __launch_bounds__(256) void k_glm_slow(const uint64_t *__restrict__ T
 }
 
 // ---- kernel 3: phase C, fp64 evaluation at the final beta + the decisions of model.py:332-344, 384 --------------------------
-template <int Q>
+template <int Q, bool DELTA>
 __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                   const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                   GlmWork wk, double *__restrict__ out, uint32_t *__restrict__ flags,
@@ -622,6 +721,11 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     double beta[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) beta[a] = fin ? wk.bw[(int64_t)a * Vpad + vr] : 0.0;
+    __shared__ float tr[DELTA ? FastCols<Q>::LDS_FLOATS : 1];
+    if (DELTA) {                                                     // to the standardised coordinates: b' = b * scale, b0' = b0 + sum b mean
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { beta[0] = fma(beta[2 + j], P.wstd[j], beta[0]); beta[2 + j] = beta[2 + j] * P.wstd[Q + j]; }
+    }
     int status = 0;
     double llf = NAN, bse1 = NAN;
     // The fast phase hands over a beta whose last step was <= P.fast_tol.  This pass evaluates llf, the separation callback and the
@@ -630,9 +734,10 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     // ~5e-7 relative), the pass is repeated at the stepped beta, so what is reported always satisfies the reference's stopping rule.
     bool redo = fin;
     for (int rep = 0; rep < 6 && __any(redo); ++rep) {
+        double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
+        if (DELTA) final_pass_mfma<Q>(T, Vpad, vr, N, y, P.ws, P.zz, P.w0, P.a0, beta, H, g, ll, maxdev, tr);   // wave-wide (MFMA, permlane)
         if (redo) {
-            double H[PC * (PC + 1) / 2], g[PC], ll, maxdev;
-            info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev, true);
+            if (!DELTA) info_pass<Q, true, true>(T, Vpad, vr, N, NB64, y, W, beta, H, g, ll, maxdev, true);
             redo = false;
             status = 0;
             if (maxdev <= 1e-8) status = 1;                                                      // callback after the last update
@@ -670,6 +775,10 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
     else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }                         // model.py:332-334
     else {
+        if (DELTA) {                                                 // back to the covariates as given
+#pragma unroll
+            for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
+        }
         const double lrstat = -2.0 * (P.null_llf - llf);
         double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);                        // model.py:336-339
         out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = bse1; out[4 * V + v] = beta[0];
@@ -1873,7 +1982,10 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
         const int S = std::min(4, glm_split_waves(P.NB64));      // 400+ VGPRs per lane: at most four wavefronts per block
         hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
     }
-    else if (which == 5) hipLaunchKernelGGL(k_glm_final<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
+    else if (which == 5) {
+        if (Q > 0 && P.a0 && P.w0 && P.zz && P.ws) hipLaunchKernelGGL((k_glm_final<Q, true>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
+        else hipLaunchKernelGGL((k_glm_final<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
+    }
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else if (which == 6) hipLaunchKernelGGL(k_glm_ols_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);

@@ -26,6 +26,8 @@ struct GlmParams {
     // cleanly is restarted by k_glm_slow from the reference's start vector on the reference's trajectory, as before.  warm_on = 0: off.
     int warm_on;
     double warm[16];
+    const double *w0, *a0;        // final pass as a correction to the null model (k_glm_final<Q, true>): w0[N] = mu0 (1 - mu0) at the null MLE,
+                                  // a0 = sum_i w0_i z_ij z_ik packed (j >= k), both in the standardised coordinates; null = plain fp64 pass
     int firth_warm;               // 1: Firth rounds start at fwarm = the null-model fit [b0, bz...] in the ORIGINAL covariate coordinates (force_firth only)
     double fwarm[16];
     int tile_mode;                // 1: k_glm_fast only classifies and lists; the Newton fits run in k_glm_tile (glm_tile.hip)
