@@ -709,11 +709,14 @@ template <int Q, bool DELTA>
 __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                   const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                   GlmWork wk, double *__restrict__ out, uint32_t *__restrict__ flags,
-                                                  int *__restrict__ firth_list, int *__restrict__ firth_count)
+                                                  int *__restrict__ firth_list, int *__restrict__ firth_count, int want_state)
 {
     constexpr int PC = Q + 2;
     const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool fin = (v < V) && (wk.state[v < V ? v : 0] == 1);
+    // DELTA: lanes in state 1; a lane whose information matrix looks (nearly) singular there is left in state 2 for the plain fp64 pass
+    // (launched right behind with want_state = 2): an exactly singular design must be SEEN as singular (note matrix-inversion-error), and
+    // the fp32 part of the DELTA sums blurs a zero pivot to ~1e-7.
+    const bool fin = (v < V) && (wk.state[v < V ? v : 0] == want_state);
     if (!__any(fin)) return;
     const int64_t vr = fin ? v : 0;
     const int N = P.N, NB64 = P.NB64;
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
 #pragma unroll
                 for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
                 double det;
-                if (!ldl_factor<PC>(H, 4.0e-16, &det)) status = 2;
+                if (!ldl_factor<PC>(H, DELTA ? 1.0e-5 : 4.0e-16, &det)) status = DELTA ? 9 : 2;
                 else {
                     double e[PC];
 #pragma unroll
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
         }
     }
     if (!fin) return;
+    if (DELTA && status == 9) { wk.state[v] = 2; return; }           // the fp64 pass decides (bw still holds the beta that came in)
     uint32_t fl = flags[v];
     bool to_firth = false;
     if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }
@@ -1983,8 +1987,10 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
         hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
     }
     else if (which == 5) {
-        if (Q > 0 && P.a0 && P.w0 && P.zz && P.ws) hipLaunchKernelGGL((k_glm_final<Q, true>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
-        else hipLaunchKernelGGL((k_glm_final<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
+        if (Q > 0 && P.a0 && P.w0 && P.zz && P.ws) {
+            hipLaunchKernelGGL((k_glm_final<Q, true>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount, 1);
+            hipLaunchKernelGGL((k_glm_final<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount, 2);
+        } else hipLaunchKernelGGL((k_glm_final<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount, 1);
     }
     else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
