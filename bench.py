@@ -93,13 +93,31 @@ def unpack_rows(bits_u8, N):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baselines (oracle/ = test infrastructure: only this leg, tests/ and smoke() may touch it), bounded samples
 # ---------------------------------------------------------------------------------------------------------------
+def effective_cpus():
+    """CPUs this process can actually use: the affinity mask, cut by the cgroup CPU quota (the GPU boxes show 256 logical CPUs under a
+    quota of 16: more busy threads than that only time-slice, and spinning ones make everything slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(np.ceil(float(q) / float(per)))))
+    except (IOError, OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (IOError, OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline_lmm(U, S, y, C, h2, N, block=1000, blocks_per_proc=3):
     """The reference's own formulation on this host's cores, run the way `pyseer --cpu P` runs it: P worker processes, one BLAS thread
     each, whole blocks of variants per task; per block: residualise, `U.T.dot(A)` through BLAS (lmm_cov.py:186), quadratic forms, F tail
     (oracle/lmm_blas.py).  A separate interpreter forks the workers (oracle/cpu_baseline_lmm.py), so nothing GPU-side is forked."""
     import subprocess
     import tempfile
-    procs = max(1, (os.cpu_count() or 2) // 2)                            # physical cores (SMT siblings add nothing to dgemm)
+    procs = max(1, min(effective_cpus(), (os.cpu_count() or 2) // 2))    # usable cores: cgroup quota, and no SMT siblings (nothing for dgemm)
     with tempfile.TemporaryDirectory() as td:
         f = os.path.join(td, "lmm_inputs.npz")
         np.savez(f, U=U, S=S, y=y, C=C, h2=h2)
@@ -109,8 +127,8 @@ def cpu_baseline_lmm(U, S, y, C, h2, N, block=1000, blocks_per_proc=3):
     if out.returncode != 0:
         raise RuntimeError("cpu baseline failed: " + out.stderr[-2000:])
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    return dict(value=r["variants"] / r["seconds"], unit="variants/s", cores=r["procs"], kind="port",
-                sample="%d synthetic k-mers x %d samples: %d worker processes (as pyseer --cpu), one BLAS thread each, %d blocks of %d variants "
+    return dict(value=r["variants"] / r["seconds"], unit="variants/s", cores=r["procs"], kind="port", host_logical_cpus=os.cpu_count(),
+                sample="%d synthetic k-mers x %d samples: %d worker processes (as pyseer --cpu; = the CPUs this container may use), one BLAS thread each, %d blocks of %d variants "
                        "per worker; fit_lmm_block restated with numpy (oracle/lmm_blas.py): U.T.dot(A) through OpenBLAS dgemm as the reference "
                        "issues it; %.1f variants/s per core" % (r["variants"], N, r["procs"], blocks_per_proc, r["block"],
                                                                r["variants"] / r["seconds"] / r["procs"]))
@@ -119,8 +137,8 @@ def cpu_baseline_lmm(U, S, y, C, h2, N, block=1000, blocks_per_proc=3):
 def cpu_baseline_glm(y, W, nl, nf, N, force_firth, target_s=12.0):
     """oracle/seer_oracle.c (C port of model.py:202-504, OpenMP over variants) on a bounded sample of the same workload."""
     from oracle import oracle as orc
-    ncores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+    ncores = effective_cpus()
+    orc.set_threads(ncores)
     rng = np.random.default_rng(78)
 
     def run(v):
@@ -141,8 +159,9 @@ def cpu_baseline_glm(y, W, nl, nf, N, force_firth, target_s=12.0):
         spent += run(per); done += per
     what = "fit_firth on every variant (orc_firth_batch)" if force_firth else "fixed_effects_regression (orc_fixed_effects_batch)"
     return dict(value=done / spent, unit="variants/s", cores=ncores, kind="port",
-                sample="%d synthetic k-mers x %d samples, %d covariates, %s, oracle/seer_oracle.c with OpenMP on %d threads"
-                       % (done, N, W.shape[1], what, ncores))
+                host_logical_cpus=os.cpu_count(),
+                sample="%d synthetic k-mers x %d samples, %d covariates, %s, oracle/seer_oracle.c with OpenMP on %d threads (= the CPUs this "
+                       "container may use)" % (done, N, W.shape[1], what, ncores))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -209,6 +228,7 @@ def rel_dev(got, want, floor=1e-300):
 def parity_lmm(U, S, y, C, h2, bits_t, out_t, N, n_check=64):
     """Re-check n_check variants of the timed output against the CPU oracle (orc_lmm_block: the reference's fit_lmm_block)."""
     from oracle import oracle as orc
+    orc.set_threads(effective_cpus())
     V = bits_t.shape[0]
     idx = np.linspace(0, V - 1, n_check).astype(np.int64)
     import torch
@@ -223,6 +243,7 @@ def parity_lmm(U, S, y, C, h2, bits_t, out_t, N, n_check=64):
 def parity_glm(y, W, nl, nf, force_firth, bits_t, out_t, fl_t, N, n_check=64):
     from oracle import oracle as orc
     import torch
+    orc.set_threads(effective_cpus())
     V = bits_t.shape[0]
     idx = np.linspace(0, V - 1, n_check).astype(np.int64)
     ti = torch.from_numpy(idx).to(bits_t.device)

@@ -45,6 +45,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """OpenMP threads of the batch entry points (default: the runtime's, i.e. every visible CPU)."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
 def _d(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

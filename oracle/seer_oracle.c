@@ -773,4 +773,17 @@ ORC_API int orc_lineage_effect(const double *lin, int l, const double *cov, int 
     return best;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads of the batch entry points (a container's CPU quota can be far below its visible CPU count) */
+ORC_API void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_abi_version(void) { return 1; }

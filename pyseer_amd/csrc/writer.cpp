@@ -25,6 +25,25 @@ static inline void put_num(std::string &s, double x)
     if (std::isfinite(x)) { char b[40]; const int n = snprintf(b, sizeof b, "%.2E", x); s.append(b, (size_t)n); }
 }
 
+// threads worth starting: the cgroup CPU quota when there is one (a GPU box shows 256 CPUs under a quota of 16; an OpenMP team of 256
+// spinning threads then only steals time from the threads that feed the GPU), at most 32
+static int format_threads()
+{
+    static const int n = [] {
+        int t = 1;
+#ifdef _OPENMP
+        t = omp_get_max_threads();
+#endif
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32]; long per = 0;
+            if (fscanf(f, "%31s %ld", q, &per) == 2 && q[0] != 'm' && per > 0) { const long qq = atol(q); if (qq > 0) t = std::min<long>(t, (qq + per - 1) / per); }
+            fclose(f);
+        }
+        return std::max(1, std::min(t, 32));
+    }();
+    return n;
+}
+
 extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t *sel, int64_t nsel,
                                   const double *const *cols, int ncol, const double *betas, int q, const uint8_t *betas_valid,
                                   const int32_t *lineage, const char *const *lineage_labels, int n_labels,
@@ -33,9 +52,7 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
     if (!names || !name_off || !sel || !cols || !flags || nsel < 0 || ncol < 1) return -1;
     if (q > 0 && (!betas || !betas_valid)) return -1;
     int nth = 1;
-#ifdef _OPENMP
-    nth = omp_get_max_threads();
-#endif
+    nth = format_threads();
     if (nsel < 4096) nth = 1;
     std::vector<std::string> parts((size_t)nth);
 #pragma omp parallel num_threads(nth)
