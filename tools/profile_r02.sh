@@ -6,6 +6,8 @@
 #      SQ busy / wait cycles, GRBM_GUI_ACTIVE                            -> pmc_<cfg>_<group>/
 # tools/summarize_r02.py then collapses them into profiles/r02/.  C3's PMC passes use tools/gpu_probe_lmm.py: torch.linalg.eigh
 # (rocSOLVER) segfaults under counter collection, and the probe has the same kernels at N = 5000 without an eigensolver.
+# NOTE: gpurun MERGES the box's gpurun_out/ into the local one: clear the local gpurun_out/r02 before a new run, or summarise on the box only
+# (the script does: $O/summary), otherwise tools/summarize_r02.py adds up the counter files of two runs.  PMC=0 skips the counter passes.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CFGS=${CFGS:-"C3 C2 C2N5000 C4"}
@@ -22,6 +24,7 @@ pmc() {  # cfg group counters...
   fi
 }
 for c in $CFGS; do
+  [ "${PMC:-1}" = "0" ] && continue
   pmc $c fetch FETCH_SIZE
   pmc $c write WRITE_SIZE
   pmc $c grbm GRBM_GUI_ACTIVE
