@@ -48,12 +48,11 @@ def main(src, dst):
                 dominant = ("quadform_i8<0>" in k or k.endswith("k_lmm_quadform_i8")) if cfg == "C3" else any(g in k for g in GLM)
                 if dominant:
                     tot[c] += sum(v) / (3.0 if cfg == "C3" else 1.0)     # the LMM probe runs three identical batches
-        if not rows:
-            continue
-        with open(os.path.join(dst, "rocprofv3_pmc_summary_%s.csv" % cfg), "w") as f:
-            f.write("pass,kernel,counter,dispatches,sum,mean_per_dispatch\n")
-            for r in rows:
-                f.write("%s,%s,%s,%d,%.6g,%.6g\n" % r)
+        if rows:                                              # a run with PMC=0 has no counter passes: bench line and kernel stats only
+            with open(os.path.join(dst, "rocprofv3_pmc_summary_%s.csv" % cfg), "w") as f:
+                f.write("pass,kernel,counter,dispatches,sum,mean_per_dispatch\n")
+                for r in rows:
+                    f.write("%s,%s,%s,%d,%.6g,%.6g\n" % r)
         tag = "lmm" if cfg == "C3" else cfg.lower()
         if "FETCH_SIZE" in tot:
             json.dump({"kernels": "k_lmm_quadform_i8" if cfg == "C3" else "all k_glm_* / k_firth_* kernels of one step",
