@@ -359,6 +359,8 @@ def main():
     dt_local = time.perf_counter() - t0
     dt = dt_local
     kms, klaunch = eng.get_timing()
+    if not lmm and os.environ.get("SEERHIP_GLM_DEBUG"):
+        eng.glm_info()                                       # the library prints its development counters to stderr
     # sanity: the timed work produced finite statistics (row 2 = beta / kbeta; AF-filtered rows of the fixed-effects configs are NaN by contract)
     fin = torch.isfinite(out[2])
     if not lmm:

@@ -523,8 +523,20 @@ __device__ __forceinline__ void final_pass_mfma(const uint64_t *__restrict__ T, 
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
 struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *tile_list; int *tile_count; };
 
+// wave-aggregated append: one atomic per wavefront; callable from divergent code (the leader is one of the active lanes)
+__device__ __forceinline__ void list_push(bool p, int *__restrict__ list, int *__restrict__ count, int v)
+{
+    const unsigned long long m = __ballot(p);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == lead) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, lead);
+    if (p) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+}
+
 // ---- kernel 1: a1 prefilter + routing + phase A (fast Newton) ---------------------------------------------------------------
-template <int Q>
+template <int Q, bool CHORD>
 __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                  const double *__restrict__ y, const double *__restrict__ W,
                                                  const float *__restrict__ Wf,
@@ -575,12 +587,22 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
         if (to_tile) wk.tile_list[base + __popcll(tm & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)v;
     }
     int it = 0, pass = 0;
+    // CHORD: this kernel only classifies; the fits run as rounds of lean kernels over lists (k_glm_pass32 ... k_glm_chord below)
+    const bool chord_go = CHORD && active;
+    if (CHORD) {
+        if (chord_go) {
+#pragma unroll
+            for (int a = 0; a < PC; ++a) P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
+        }
+        list_push(chord_go, P.ch_list[0], P.ch_cnt, (int)v);
+        active = false;
+    }
     // Newton's iteration is affine invariant, so this phase runs on covariates standardised per column (Wf and the products table
     // are built from them too): a column like "year of isolation" (2000 +- 10) would otherwise defeat the fp32 Hessian and send every
     // variant to the fp64 restart.  Same start vector (the slopes start at 0), same fixed point; beta is mapped back at the end.
     const double *__restrict__ Wx = P.ws ? P.ws : W;
-    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
-    while (__any(active)) {
+    __shared__ float tr[CHORD ? 1 : FastCols<Q>::LDS_FLOATS];
+    while (!CHORD && __any(active)) {
         float Hf[PC * (PC + 1) / 2];
         double g[PC], maxdev;
         // the matrix-pipe pass is wave-wide (permlane swap, MFMA): lanes that already stopped ride along with their frozen beta.
@@ -632,8 +654,8 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
 #pragma unroll
     for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
     flags[v] = fl;
-    wk.state[v] = (want_fit && !need_slow && !to_tile) ? 1 : 0;
-    if (want_fit && !need_slow && !to_tile) {
+    wk.state[v] = (want_fit && !need_slow && !to_tile && !chord_go) ? 1 : 0;
+    if (want_fit && !need_slow && !to_tile && !chord_go) {
         if (P.ws) {                                                  // z' = (z - mean) / scale  =>  b = b' / scale, b0 = b0' - sum b' mean / scale
 #pragma unroll
             for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
@@ -643,6 +665,250 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
     }
     if (need_slow) { const int slot = atomicAdd(wk.slow_count, 1); wk.slow_list[slot] = (int)v; }
     if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
+}
+
+// ---- the fast phase as ROUNDS of lean kernels over lists of variants (GlmParams.chord_on) -------------------------------------
+// k_glm_fast<Q, false> above keeps a variant on its lane through every pass and the solves between them: 256 VGPRs + 570-890 bytes of
+// scratch at two wavefronts per SIMD, every wavefront iterating as long as its slowest lane, and the fp64-score passes at 3.4x the cost of
+// a single-precision one (8.6 vs 2.5 ms per 262 144 variants at N = 5000, q = 10).  Here each pass is its own kernel with only the pass'
+// registers, the 12x12 LDL^T solves are small kernels of their own, and between rounds the variants still iterating are re-listed, so
+// every wavefront of every round is full:
+//   k_glm_fast<Q, true>  prefilter + routing; lists the variants to fit, beta = the warm start                    (ch_list[0])
+//   k_glm_pass32 / k_glm_solve32   one single-precision Newton step per round (Hessian on the matrix pipe) until the step is <= chord_enter
+//   k_glm_score / k_glm_chord      fp64 refinement WITHOUT refreshing the Hessian: with the factor of the last single-precision pass (taken
+//       at distance s from the optimum) the iteration  beta += H1^-1 g(beta)  contracts by ~|H(beta) - H1| / |H| ~ 8 s per round, and the fp64
+//       score (eta in fp64, the logistic function in fp32 as in the fast passes) is all a round evaluates -- 63 VGPRs, 8 wavefronts per SIMD
+//   then k_glm_slow / k_glm_final as before: the final pass takes its exact fp64 Newton step and repeats itself should a lane have been
+//       handed over too early.
+// Anything that does not behave (pivot test, non-finite, no contraction, round limits) goes to k_glm_slow's list: the reference's iteration.
+__device__ __forceinline__ bool round_lane(const int *__restrict__ list, const int *__restrict__ cnt, int64_t idx, int64_t &v)
+{
+    const int n = *cnt;
+    const bool on = idx < n;
+    v = list[on ? idx : 0];
+    return on;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64, 3) void k_glm_pass32(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
+                                                      const float *__restrict__ Wf, GlmParams P, const int *__restrict__ list,
+                                                      const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    double beta[PC], g[PC], maxdev;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
+    float Hf[NH];
+    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
+    fast_pass_mfma<Q, true>(T, Vpad, v, P.N, P.NB64, y, P.ws, Wf, P.zz, beta, Hf, g, maxdev, tr);
+    if (!on) return;
+#pragma unroll
+    for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = Hf[a];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) P.ch_g[(int64_t)a * Vpad + v] = g[a];
+}
+
+template <int Q, bool FIRST>
+__global__ __launch_bounds__(64) void k_glm_solve32(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                    int *__restrict__ next, int *__restrict__ next_cnt, int *__restrict__ chord, int *__restrict__ chord_cnt,
+                                                    int last_round)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const double nobs = (double)P.N;
+    bool go_next = false, go_chord = false, go_slow = false;
+    if (on) {
+        double A[NH], g[PC];
+        if (FIRST) {
+            // the step from the warm start needs no pass over the samples: there eta_i is the NULL model's, so w_i = w0_i and r_i = r0_i do
+            // not depend on the variant, and the variant's row of X^T W X and its score are sums of per-run vectors over the carriers
+            // (k_glm_bitdot); the [1, z] block is the null model's (null_h, a0).  All fp64.
+            A[sidx(0, 0)] = P.null_h[0]; A[sidx(1, 0)] = A[sidx(1, 1)] = P.ch_bd[v];
+            g[0] = P.null_g[0]; g[1] = P.ch_bd[(int64_t)(Q + 1) * Vpad + v];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                A[sidx(2 + j, 0)] = P.null_h[1 + j]; A[sidx(2 + j, 1)] = P.ch_bd[(int64_t)(1 + j) * Vpad + v]; g[2 + j] = P.null_g[1 + j];
+#pragma unroll
+                for (int k = 0; k <= j; ++k) A[sidx(2 + j, 2 + k)] = P.a0[j * (j + 1) / 2 + k];
+            }
+#pragma unroll
+            for (int a = 0; a < NH; ++a) A[a] = A[a] / nobs;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) { A[sidx(a, a)] -= 1e-10; g[a] = g[a] / nobs; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < NH; ++a) A[a] = (double)P.ch_hf[(int64_t)a * Vpad + v] / nobs;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) { A[sidx(a, a)] -= 1e-10; g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; }
+        }
+        double det;
+        if (!ldl_factor<PC>(A, 1e-4, &det)) go_slow = true;                                          // fp32 cannot resolve this design
+        else {
+            ldl_solve<PC>(A, g);
+            double stp = 0.0; bool finite = true;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) {
+                const double b = P.ch_bs[(int64_t)a * Vpad + v] + g[a];
+                stp = fmax(stp, fabs(g[a])); finite = finite && isfinite(b);
+                P.ch_bs[(int64_t)a * Vpad + v] = b;
+            }
+            if (!finite) go_slow = true;
+            else if (stp <= P.chord_enter) {
+                go_chord = true;
+#pragma unroll
+                for (int a = 0; a < NH; ++a) P.ch_fac[(int64_t)a * Vpad + v] = A[a];
+                P.ch_rho[v] = (float)fmin(0.5, fmax(8.0 * stp, 1e-4));
+            }
+            else if (last_round) go_slow = true;
+            else go_next = true;
+        }
+    }
+    list_push(go_next, next, next_cnt, (int)v);
+    list_push(go_chord, chord, chord_cnt, (int)v);
+    list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void k_glm_score(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
+                                                   const double *__restrict__ W, GlmParams P, const int *__restrict__ list,
+                                                   const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2;
+    if ((int64_t)blockIdx.x * 256 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
+    if (!__any(on)) return;
+    const int N = P.N, NB64 = P.NB64;
+    const double *__restrict__ Wx = P.ws ? P.ws : W;
+    double beta[PC], g[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
+    double maxdev = 0.0;
+    for (int wd = 0; wd < NB64; ++wd) {
+        const uint64_t w = T[(int64_t)wd * Vpad + v];
+        const int lim = min(64, N - wd * 64);
+#pragma unroll 2
+        for (int b = 0; b < lim; ++b) {
+            const int i = wd * 64 + b;
+            const bool xb = (w >> b) & 1ull;
+            double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], Wx[(int64_t)i * Q + j], eta);
+            const double mu = (double)(1.0f / (1.0f + __expf(-(float)eta)));
+            const double r = y[i] - mu;
+            maxdev = fmax(maxdev, fabs(r));
+            g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, Wx[(int64_t)i * Q + j], g[2 + j]);
+        }
+    }
+    if (!on) return;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) P.ch_g[(int64_t)a * Vpad + v] = g[a];
+    P.ch_md[v] = maxdev;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                  int *__restrict__ next, int *__restrict__ next_cnt, int last_round)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const double nobs = (double)P.N;
+    bool go_next = false, go_slow = false, go_fin = false;
+    if (on) {
+        double A[NH], g[PC], beta[PC];
+#pragma unroll
+        for (int a = 0; a < NH; ++a) A[a] = P.ch_fac[(int64_t)a * Vpad + v];
+#pragma unroll
+        for (int a = 0; a < PC; ++a) { g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; }
+        ldl_solve<PC>(A, g);
+        double stp = 0.0; bool finite = true;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) { beta[a] += g[a]; stp = fmax(stp, fabs(g[a])); finite = finite && isfinite(beta[a]); }
+        const bool sep = P.ch_md[v] <= 1e-8;
+        if (finite && !sep && (double)P.ch_rho[v] * stp <= P.chord_tol && P.fin_rounds) {         // done: on to the finishing kernels
+            go_fin = true;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
+        }
+        else if (finite && !sep && (double)P.ch_rho[v] * stp <= P.chord_tol) {                     // done: beta to the final pass
+            wk.state[v] = 1;
+            if (P.ws) {
+#pragma unroll
+                for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
+            }
+#pragma unroll
+            for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
+        }
+        else if (!finite || sep || last_round || stp > 0.05) go_slow = true;                       // not contracting: the fp64 restart decides
+        else {
+            go_next = true;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
+        }
+    }
+    list_push(go_next, next, next_cnt, (int)v);
+    list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
+    list_push(go_fin, P.ch_list[4], P.ch_cnt + 30, (int)v);
+}
+
+// ---- sums of per-run vectors over a variant's carriers, by nibble table (the device of k_glm_ols_tab) --------------------------
+// vals[i][c], c < NE = Q + 2: (w0_i, w0_i z_i0 .. w0_i z_i,Q-1, r0_i) at the null model.  tab[(sb * 16 + nib) * 16 + value][c] = the sum
+// over the set bits of `value` of the four samples of nibble `nib` of word `sb`.
+__global__ __launch_bounds__(256) void k_bitdot_build_tab(const double *__restrict__ vals, int NE, int N, int NB64, double *__restrict__ tab)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= NB64 * 256) return;
+    const int value = e & 15, base = (e >> 4) * 4;
+    for (int c = 0; c < NE; ++c) {
+        double a = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k;
+            if (((value >> k) & 1) && i < N) a += vals[(int64_t)i * NE + c];
+        }
+        tab[(int64_t)e * NE + c] = a;
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void k_glm_bitdot(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P)
+{
+    constexpr int NE = Q + 2;
+    __shared__ __attribute__((aligned(16))) double lt[2][256 * NE];
+    const int tid = threadIdx.x;
+    const int64_t v = (int64_t)blockIdx.x * 256 + tid;               // Vpad is a multiple of 256: every thread walks (rows >= V are zero)
+    const int NB64 = P.NB64;
+    const double *__restrict__ tab = P.bd_tab;
+    double acc[NE];
+#pragma unroll
+    for (int c = 0; c < NE; ++c) { acc[c] = 0.0; lt[0][tid * NE + c] = tab[(int64_t)tid * NE + c]; }
+    for (int sb = 0; sb < NB64; sb++) {
+        double nxt[NE];
+        const bool more = sb + 1 < NB64;
+#pragma unroll
+        for (int c = 0; c < NE; ++c) nxt[c] = more ? tab[((int64_t)(sb + 1) * 256 + tid) * NE + c] : 0.0;
+        const uint64_t w = T[(int64_t)sb * Vpad + v];
+        __syncthreads();
+        const double *cur = lt[sb & 1];
+#pragma unroll 4
+        for (int nib = 0; nib < 16; ++nib) {
+            const double *e = cur + (nib * 16 + (int)((w >> (4 * nib)) & 15ull)) * NE;
+#pragma unroll
+            for (int c = 0; c < NE; ++c) acc[c] += e[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NE; ++c) lt[(sb + 1) & 1][tid * NE + c] = nxt[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NE; ++c) P.ch_bd[(int64_t)c * Vpad + v] = acc[c];
 }
 
 // ---- kernel 2: phase B, the reference's all-fp64 iteration restarted for the listed variants -------------------------------
@@ -702,6 +968,33 @@ __global__ __launch_bounds__(256) void k_glm_slow(const uint64_t *__restrict__ T
         flags[v] |= (status == 1) ? SH_NOTE_PERFECT_SEP : SH_NOTE_MATRIX_INV;                   // model.py:345-352
         const int s2 = atomicAdd(firth_count, 1); firth_list[s2] = (int)v;
     }
+}
+
+// the decisions of model.py:332-344, 384 on a finished fit, and its output row (shared by k_glm_final and k_glm_finish)
+template <int Q>
+__device__ __forceinline__ void glm_emit(int status, double bse1, double llf, double (&beta)[Q + 2], bool standardised, int64_t v, int64_t V,
+                                         const GlmParams &P, double *__restrict__ out, uint32_t *__restrict__ flags,
+                                         int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    uint32_t fl = flags[v];
+    bool to_firth = false;
+    if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }
+    else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
+    else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }                         // model.py:332-334
+    else {
+        if (standardised) {                                          // back to the covariates as given
+#pragma unroll
+            for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
+        }
+        const double lrstat = -2.0 * (P.null_llf - llf);
+        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);                        // model.py:336-339
+        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = bse1; out[4 * V + v] = beta[0];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
+        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
+    }
+    flags[v] = fl;
+    if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
 }
 
 // ---- kernel 3: phase C, fp64 evaluation at the final beta + the decisions of model.py:332-344, 384 --------------------------
@@ -773,25 +1066,207 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     }
     if (!fin) return;
     if (DELTA && status == 9) { wk.state[v] = 2; return; }           // the fp64 pass decides (bw still holds the beta that came in)
-    uint32_t fl = flags[v];
-    bool to_firth = false;
-    if (status == 1) { fl |= SH_NOTE_PERFECT_SEP; to_firth = true; }
-    else if (status == 2) { fl |= SH_NOTE_MATRIX_INV; to_firth = true; }
-    else if (bse1 > 3.0) { fl |= SH_NOTE_HIGH_BSE; to_firth = true; }                         // model.py:332-334
-    else {
-        if (DELTA) {                                                 // back to the covariates as given
+    glm_emit<Q>(status, bse1, llf, beta, DELTA, v, V, P, out, flags, firth_list, firth_count);
+}
+
+// ---- the finishing rounds: what k_glm_final<Q, true> does, as three lean kernels over the list of converged variants ------------
+//   k_glm_ll      fp64: eta, mu, the log-likelihood, the separation callback's max |y - mu| and the score        (~70 VGPRs)
+//   k_glm_dpass   fp32: X^T (W - W0) X, every entry a difference from the null model's -- the z x z block on the matrix pipe against the
+//                 products table, the intercept and variant rows on the VALU.  The parts they are differences FROM are exact: the null model's
+//                 block (null_h, a0) and, for the variant's row, the carrier sums of k_glm_bitdot.
+//   k_glm_finish  fp64: assemble and factor the information matrix, bse, the exact Newton step (certificate: <= 5e-7, else the variant is
+//                 restarted by k_glm_slow), decisions and the output row.
+template <int Q>
+__global__ __launch_bounds__(256) void k_glm_ll(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y, GlmParams P,
+                                                const int *__restrict__ list, const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2;
+    if ((int64_t)blockIdx.x * 256 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
+    if (!__any(on)) return;
+    const int N = P.N, NB64 = P.NB64;
+    const double *__restrict__ Wx = P.ws;
+    double beta[PC], g[PC];
 #pragma unroll
-            for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
+    for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
+    double maxdev = 0.0, ll = 0.0;
+    for (int wd = 0; wd < NB64; ++wd) {
+        const uint64_t w = T[(int64_t)wd * Vpad + v];
+        const int lim = min(64, N - wd * 64);
+        for (int b = 0; b < lim; ++b) {
+            const int i = wd * 64 + b;
+            const bool xb = (w >> b) & 1ull;
+            double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], Wx[(int64_t)i * Q + j], eta);
+            const double yi = y[i];
+            const double mu = 1.0 / (1.0 + exp(-eta));                            // SM Logit.cdf
+            const double r = yi - mu;
+            maxdev = fmax(maxdev, fabs(r));
+            const double lm = log(mu);                                            // SM Logit.loglike, as info_pass
+            ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+            g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, Wx[(int64_t)i * Q + j], g[2 + j]);
         }
-        const double lrstat = -2.0 * (P.null_llf - llf);
-        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);                        // model.py:336-339
-        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = bse1; out[4 * V + v] = beta[0];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
-        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;   // model.py:384
     }
-    flags[v] = fl;
-    if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
+    if (!on) return;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) P.ch_g[(int64_t)a * Vpad + v] = g[a];
+    P.ch_md[v] = maxdev; P.ch_ll[v] = ll;
+}
+
+template <int Q>
+__global__ __launch_bounds__(64, 3) void k_glm_dpass(const uint64_t *__restrict__ T, int64_t Vpad, const float *__restrict__ Wf, GlmParams P,
+                                                     const int *__restrict__ list, const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const int N = P.N;
+    const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
+    const float *__restrict__ ZZ = P.zz;
+    const double *__restrict__ w0 = P.w0;
+    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
+    float bf[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) bf[a] = (float)P.ch_bs[(int64_t)a * Vpad + v];
+    v16f acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][h][r] = 0.0f;
+    float h00 = 0.0f, h10 = 0.0f, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0[j] = 0.0f; hz1[j] = 0.0f; }
+    auto sample = [&](int i, bool xb) -> float {
+        float eta = bf[0] + (xb ? bf[1] : 0.0f);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j], Wf[(int64_t)i * Q + j], eta);
+        const float mu = 1.0f / (1.0f + __expf(-eta));
+        const float d = mu * (1.0f - mu) - (float)w0[i];
+        const float dx = xb ? d : 0.0f;
+        h00 += d; h10 += dx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0[j] = fmaf(d, zj, hz0[j]); hz1[j] = fmaf(dx, zj, hz1[j]); }
+        return d;
+    };
+    const int nfull = N >> 1;
+    for (int pr = 0; pr < nfull; ++pr) {
+        const int i = 2 * pr, b = i & 63;
+        const float *zrow = ZZ + (int64_t)(i + lh) * STRIDE + l31;
+        float bz[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) bz[cb] = zrow[cb * 32];
+        const uint64_t w = T[(int64_t)(i >> 6) * Vpad + v];
+        const float d0 = sample(i, (w >> b) & 1ull);
+        const float d1 = sample(i + 1, (w >> (b + 1)) & 1ull);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d1), false, false);
+        const float a0f = __uint_as_float(sw[0]), a1f = __uint_as_float(sw[1]);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0f, bz[cb], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1f, bz[cb], acc[cb][1], 0, 0, 0);
+        }
+    }
+    if (N & 1) {
+        const int i = N - 1;
+        const float *zrow = ZZ + (int64_t)i * STRIDE + l31;
+        const float d0 = sample(i, (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), 0u, false, false);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[0]), zrow[cb * 32], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[1]), zrow[cb * 32], acc[cb][1], 0, 0, 0);
+        }
+    }
+    float H[NH];
+    H[sidx(0, 0)] = h00; H[sidx(1, 0)] = h10; H[sidx(1, 1)] = h10;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0[j]; H[sidx(2 + j, 1)] = hz1[j]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * (STRIDE + 1) + cb * 32 + l31] = acc[cb][h][r];
+        __syncthreads();
+        if (lh == h) {
+            const float *row = tr + l31 * (STRIDE + 1);
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
+        }
+    }
+    if (!on) return;
+#pragma unroll
+    for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmParams P, GlmWork wk, const int *__restrict__ list,
+                                                   const int *__restrict__ cnt, double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                   int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const double nobs = (double)P.N;
+    bool go_slow = false;
+    if (on) {
+        double beta[PC];
+#pragma unroll
+        for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
+        int status = 0;
+        double bse1 = NAN;
+        const double llf = P.ch_ll[v];
+        bool emit = true;
+        if (P.ch_md[v] <= 1e-8) status = 1;                                                       // callback after the last update
+        else {
+            double H[NH], g[PC];
+            H[sidx(0, 0)] = P.null_h[0]; H[sidx(1, 0)] = H[sidx(1, 1)] = P.ch_bd[v];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                H[sidx(2 + j, 0)] = P.null_h[1 + j]; H[sidx(2 + j, 1)] = P.ch_bd[(int64_t)(1 + j) * Vpad + v];
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = P.a0[j * (j + 1) / 2 + k];
+            }
+#pragma unroll
+            for (int a = 0; a < NH; ++a) H[a] = (H[a] + (double)P.ch_hf[(int64_t)a * Vpad + v]) / nobs;
+            double det;
+            if (!ldl_factor<PC>(H, 1.0e-5, &det)) {                  // (nearly) singular: the plain fp64 pass decides (k_glm_final<Q, false>, state 2)
+                emit = false; wk.state[v] = 2;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
+#pragma unroll
+                for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
+            } else {
+                double e[PC];
+#pragma unroll
+                for (int a = 0; a < PC; ++a) { e[a] = (a == 1) ? 1.0 : 0.0; g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; }
+                ldl_solve<PC>(H, e);
+                bse1 = sqrt(e[1] / nobs);
+                ldl_solve<PC>(H, g);
+                double smax = 0.0; bool finite = true;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) { smax = fmax(smax, fabs(g[a])); finite = finite && isfinite(g[a]); }
+                if (!finite || smax > 5e-7) { emit = false; go_slow = true; if (P.dbg) atomicAdd(&P.dbg[4], 1); }
+                else {
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) beta[a] += g[a];
+                }
+            }
+        }
+        if (emit) glm_emit<Q>(status, bse1, llf, beta, true, v, V, P, out, flags, firth_list, firth_count);
+    }
+    list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
 
 // =====================================================================================================================
@@ -1981,7 +2456,37 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                              int *plist, int *pcount, GlmWork wk)
 {
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64);
-    if (which == 0) hipLaunchKernelGGL(k_glm_fast<Q>, grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
+    if (which == 0) {
+        if (P.chord_on && Q > 0 && P.zz) {
+            // counters: ch_cnt[0 .. n32] Newton lists, ch_cnt[n32 + 1 ..] chord lists (zeroed by the caller); lists ping-pong
+            const int n32 = P.chord_n32, nc = P.chord_rounds;
+            int *cc = P.ch_cnt + n32 + 1;
+            hipLaunchKernelGGL((k_glm_fast<Q, true>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
+            const dim3 g256((unsigned)(Vpad / 256)), b256(256);
+            int r0 = 0;
+            if (P.bd_tab) {                                          // carrier sums: the first Newton step needs no pass, the finishing rounds use them too
+                hipLaunchKernelGGL(k_glm_bitdot<Q>, g256, b256, 0, st, T, Vpad, P);
+                hipLaunchKernelGGL((k_glm_solve32<Q, true>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1,
+                                   P.ch_list[2], cc, n32 == 1 ? 1 : 0);
+                r0 = 1;
+            }
+            for (int r = r0; r < n32; ++r) {
+                hipLaunchKernelGGL(k_glm_pass32<Q>, grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
+                hipLaunchKernelGGL((k_glm_solve32<Q, false>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[r & 1], P.ch_cnt + r, P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1,
+                                   P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
+            }
+            for (int r = 0; r < nc; ++r) {
+                hipLaunchKernelGGL(k_glm_score<Q>, g256, b256, 0, st, T, Vpad, y, W, P, P.ch_list[2 + (r & 1)], cc + r);
+                hipLaunchKernelGGL(k_glm_chord<Q>, grid, blk, 0, st, Vpad, P, wk, P.ch_list[2 + (r & 1)], cc + r, P.ch_list[2 + ((r + 1) & 1)], cc + r + 1,
+                                   r == nc - 1 ? 1 : 0);
+            }
+            if (P.fin_rounds) {
+                hipLaunchKernelGGL(k_glm_ll<Q>, g256, b256, 0, st, T, Vpad, y, P, P.ch_list[4], P.ch_cnt + 30);
+                hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
+                hipLaunchKernelGGL(k_glm_finish<Q>, grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[4], P.ch_cnt + 30, out, flags, flist, fcount);
+            }
+        } else hipLaunchKernelGGL((k_glm_fast<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
+    }
     else if (which == 4) {
         const int S = std::min(4, glm_split_waves(P.NB64));      // 400+ VGPRs per lane: at most four wavefronts per block
         hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
@@ -2014,6 +2519,12 @@ extern "C" hipError_t shk_glm_launch(hipStream_t st, int Q, int which, const uin
     default: return hipErrorInvalidValue;
     }
 #undef GLM_CASE
+}
+
+extern "C" hipError_t shk_bitdot_build_tab(hipStream_t st, const double *vals, int NE, int N, int NB64, double *tab)
+{
+    hipLaunchKernelGGL(k_bitdot_build_tab, dim3((unsigned)NB64), dim3(256), 0, st, vals, NE, N, NB64, tab);
+    return hipGetLastError();
 }
 
 // ---- Firth state machine launchers: which = 0 init, 1 eval, 2 step, 3 hand-off list; n = upper bound of the list length ----

@@ -34,6 +34,20 @@ struct GlmParams {
     int *dbg;                     // development counters (SEERHIP_GLM_DEBUG): [0] wave passes, [1] waves, [2] lane steps, [3] fitted lanes, [4] final-pass repeats
     double f32_tol;               // a single-precision pass whose step is <= f32_tol ends the fast phase (the fp32 score's noise floor is ~1e-7)
     double fast_tol;              // largest step (any coordinate) at which the fast phase hands over to the final pass' exact Newton step
+    // The fast phase as rounds of lean kernels over lists (glm_kernels.hip, "the fast phase as ROUNDS"): single-precision Newton rounds until a
+    // lane's step is <= chord_enter, then chord rounds (fp64 score, the last single-precision Hessian factor kept) until rho * step <= chord_tol.
+    // Workspaces are SoA over the batch's padded variant count: ch_bs / ch_g [PC][Vpad], ch_fac [PC(PC+1)/2][Vpad] (double), ch_hf the same
+    // shape in float, ch_md / ch_rho [Vpad]; ch_list: two ping-pong lists for the Newton rounds, two for the chord rounds; ch_cnt their counters.
+    // ch_list[4] + ch_cnt[30]: the converged variants, for the finishing kernels (fin_rounds; k_glm_ll / k_glm_dpass / k_glm_finish).
+    // bd_tab: nibble tables of (w0, w0 z, r0) at the null model (k_glm_bitdot -> ch_bd [Q+2][Vpad]); null_h = (sum w0, sum w0 z_j),
+    // null_g = the null model's score (sum r0, sum r0 z_j; ~1e-12), both in the standardised coordinates.
+    int chord_on, chord_n32, chord_rounds, fin_rounds;
+    double chord_enter, chord_tol;
+    double *ch_bs, *ch_fac, *ch_g, *ch_md, *ch_bd, *ch_ll;
+    float *ch_hf, *ch_rho;
+    int *ch_list[5], *ch_cnt;
+    const double *bd_tab;
+    double null_h[16], null_g[16];
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
 #define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */

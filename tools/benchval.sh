@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage: tools/benchval.sh <bench.py args...>  -> one short line (value, ms/step, kernel ms) + any "[glm debug]" line
+python bench.py "$@" 2>/tmp/benchval.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.readlines()[-1])
+print('value %.4g %s  ms/step %.3f  kernel_ms %s  parity %s' % (d['value'], d['unit'], d['ms_per_step'], d['roofline'].get('kernel_ms'), d.get('parity_max_rel_dev')))
+"
+grep "glm debug" /tmp/benchval.err | tail -1
