@@ -523,6 +523,13 @@ __device__ __forceinline__ void final_pass_mfma(const uint64_t *__restrict__ T, 
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
 struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *tile_list; int *tile_count; };
 
+// Scalar loads return out of order, so the only wait the compiler can place for them is "all of them" (s_waitcnt lgkmcnt(0)).  A software
+// pipeline over two wave-uniform buffers therefore needs the wait for buffer A to sit BEFORE the loads of buffer B are issued; left alone,
+// the scheduler hoists B's loads above A's first use and the wait then covers both.  pipe_zero(x) is a zero the compiler cannot see
+// through, computed from one of A's SGPRs: added to B's index, it orders B's loads behind A's arrival and keeps them scalar.
+__device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x))); return z; }
+__device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x))); return z; }
+
 // wave-aggregated append: one atomic per wavefront; callable from divergent code (the leader is one of the active lanes)
 __device__ __forceinline__ void list_push(bool p, int *__restrict__ list, int *__restrict__ count, int v)
 {
@@ -667,6 +674,148 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
     if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
 }
 
+// ---- a single-precision pass with the two samples of an MFMA issue as the halves of packed-fp32 operations -------------------------
+// v_pk_fma_f32 and friends do two fp32 operations per lane per issue; an unpacked fp32 instruction costs the same four cycles per
+// wavefront as an fp64 one.  Samples (2p, 2p + 1) feed one MFMA issue anyway, so eta, mu, w and every VALU accumulator are carried as
+// float2 = (even sample, odd sample) and their sums are folded at the end of the pass.  Needs the covariates in pair layout
+// (GlmParams.wfp: [pair][Q] float2) and y, w0 as float arrays (yf, w0f).  DELTA: the A operand is w - w0 and no score is formed (k_glm_dpass).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+template <int Q, bool DELTA>
+__device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
+                                          const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr)
+{
+    constexpr int PC = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE;
+    const int N = P.N;
+    const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
+    const float *__restrict__ ZZ = P.zz;
+    // per pair of samples one wave-uniform record: z (Q float2), y pair, w0 pair -- fetched one pair AHEAD (scalar loads otherwise sit
+    // exposed in front of every pair: ~900 cycles per pair and wavefront, measured), as is the lane's B operand of the MFMA
+    constexpr int RS = Q + 2;
+    const v2f *__restrict__ Rp = (const v2f *)P.wfp;
+    v16f acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][h][r] = 0.0f;
+    v2f bf[PC], gf[PC], h00 = {0.0f, 0.0f}, h10 = {0.0f, 0.0f}, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) { const float b = (float)beta[a]; bf[a] = v2f{b, b}; gf[a] = v2f{0.0f, 0.0f}; }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f}; }
+    const int nfull = N >> 1;
+    auto pair = [&](const v2f (&rec)[RS], const float (&bz)[NCB], uint32_t two) {
+        const v2f xb = {(float)(two & 1u), (float)(two >> 1)};
+        v2f eta = pkfma(xb, bf[1], bf[0]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = pkfma(bf[2 + j], rec[j], eta);
+        v2f mu;
+        mu.x = 1.0f / (1.0f + __expf(-eta.x)); mu.y = 1.0f / (1.0f + __expf(-eta.y));
+        const v2f wf = pkfma(-mu, mu, mu);
+        v2f d = wf;
+        if (DELTA) d = wf - rec[Q + 1];
+        else {
+            const v2f r = rec[Q] - mu;
+            gf[0] += r; gf[1] = pkfma(xb, r, gf[1]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) gf[2 + j] = pkfma(r, rec[j], gf[2 + j]);
+        }
+        const v2f dx = xb * d;
+        h00 += d; h10 += dx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d.x), __float_as_uint(d.y), false, false);
+        const float a0f = __uint_as_float(sw[0]), a1f = __uint_as_float(sw[1]);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0f, bz[cb], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1f, bz[cb], acc[cb][1], 0, 0, 0);
+        }
+    };
+    auto fetch = [&](int pr, v2f (&rec)[RS], float (&bz)[NCB]) {
+#pragma unroll
+        for (int k = 0; k < RS; ++k) rec[k] = Rp[(int64_t)pr * RS + k];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) bz[cb] = ZZ[(int64_t)(2 * pr + lh) * STRIDE + l31 + cb * 32];
+    };
+    // two record / B-operand buffers in turn: pair p + 1 is fetched while pair p is computed.  A 64-sample word holds 32 pairs.
+    v2f ra[RS], rb[RS];
+    float za[NCB], zb[NCB];
+    const int nwords = nfull >> 5;                                            // whole words: pipelined
+    if (nfull > 0) fetch(0, ra, za);
+    for (int wd = 0; wd < nwords; ++wd) {
+        const uint64_t w = T[(int64_t)wd * Vpad + v];
+        for (int k = 0; k < 32; k += 2) {
+            const int pr = wd * 32 + k;
+            fetch(pr + 1 + pipe_zero(ra[0].x), rb, zb);
+            pair(ra, za, (uint32_t)(w >> (2 * k)) & 3u);
+            fetch(min(pr + 2, nfull - 1) + pipe_zero(rb[0].x), ra, za);
+            pair(rb, zb, (uint32_t)(w >> (2 * k + 2)) & 3u);
+        }
+    }
+    for (int pr = nwords * 32; pr < nfull; ++pr) {                            // the last partial word, plainly
+        const uint64_t w = T[(int64_t)(pr >> 5) * Vpad + v];
+        fetch(pr, ra, za);
+        pair(ra, za, (uint32_t)(w >> (2 * (pr & 31))) & 3u);
+    }
+    float h00s = h00.x + h00.y, h10s = h10.x + h10.y, gs[PC], hz0s[Q > 0 ? Q : 1], hz1s[Q > 0 ? Q : 1];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) gs[a] = gf[a].x + gf[a].y;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0s[j] = hz0[j].x + hz0[j].y; hz1s[j] = hz1[j].x + hz1[j].y; }
+    if (N & 1) {                                                              // the odd sample: k = 1 rows of A are zero
+        const int i = N - 1;
+        const float *zrow = ZZ + (int64_t)i * STRIDE + l31;
+        const bool xb = (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull;
+        float eta = bf[0].x + (xb ? bf[1].x : 0.0f);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j].x, Wf[(int64_t)i * Q + j], eta);
+        const float mu = 1.0f / (1.0f + __expf(-eta));
+        const float wf = mu * (1.0f - mu);
+        float d = wf;
+        if (DELTA) d = wf - P.w0f[i];
+        else {
+            const float r = P.yf[i] - mu;
+            gs[0] += r; gs[1] += xb ? r : 0.0f;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) gs[2 + j] = fmaf(r, Wf[(int64_t)i * Q + j], gs[2 + j]);
+        }
+        const float dx = xb ? d : 0.0f;
+        h00s += d; h10s += dx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0s[j] = fmaf(d, zj, hz0s[j]); hz1s[j] = fmaf(dx, zj, hz1s[j]); }
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), 0u, false, false);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[0]), zrow[cb * 32], acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(sw[1]), zrow[cb * 32], acc[cb][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < PC; ++a) g[a] = (double)gs[a];
+    H[sidx(0, 0)] = h00s; H[sidx(1, 0)] = h10s; H[sidx(1, 1)] = h10s;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0s[j]; H[sidx(2 + j, 1)] = hz1s[j]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * (STRIDE + 1) + cb * 32 + l31] = acc[cb][h][r];
+        __syncthreads();
+        if (lh == h) {
+            const float *row = tr + l31 * (STRIDE + 1);
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
+        }
+    }
+}
+
 // ---- the fast phase as ROUNDS of lean kernels over lists of variants (GlmParams.chord_on) -------------------------------------
 // k_glm_fast<Q, false> above keeps a variant on its lane through every pass and the solves between them: 256 VGPRs + 570-890 bytes of
 // scratch at two wavefronts per SIMD, every wavefront iterating as long as its slowest lane, and the fp64-score passes at 3.4x the cost of
@@ -689,8 +838,8 @@ __device__ __forceinline__ bool round_lane(const int *__restrict__ list, const i
     return on;
 }
 
-template <int Q>
-__global__ __launch_bounds__(64, 3) void k_glm_pass32(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
+template <int Q, bool PK>
+__global__ __launch_bounds__(64, PK ? 2 : 3) void k_glm_pass32(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
                                                       const float *__restrict__ Wf, GlmParams P, const int *__restrict__ list,
                                                       const int *__restrict__ cnt)
 {
@@ -703,7 +852,8 @@ __global__ __launch_bounds__(64, 3) void k_glm_pass32(const uint64_t *__restrict
     for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
     float Hf[NH];
     __shared__ float tr[FastCols<Q>::LDS_FLOATS];
-    fast_pass_mfma<Q, true>(T, Vpad, v, P.N, P.NB64, y, P.ws, Wf, P.zz, beta, Hf, g, maxdev, tr);
+    if (PK) pass32_pk<Q, false>(T, Vpad, v, P, Wf, beta, Hf, g, tr);
+    else fast_pass_mfma<Q, true>(T, Vpad, v, P.N, P.NB64, y, P.ws, Wf, P.zz, beta, Hf, g, maxdev, tr);
     if (!on) return;
 #pragma unroll
     for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = Hf[a];
@@ -778,33 +928,54 @@ __global__ __launch_bounds__(256) void k_glm_score(const uint64_t *__restrict__ 
                                                    const double *__restrict__ W, GlmParams P, const int *__restrict__ list,
                                                    const int *__restrict__ cnt)
 {
-    constexpr int PC = Q + 2;
+    constexpr int PC = Q + 2, RS = Q + 1;                            // record of a sample: its standardised covariates, then y (GlmParams.rec)
     if ((int64_t)blockIdx.x * 256 >= *cnt) return;
     int64_t v;
     const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
     if (!__any(on)) return;
     const int N = P.N, NB64 = P.NB64;
-    const double *__restrict__ Wx = P.ws ? P.ws : W;
+    const double *__restrict__ R = P.rec;
     double beta[PC], g[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
     double maxdev = 0.0;
+    // Two record buffers in turn, each fetched while the other sample is computed: the scalar loads are otherwise exposed in front of every
+    // sample (measured: 2.3x the VALU time).  Whole 64-sample words run in this pipelined form, the last partial word plainly.
+    auto one = [&](const double (&rc)[RS], bool xb) {
+        double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
+        const double mu = (double)(1.0f / (1.0f + __expf(-(float)eta)));
+        const double r = rc[Q] - mu;
+        maxdev = fmax(maxdev, fabs(r));
+        g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, rc[j], g[2 + j]);
+    };
+    double ra[RS], rb[RS];
+#pragma unroll
+    for (int k = 0; k < RS; ++k) ra[k] = R[k];
     for (int wd = 0; wd < NB64; ++wd) {
         const uint64_t w = T[(int64_t)wd * Vpad + v];
         const int lim = min(64, N - wd * 64);
-#pragma unroll 2
-        for (int b = 0; b < lim; ++b) {
-            const int i = wd * 64 + b;
-            const bool xb = (w >> b) & 1ull;
-            double eta = beta[0] + (xb ? beta[1] : 0.0);
+        if (lim == 64) {
+            for (int b = 0; b < 64; b += 2) {
+                const int i = wd * 64 + b, i2 = min(i + 2, N - 1);
+                const int za = pipe_zero(ra[0]);
 #pragma unroll
-            for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], Wx[(int64_t)i * Q + j], eta);
-            const double mu = (double)(1.0f / (1.0f + __expf(-(float)eta)));
-            const double r = y[i] - mu;
-            maxdev = fmax(maxdev, fabs(r));
-            g[0] += r; g[1] += xb ? r : 0.0;
+                for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
+                one(ra, (w >> b) & 1ull);
+                const int zb = pipe_zero(rb[0]);
 #pragma unroll
-            for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, Wx[(int64_t)i * Q + j], g[2 + j]);
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
+                one(rb, (w >> (b + 1)) & 1ull);
+            }
+        } else {
+            for (int b = 0; b < lim; ++b) {
+#pragma unroll
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(wd * 64 + b) * RS + k];
+                one(ra, (w >> b) & 1ull);
+            }
         }
     }
     if (!on) return;
@@ -1069,6 +1240,30 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     glm_emit<Q>(status, bse1, llf, beta, DELTA, v, V, P, out, flags, firth_list, firth_count);
 }
 
+// e^-x for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 (two-part ln 2), |r| <= 0.3466, Taylor to degree 13 (remainder 4e-18), 2^k by v_ldexp
+__device__ __forceinline__ double exp_neg(double x)
+{
+    const double u = -fmin(x, 800.0);
+    const double kf = rint(u * 1.4426950408889634074);
+    double r = fma(kf, -6.93147180369123816490e-01, u);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                       // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                    // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                    // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);                   // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
 // ---- the finishing rounds: what k_glm_final<Q, true> does, as three lean kernels over the list of converged variants ------------
 //   k_glm_ll      fp64: eta, mu, the log-likelihood, the separation callback's max |y - mu| and the score        (~70 VGPRs)
 //   k_glm_dpass   fp32: X^T (W - W0) X, every entry a difference from the null model's -- the z x z block on the matrix pipe against the
@@ -1080,41 +1275,72 @@ template <int Q>
 __global__ __launch_bounds__(256) void k_glm_ll(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y, GlmParams P,
                                                 const int *__restrict__ list, const int *__restrict__ cnt)
 {
-    constexpr int PC = Q + 2;
+    constexpr int PC = Q + 2, RS = Q + 1;
     if ((int64_t)blockIdx.x * 256 >= *cnt) return;
     int64_t v;
     const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
     if (!__any(on)) return;
     const int N = P.N, NB64 = P.NB64;
-    const double *__restrict__ Wx = P.ws;
+    const double *__restrict__ R = P.rec;
     double beta[PC], g[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
-    double maxdev = 0.0, ll = 0.0;
+    // y is 0/1 here (sh_glm_setup turns the finishing kernels off otherwise): ll_i = -softplus(a_i), a_i = (1 - 2 y_i) eta_i (= log mu_i for
+    // y = 1, log(1 - mu_i) for y = 0: SM Logit.loglike), and with t = exp(-|eta|):  softplus(a) = max(a, 0) + log(1 + t),  mu = 1 / (1 + t)
+    // or t / (1 + t).  The logs are not taken one by one: the factors 1 + t in (1, 2] are MULTIPLIED (one rounding each, like a sum's),
+    // renormalised once per 64-sample word, and one log at the end turns the product into the sum.  One exp (argument reduced, degree-13
+    // polynomial, v_ldexp) and one reciprocal per sample, no log.  The sample's record is fetched one sample ahead.
+    double maxdev = 0.0, apos = 0.0, prod = 1.0;
+    int pexp = 0;
+    auto one = [&](const double (&rc)[RS], bool xb) {
+        double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
+        const double yi = rc[Q];
+        const double t = exp_neg(fabs(eta)), u = 1.0 + t;
+        double inv = __builtin_amdgcn_rcp(u);                                      // two Newton steps: 1 / u to the last bit or two
+        inv = fma(fma(-u, inv, 1.0), inv, inv);
+        inv = fma(fma(-u, inv, 1.0), inv, inv);
+        const double mu = (eta >= 0.0) ? inv : t * inv;
+        const double r = yi - mu;
+        apos += fmax(fma(-2.0 * yi, eta, eta), 0.0);                              // a = (1 - 2 y) eta
+        prod *= u;
+        maxdev = fmax(maxdev, fabs(r));
+        g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, rc[j], g[2 + j]);
+    };
+    double ra[RS], rb[RS];                                           // two record buffers in turn, as in k_glm_score
+#pragma unroll
+    for (int k = 0; k < RS; ++k) ra[k] = R[k];
     for (int wd = 0; wd < NB64; ++wd) {
         const uint64_t w = T[(int64_t)wd * Vpad + v];
         const int lim = min(64, N - wd * 64);
-        for (int b = 0; b < lim; ++b) {
-            const int i = wd * 64 + b;
-            const bool xb = (w >> b) & 1ull;
-            double eta = beta[0] + (xb ? beta[1] : 0.0);
+        if (lim == 64) {
+            for (int b = 0; b < 64; b += 2) {
+                const int i = wd * 64 + b, i2 = min(i + 2, N - 1);
+                const int za = pipe_zero(ra[0]);
 #pragma unroll
-            for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], Wx[(int64_t)i * Q + j], eta);
-            const double yi = y[i];
-            const double mu = 1.0 / (1.0 + exp(-eta));                            // SM Logit.cdf
-            const double r = yi - mu;
-            maxdev = fmax(maxdev, fabs(r));
-            const double lm = log(mu);                                            // SM Logit.loglike, as info_pass
-            ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
-            g[0] += r; g[1] += xb ? r : 0.0;
+                for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
+                one(ra, (w >> b) & 1ull);
+                const int zb = pipe_zero(rb[0]);
 #pragma unroll
-            for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, Wx[(int64_t)i * Q + j], g[2 + j]);
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
+                one(rb, (w >> (b + 1)) & 1ull);
+            }
+        } else {
+            for (int b = 0; b < lim; ++b) {
+#pragma unroll
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(wd * 64 + b) * RS + k];
+                one(ra, (w >> b) & 1ull);
+            }
         }
+        int e2; prod = frexp(prod, &e2); pexp += e2;
     }
     if (!on) return;
 #pragma unroll
     for (int a = 0; a < PC; ++a) P.ch_g[(int64_t)a * Vpad + v] = g[a];
-    P.ch_md[v] = maxdev; P.ch_ll[v] = ll;
+    P.ch_md[v] = maxdev; P.ch_ll[v] = -(apos + fma((double)pexp, 0.6931471805599453, log(prod)));
 }
 
 template <int Q>
@@ -1204,6 +1430,25 @@ __global__ __launch_bounds__(64, 3) void k_glm_dpass(const uint64_t *__restrict_
                 for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
         }
     }
+    if (!on) return;
+#pragma unroll
+    for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
+}
+
+template <int Q>
+__global__ __launch_bounds__(64, 2) void k_glm_dpass_pk(const uint64_t *__restrict__ T, int64_t Vpad, const float *__restrict__ Wf, GlmParams P,
+                                                        const int *__restrict__ list, const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
+    double beta[PC], g[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
+    float H[NH];
+    pass32_pk<Q, true>(T, Vpad, v, P, Wf, beta, H, g, tr);
     if (!on) return;
 #pragma unroll
     for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
@@ -2471,7 +2716,8 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                 r0 = 1;
             }
             for (int r = r0; r < n32; ++r) {
-                hipLaunchKernelGGL(k_glm_pass32<Q>, grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
+                if (P.wfp) hipLaunchKernelGGL((k_glm_pass32<Q, true>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
+                else hipLaunchKernelGGL((k_glm_pass32<Q, false>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
                 hipLaunchKernelGGL((k_glm_solve32<Q, false>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[r & 1], P.ch_cnt + r, P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1,
                                    P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
             }
@@ -2482,7 +2728,8 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
             }
             if (P.fin_rounds) {
                 hipLaunchKernelGGL(k_glm_ll<Q>, g256, b256, 0, st, T, Vpad, y, P, P.ch_list[4], P.ch_cnt + 30);
-                hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
+                if (P.wfp) hipLaunchKernelGGL(k_glm_dpass_pk<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
+                else hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
                 hipLaunchKernelGGL(k_glm_finish<Q>, grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[4], P.ch_cnt + 30, out, flags, flist, fcount);
             }
         } else hipLaunchKernelGGL((k_glm_fast<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);

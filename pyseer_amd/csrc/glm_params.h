@@ -47,6 +47,9 @@ struct GlmParams {
     float *ch_hf, *ch_rho;
     int *ch_list[5], *ch_cnt;
     const double *bd_tab;
+    const float *wfp, *yf, *w0f;  // packed-fp32 passes (pass32_pk): wfp = per pair of samples a record of Q + 2 float2 (standardised covariates, y, w0;
+                                  // each (even sample, odd sample)); yf, w0f = y and w0 as float arrays (the odd last sample); null = unpacked passes
+    const double *rec;            // per sample a record of Q + 1 doubles (standardised covariates, then y): k_glm_score / k_glm_ll
     double null_h[16], null_g[16];
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
