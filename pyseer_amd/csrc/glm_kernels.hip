@@ -680,6 +680,9 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
 // float2 = (even sample, odd sample) and their sums are folded at the end of the pass.  Needs the covariates in pair layout
 // (GlmParams.wfp: [pair][Q] float2) and y, w0 as float arrays (yf, w0f).  DELTA: the A operand is w - w0 and no score is formed (k_glm_dpass).
 typedef float v2f __attribute__((ext_vector_type(2)));
+// the logistic function on the transcendental unit alone: v_exp_f32 and v_rcp_f32 (1 ulp each) instead of expf's range fix-ups and an IEEE
+// division (~12 instructions).  exp2 overflows to inf -> mu = 0, underflows to 0 -> mu = 1: the right limits.
+__device__ __forceinline__ float sigmoid_fast(float eta) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(eta * -1.4426950408889634f)); }
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 template <int Q, bool DELTA>
 __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
@@ -712,7 +715,7 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = pkfma(bf[2 + j], rec[j], eta);
         v2f mu;
-        mu.x = 1.0f / (1.0f + __expf(-eta.x)); mu.y = 1.0f / (1.0f + __expf(-eta.y));
+        mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y);
         const v2f wf = pkfma(-mu, mu, mu);
         v2f d = wf;
         if (DELTA) d = wf - rec[Q + 1];
@@ -734,30 +737,38 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
             acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1f, bz[cb], acc[cb][1], 0, 0, 0);
         }
     };
-    auto fetch = [&](int pr, v2f (&rec)[RS], float (&bz)[NCB]) {
+    auto fetch_rec = [&](int pr, v2f (&rec)[RS]) {
 #pragma unroll
         for (int k = 0; k < RS; ++k) rec[k] = Rp[(int64_t)pr * RS + k];
+    };
+    auto fetch_bz = [&](int pr, float (&bz)[NCB]) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) bz[cb] = ZZ[(int64_t)(2 * pr + lh) * STRIDE + l31 + cb * 32];
     };
-    // two record / B-operand buffers in turn: pair p + 1 is fetched while pair p is computed.  A 64-sample word holds 32 pairs.
+    // Records: two buffers in turn, pair p + 1 fetched while pair p is computed (scalar loads, ordered by pipe_zero).  The lane's B operands
+    // come from L2 (the products table is 1.3 MB at N = 5000): four buffers, fetched two pairs ahead.  A 64-sample word holds 32 pairs.
     v2f ra[RS], rb[RS];
-    float za[NCB], zb[NCB];
+    float za[NCB], zb[NCB], zc[NCB], zd[NCB];
     const int nwords = nfull >> 5;                                            // whole words: pipelined
-    if (nfull > 0) fetch(0, ra, za);
+    const int plast = nfull > 0 ? nfull - 1 : 0;
+    fetch_rec(0, ra); fetch_bz(0, za); fetch_bz(min(1, plast), zb);
+    uint64_t w = T[v];
     for (int wd = 0; wd < nwords; ++wd) {
-        const uint64_t w = T[(int64_t)wd * Vpad + v];
+        const uint64_t wn = T[(int64_t)min(wd + 1, (N - 1) >> 6) * Vpad + v];
         for (int k = 0; k < 32; k += 2) {
             const int pr = wd * 32 + k;
-            fetch(pr + 1 + pipe_zero(ra[0].x), rb, zb);
+            fetch_bz(min(pr + 2, plast), zc); fetch_bz(min(pr + 3, plast), zd);
+            fetch_rec(pr + 1 + pipe_zero(ra[0].x), rb);
             pair(ra, za, (uint32_t)(w >> (2 * k)) & 3u);
-            fetch(min(pr + 2, nfull - 1) + pipe_zero(rb[0].x), ra, za);
+            fetch_rec(min(pr + 2, plast) + pipe_zero(rb[0].x), ra);
             pair(rb, zb, (uint32_t)(w >> (2 * k + 2)) & 3u);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) { za[cb] = zc[cb]; zb[cb] = zd[cb]; }
         }
+        w = wn;
     }
     for (int pr = nwords * 32; pr < nfull; ++pr) {                            // the last partial word, plainly
-        const uint64_t w = T[(int64_t)(pr >> 5) * Vpad + v];
-        fetch(pr, ra, za);
+        fetch_rec(pr, ra); fetch_bz(pr, za);
         pair(ra, za, (uint32_t)(w >> (2 * (pr & 31))) & 3u);
     }
     float h00s = h00.x + h00.y, h10s = h10.x + h10.y, gs[PC], hz0s[Q > 0 ? Q : 1], hz1s[Q > 0 ? Q : 1];
@@ -772,7 +783,7 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
         float eta = bf[0].x + (xb ? bf[1].x : 0.0f);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j].x, Wf[(int64_t)i * Q + j], eta);
-        const float mu = 1.0f / (1.0f + __expf(-eta));
+        const float mu = sigmoid_fast(eta);
         const float wf = mu * (1.0f - mu);
         float d = wf;
         if (DELTA) d = wf - P.w0f[i];
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(256) void k_glm_score(const uint64_t *__restrict__ 
         double eta = beta[0] + (xb ? beta[1] : 0.0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
-        const double mu = (double)(1.0f / (1.0f + __expf(-(float)eta)));
+        const double mu = (double)sigmoid_fast((float)eta);
         const double r = rc[Q] - mu;
         maxdev = fmax(maxdev, fabs(r));
         g[0] += r; g[1] += xb ? r : 0.0;
