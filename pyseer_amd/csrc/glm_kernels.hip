@@ -686,8 +686,11 @@ __device__ __forceinline__ float sigmoid_fast(float eta) { return __builtin_amdg
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 template <int Q, bool DELTA>
 __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
-                                          const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr)
+                                          const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
+                                          int part = 0, int nparts = 1)
 {
+    // part / nparts: this wavefront's share of the samples (k_glm_pass32_split): whole 64-sample words [wd0, wd1); the last part also takes
+    // the partial word and the odd sample
     constexpr int PC = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE;
     const int N = P.N;
     const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
@@ -751,9 +754,11 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
     float za[NCB], zb[NCB], zc[NCB], zd[NCB];
     const int nwords = nfull >> 5;                                            // whole words: pipelined
     const int plast = nfull > 0 ? nfull - 1 : 0;
-    fetch_rec(0, ra); fetch_bz(0, za); fetch_bz(min(1, plast), zb);
-    uint64_t w = T[v];
-    for (int wd = 0; wd < nwords; ++wd) {
+    const int wd0 = (int)((int64_t)nwords * part / nparts), wd1 = (int)((int64_t)nwords * (part + 1) / nparts);
+    const bool tail = part == nparts - 1;
+    fetch_rec(min(wd0 * 32, plast), ra); fetch_bz(min(wd0 * 32, plast), za); fetch_bz(min(wd0 * 32 + 1, plast), zb);
+    uint64_t w = T[(int64_t)min(wd0, (N - 1) >> 6) * Vpad + v];
+    for (int wd = wd0; wd < wd1; ++wd) {
         const uint64_t wn = T[(int64_t)min(wd + 1, (N - 1) >> 6) * Vpad + v];
         for (int k = 0; k < 32; k += 2) {
             const int pr = wd * 32 + k;
@@ -767,7 +772,8 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
         }
         w = wn;
     }
-    for (int pr = nwords * 32; pr < nfull; ++pr) {                            // the last partial word, plainly
+    for (int pr = nwords * 32; tail && pr < nfull; ++pr) {                    // the last partial word, plainly
+        if (pr == nwords * 32) w = T[(int64_t)(pr >> 5) * Vpad + v];
         fetch_rec(pr, ra); fetch_bz(pr, za);
         pair(ra, za, (uint32_t)(w >> (2 * (pr & 31))) & 3u);
     }
@@ -776,7 +782,7 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
     for (int a = 0; a < PC; ++a) gs[a] = gf[a].x + gf[a].y;
 #pragma unroll
     for (int j = 0; j < Q; ++j) { hz0s[j] = hz0[j].x + hz0[j].y; hz1s[j] = hz1[j].x + hz1[j].y; }
-    if (N & 1) {                                                              // the odd sample: k = 1 rows of A are zero
+    if ((N & 1) && tail) {                                                    // the odd sample: k = 1 rows of A are zero
         const int i = N - 1;
         const float *zrow = ZZ + (int64_t)i * STRIDE + l31;
         const bool xb = (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull;
@@ -847,6 +853,44 @@ __device__ __forceinline__ bool round_lane(const int *__restrict__ list, const i
     const bool on = idx < n;
     v = list[on ? idx : 0];
     return on;
+}
+
+// From the second pass round on the lists are short (a per cent of the batch), most of the chip idles, and a pass is as long as its 5000
+// dependent samples: those rounds run k_glm_pass32_split, where SplitCfg<Q>::S wavefronts share a variant's samples and add their partial
+// sums in a fixed order.  Which kernel a round uses depends on the round only, never on the list length: a variant's result must not
+// depend on what else is in its batch.
+template <int Q> struct SplitCfg {                                  // wavefronts per variant: as many as their LDS (transposition tile + partial sums) allows
+    static constexpr int PC = Q + 2, NV = PC * (PC + 1) / 2 + PC;
+    static constexpr int PER_WAVE = 4 * (FastCols<Q>::LDS_FLOATS + NV * 64);
+    static constexpr int S = 4 * PER_WAVE <= 150 * 1024 ? 4 : (2 * PER_WAVE <= 150 * 1024 ? 2 : 1);
+};
+template <int Q>
+__global__ __launch_bounds__(64 * SplitCfg<Q>::S) void k_glm_pass32_split(const uint64_t *__restrict__ T, int64_t Vpad, const float *__restrict__ Wf,
+                                                                           GlmParams P, const int *__restrict__ list, const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2, S = SplitCfg<Q>::S, NV = NH + PC;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    extern __shared__ float sm[];                                    // [S] transposition tiles, then partial sums [S][NV][64]
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wave-uniform, and known to be
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + lane, v);
+    double beta[PC], g[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
+    float Hf[NH];
+    // pass32_pk's __syncthreads() pairs are hit by all S wavefronts the same number of times
+    pass32_pk<Q, false>(T, Vpad, v, P, Wf, beta, Hf, g, sm + wv * FastCols<Q>::LDS_FLOATS, wv, S);
+    float *part = sm + S * FastCols<Q>::LDS_FLOATS;
+#pragma unroll
+    for (int a = 0; a < NH; ++a) part[(wv * NV + a) * 64 + lane] = Hf[a];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) part[(wv * NV + NH + a) * 64 + lane] = (float)g[a];
+    __syncthreads();
+    if (wv != 0 || !on) return;
+#pragma unroll
+    for (int a = 0; a < NH; ++a) { float t = part[a * 64 + lane]; for (int s2 = 1; s2 < S; ++s2) t += part[(s2 * NV + a) * 64 + lane]; P.ch_hf[(int64_t)a * Vpad + v] = t; }
+#pragma unroll
+    for (int a = 0; a < PC; ++a) { float t = part[(NH + a) * 64 + lane]; for (int s2 = 1; s2 < S; ++s2) t += part[(s2 * NV + NH + a) * 64 + lane]; P.ch_g[(int64_t)a * Vpad + v] = (double)t; }
 }
 
 template <int Q, bool PK>
@@ -2727,7 +2771,13 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                 r0 = 1;
             }
             for (int r = r0; r < n32; ++r) {
-                if (P.wfp) hipLaunchKernelGGL((k_glm_pass32<Q, true>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
+                if (P.wfp && r > r0) {
+                    const size_t lds = (size_t)SplitCfg<Q>::S * SplitCfg<Q>::PER_WAVE;
+                    static bool attr_set = false;                    // per instantiation (one Q per process in practice)
+                    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_glm_pass32_split<Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+                    hipLaunchKernelGGL(k_glm_pass32_split<Q>, grid, dim3(64 * SplitCfg<Q>::S), lds, st, T, Vpad, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
+                }
+                else if (P.wfp) hipLaunchKernelGGL((k_glm_pass32<Q, true>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
                 else hipLaunchKernelGGL((k_glm_pass32<Q, false>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
                 hipLaunchKernelGGL((k_glm_solve32<Q, false>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[r & 1], P.ch_cnt + r, P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1,
                                    P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
