@@ -212,6 +212,114 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
     H[sidx(1, 1)] = H[sidx(1, 0)];
 }
 
+// Scalar loads return out of order, so the only wait the compiler can place for them is "all of them" (s_waitcnt lgkmcnt(0)).  A software
+// pipeline over two wave-uniform buffers therefore needs the wait for buffer A to sit BEFORE the loads of buffer B are issued; left alone,
+// the scheduler hoists B's loads above A's first use and the wait then covers both.  pipe_zero(x) is a zero the compiler cannot see
+// through, computed from one of A's SGPRs: added to B's index, it orders B's loads behind A's arrival and keeps them scalar.
+__device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x))); return z; }
+__device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x))); return z; }
+
+// e^-x for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 (two-part ln 2), |r| <= 0.3466, Taylor to degree 13 (remainder 4e-18), 2^k by v_ldexp
+__device__ __forceinline__ double exp_neg(double x)
+{
+    const double u = -fmin(x, 800.0);
+    const double kf = rint(u * 1.4426950408889634074);
+    double r = fma(kf, -6.93147180369123816490e-01, u);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                       // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);                    // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);                    // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);                   // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
+// ---- info_pass for y in {0, 1}, leaner and with the sample's record (covariates, y) fetched one sample ahead ----------------------
+// Same sums as info_pass<Q, false, true> (information matrix, log-likelihood, max |y - mu|), all fp64.  What changes is how a sample's
+// mu and log-likelihood term are formed (see k_glm_ll): t = exp(-|eta|) by exp_neg, 1 / (1 + t) by v_rcp_f64 + two Newton steps, and
+// ll_i = -max(a_i, 0) - log(1 + t) with the logs folded into a running product (one log per wavefront at the end).  R: per sample Q
+// covariates then y (GlmParams.rec_o, the covariates as given).
+template <int Q>
+__device__ __forceinline__ void info_pass_bin(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int N, int NB64,
+                                              const double *__restrict__ R, const double (&beta)[Q + 2],
+                                              double (&H)[(Q + 2) * (Q + 3) / 2], double &ll, double &maxdev, int sb0, int sbs)
+{
+    constexpr int P = Q + 2, RS = Q + 1;
+#pragma unroll
+    for (int a = 0; a < P * (P + 1) / 2; ++a) H[a] = 0.0;
+    maxdev = 0.0;
+    double apos = 0.0, prod = 1.0;
+    int pexp = 0;
+    auto one = [&](const double (&rc)[RS], bool xb) {
+        double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
+        const double yi = rc[Q];
+        const double t = exp_neg(fabs(eta)), u = 1.0 + t;
+        double inv = __builtin_amdgcn_rcp(u);
+        inv = fma(fma(-u, inv, 1.0), inv, inv);
+        inv = fma(fma(-u, inv, 1.0), inv, inv);
+        const double mu = (eta >= 0.0) ? inv : t * inv;
+        const double wgt = t * inv * inv;                                         // mu (1 - mu) = t / (1 + t)^2, without the cancellation
+        maxdev = fmax(maxdev, fabs(yi - mu));
+        apos += fmax(fma(-2.0 * yi, eta, eta), 0.0);
+        prod *= u;
+        const double wx = xb ? wgt : 0.0;
+        H[sidx(0, 0)] += wgt;
+        H[sidx(1, 0)] += wx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const double wz = wgt * rc[j];
+            H[sidx(2 + j, 0)] += wz;
+            H[sidx(2 + j, 1)] = fma(wx, rc[j], H[sidx(2 + j, 1)]);
+#pragma unroll
+            for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = fma(wz, rc[k], H[sidx(2 + j, 2 + k)]);
+        }
+    };
+    double ra[RS], rb[RS];
+    {
+        const int i0 = min(sb0 * 64, N - 1);
+#pragma unroll
+        for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)i0 * RS + k];
+    }
+    for (int sb = sb0; sb < NB64; sb += sbs) {                                 // (sb0, sbs) = (wave, waves) of a sample-split block
+        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+        const int nb = min(64, N - sb * 64);
+        if (nb == 64) {
+            const int inext = min((sb + sbs) * 64, N - 1);                    // first sample of this wavefront's next word
+            for (int b = 0; b < 64; b += 2) {
+                const int i = sb * 64 + b, i2 = (b == 62) ? inext : i + 2;
+                const int za = pipe_zero(ra[0]);
+#pragma unroll
+                for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
+                one(ra, (w64 >> b) & 1ull);
+                const int zb = pipe_zero(rb[0]);
+#pragma unroll
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
+                one(rb, (w64 >> (b + 1)) & 1ull);
+            }
+        } else {
+            for (int b = 0; b < nb; ++b) {
+#pragma unroll
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(sb * 64 + b) * RS + k];
+                one(ra, (w64 >> b) & 1ull);
+            }
+        }
+        int e2; prod = frexp(prod, &e2); pexp += e2;
+    }
+    H[sidx(1, 1)] = H[sidx(1, 0)];
+    ll = -(apos + fma((double)pexp, 0.6931471805599453, log(prod)));
+}
+
 // =====================================================================================================================
 // Logistic Newton (binary phenotype) -- one variant per lane
 //
@@ -522,13 +630,6 @@ __device__ __forceinline__ void final_pass_mfma(const uint64_t *__restrict__ T, 
 
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
 struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *tile_list; int *tile_count; };
-
-// Scalar loads return out of order, so the only wait the compiler can place for them is "all of them" (s_waitcnt lgkmcnt(0)).  A software
-// pipeline over two wave-uniform buffers therefore needs the wait for buffer A to sit BEFORE the loads of buffer B are issued; left alone,
-// the scheduler hoists B's loads above A's first use and the wait then covers both.  pipe_zero(x) is a zero the compiler cannot see
-// through, computed from one of A's SGPRs: added to B's index, it orders B's loads behind A's arrival and keeps them scalar.
-__device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x))); return z; }
-__device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x))); return z; }
 
 // wave-aggregated append: one atomic per wavefront; callable from divergent code (the leader is one of the active lanes)
 __device__ __forceinline__ void list_push(bool p, int *__restrict__ list, int *__restrict__ count, int v)
@@ -1295,30 +1396,6 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
     glm_emit<Q>(status, bse1, llf, beta, DELTA, v, V, P, out, flags, firth_list, firth_count);
 }
 
-// e^-x for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 (two-part ln 2), |r| <= 0.3466, Taylor to degree 13 (remainder 4e-18), 2^k by v_ldexp
-__device__ __forceinline__ double exp_neg(double x)
-{
-    const double u = -fmin(x, 800.0);
-    const double kf = rint(u * 1.4426950408889634074);
-    double r = fma(kf, -6.93147180369123816490e-01, u);
-    r = fma(kf, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                       // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);                    // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);                    // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);                   // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
-}
-
 // ---- the finishing rounds: what k_glm_final<Q, true> does, as three lean kernels over the list of converged variants ------------
 //   k_glm_ll      fp64: eta, mu, the log-likelihood, the separation callback's max |y - mu| and the score        (~70 VGPRs)
 //   k_glm_dpass   fp32: X^T (W - W0) X, every entry a difference from the null model's -- the z x z block on the matrix pipe against the
@@ -1755,7 +1832,7 @@ __global__ __launch_bounds__(64) void k_firth_init(const int *__restrict__ firth
 }
 
 // penalised likelihood at cand; accept / halve / converge / fail (the state == 1 arm of k_glm_firth)
-template <int Q>
+template <int Q, bool LEAN>
 __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                       const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                       FirthWork fw, const int *__restrict__ eval_list, const int *__restrict__ eval_count,
@@ -1780,7 +1857,8 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
 #pragma unroll
     for (int a = 0; a < PC; ++a) cand[a] = fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s];
     double ll, maxdev, det;
-    info_pass<Q, false, true>(T, Vpad, v, P.N, P.NB64, y, W, cand, A, dummy, ll, maxdev, true, xw.w, xw.S);
+    if constexpr (LEAN) info_pass_bin<Q>(T, Vpad, v, P.N, P.NB64, P.rec_o, cand, A, ll, maxdev, xw.w, xw.S);
+    else info_pass<Q, false, true>(T, Vpad, v, P.N, P.NB64, y, W, cand, A, dummy, ll, maxdev, true, xw.w, xw.S);
     xw_sum(xw, A); xw_sum_max(xw, ll, maxdev);
     if (!live || xw.w != 0) return;
     const double i11c = A[sidx(1, 1)];
@@ -1869,7 +1947,7 @@ __global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__
 }
 
 // penalised score at beta through the stored factor, Newton step -> cand (the state == 0 arm of k_glm_firth)
-template <int Q>
+template <int Q, bool LEAN>
 __global__ __launch_bounds__(512) void k_firth_step(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
                                                       const double *__restrict__ W, GlmParams P, FirthWork fw,
                                                       const int *__restrict__ step_list, const int *__restrict__ step_count,
@@ -1892,32 +1970,82 @@ __global__ __launch_bounds__(512) void k_firth_step(const uint64_t *__restrict__
     for (int a = 0; a < PC * (PC + 1) / 2; ++a) A[a] = fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { U[a] = 0.0; dinv[a] = 1.0 / A[sidx(a, a)]; }
-    for (int sb = xw.w; sb < NB64; sb += xw.S) {
-        const uint64_t w64 = T[(int64_t)sb * Vpad + v];
-        const int nb = min(64, N - sb * 64);
-        for (int b = 0; b < nb; ++b) {
-            const int i = sb * 64 + b;
-            double x[PC];
-            x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
+    constexpr int RS = Q + 1;
+    // one sample: x = (1, bit, covariates).  LEAN (y in {0, 1}, GlmParams.rec_o): mu by exp_neg + v_rcp_f64 as in info_pass_bin, and the
+    // sample's record (covariates, y) fetched one sample ahead; else the plain form
+    auto one = [&](const double (&cv)[RS], bool xbit) {
+        double x[PC];
+        x[0] = 1.0; x[1] = xbit ? 1.0 : 0.0;
 #pragma unroll
-            for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
-            double eta = 0.0;
+        for (int j = 0; j < Q; ++j) x[2 + j] = cv[j];
+        double eta = 0.0;
 #pragma unroll
-            for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
-            const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
-            double zt[PC]; double qf = 0.0;
+        for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+        double mu, wgt;
+        if constexpr (LEAN) {
+            const double t = exp_neg(fabs(eta)), u = 1.0 + t;
+            double inv = __builtin_amdgcn_rcp(u);
+            inv = fma(fma(-u, inv, 1.0), inv, inv);
+            inv = fma(fma(-u, inv, 1.0), inv, inv);
+            mu = (eta >= 0.0) ? inv : t * inv; wgt = t * inv * inv;
+        } else { mu = logit_cdf(eta); wgt = mu * (1.0 - mu); }
+        double zt[PC]; double qf = 0.0;
 #pragma unroll
-            for (int a = 0; a < PC; ++a) {
-                double t = x[a];
+        for (int a = 0; a < PC; ++a) {
+            double t = x[a];
 #pragma unroll
-                for (int k = 0; k < a; ++k) t = fma(-A[sidx(a, k)], zt[k], t);
-                zt[a] = t;
-                qf = fma(t * t, dinv[a], qf);
+            for (int k = 0; k < a; ++k) t = fma(-A[sidx(a, k)], zt[k], t);
+            zt[a] = t;
+            qf = fma(t * t, dinv[a], qf);
+        }
+        const double h = wgt * qf;                                   // diagonal of the hat matrix, model.py:455-462
+        const double res = cv[Q] - mu + h * (0.5 - mu);
+#pragma unroll
+        for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
+    };
+    double ra[RS], rb[RS];
+    if constexpr (LEAN) {
+        const double *__restrict__ R = P.rec_o;
+        {
+            const int i0 = min(xw.w * 64, N - 1);
+#pragma unroll
+            for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)i0 * RS + k];
+        }
+        for (int sb = xw.w; sb < NB64; sb += xw.S) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+            if (nb == 64) {
+                const int inext = min((sb + xw.S) * 64, N - 1);
+                for (int b = 0; b < 64; b += 2) {
+                    const int i = sb * 64 + b, i2 = (b == 62) ? inext : i + 2;
+                    const int za = pipe_zero(ra[0]);
+#pragma unroll
+                    for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
+                    one(ra, (w64 >> b) & 1ull);
+                    const int zb = pipe_zero(rb[0]);
+#pragma unroll
+                    for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
+                    one(rb, (w64 >> (b + 1)) & 1ull);
+                }
+            } else {
+                for (int b = 0; b < nb; ++b) {
+#pragma unroll
+                    for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(sb * 64 + b) * RS + k];
+                    one(ra, (w64 >> b) & 1ull);
+                }
             }
-            const double h = wgt * qf;                               // diagonal of the hat matrix, model.py:455-462
-            const double res = y[i] - mu + h * (0.5 - mu);
+        }
+    } else {
+        for (int sb = xw.w; sb < NB64; sb += xw.S) {
+            const uint64_t w64 = T[(int64_t)sb * Vpad + v];
+            const int nb = min(64, N - sb * 64);
+            for (int b = 0; b < nb; ++b) {
+                const int i = sb * 64 + b;
 #pragma unroll
-            for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
+                for (int j = 0; j < Q; ++j) ra[j] = W[(int64_t)i * Q + j];
+                ra[Q] = y[i];
+                one(ra, (w64 >> b) & 1ull);
+            }
         }
     }
     xw_sum(xw, U);
@@ -2845,9 +2973,12 @@ static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint6
     const int S = glm_split_waves(P.NB64);
     const dim3 grid((unsigned)((n + 63) / 64)), blk(64), blks(64 * S);
     if (which == 0) hipLaunchKernelGGL(k_firth_init<Q>, grid, blk, 0, st, in_list, in_count, P, fw, next_eval, next_eval_count);
-    else if (which == 1) hipLaunchKernelGGL(k_firth_eval<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
+    else if (which == 1 && P.rec_o) hipLaunchKernelGGL((k_firth_eval<Q, true>), grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
                                             next_eval_count, step_list, step_count, out, flags, plist, pcount);
-    else if (which == 2) hipLaunchKernelGGL(k_firth_step<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    else if (which == 1) hipLaunchKernelGGL((k_firth_eval<Q, false>), grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
+                                            next_eval_count, step_list, step_count, out, flags, plist, pcount);
+    else if (which == 2 && P.rec_o) hipLaunchKernelGGL((k_firth_step<Q, true>), grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    else if (which == 2) hipLaunchKernelGGL((k_firth_step<Q, false>), grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
     else hipLaunchKernelGGL(k_firth_blk<Q>, dim3((unsigned)std::min<int64_t>(n, 2048)), dim3(256), 0, st, T, Vpad, V, y, W, P, fw, out, flags, plist, pcount);
     return hipGetLastError();
 }
