@@ -1832,8 +1832,11 @@ __global__ __launch_bounds__(64) void k_firth_init(const int *__restrict__ firth
 }
 
 // penalised likelihood at cand; accept / halve / converge / fail (the state == 1 arm of k_glm_firth)
+#ifndef FIRTH_EVAL_THREADS
+#define FIRTH_EVAL_THREADS 512     /* A/B: 256 = four wavefronts per block, one per SIMD, 512 registers each (36 instead of 820 bytes of scratch): 61.5 vs 60.1 ms per C4 batch, not kept */
+#endif
 template <int Q, bool LEAN>
-__global__ __launch_bounds__(512) void k_firth_eval(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+__global__ __launch_bounds__(LEAN ? FIRTH_EVAL_THREADS : 512) void k_firth_eval(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                       const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
                                                       FirthWork fw, const int *__restrict__ eval_list, const int *__restrict__ eval_count,
                                                       int *__restrict__ next_eval, int *__restrict__ next_eval_count,
@@ -2973,7 +2976,7 @@ static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint6
     const int S = glm_split_waves(P.NB64);
     const dim3 grid((unsigned)((n + 63) / 64)), blk(64), blks(64 * S);
     if (which == 0) hipLaunchKernelGGL(k_firth_init<Q>, grid, blk, 0, st, in_list, in_count, P, fw, next_eval, next_eval_count);
-    else if (which == 1 && P.rec_o) hipLaunchKernelGGL((k_firth_eval<Q, true>), grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
+    else if (which == 1 && P.rec_o) hipLaunchKernelGGL((k_firth_eval<Q, true>), grid, dim3(64 * std::min(S, FIRTH_EVAL_THREADS / 64)), glm_split_lds(std::min(S, FIRTH_EVAL_THREADS / 64)), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
                                             next_eval_count, step_list, step_count, out, flags, plist, pcount);
     else if (which == 1) hipLaunchKernelGGL((k_firth_eval<Q, false>), grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
                                             next_eval_count, step_list, step_count, out, flags, plist, pcount);
