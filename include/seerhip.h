@@ -125,7 +125,10 @@ int sh_glm_setup(sh_ctx *ctx, const double *y, const double *W, int q, int conti
 int sh_glm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
                  double *prep, double *pvalue, double *kbeta, double *bse, double *intercept,
                  double *betas, uint32_t *flags);
-/* d_out: (5+q)*V doubles SoA: prep,pvalue,kbeta,bse,intercept,betas[0..q) ; d_flags: V */
+/* d_out: (5+q)*V doubles SoA: prep,pvalue,kbeta,bse,intercept,betas[0..q) ; d_flags: V.
+ * Device memory: the context keeps per-variant workspaces sized for the largest batch seen (logistic with 1..14 covariates:
+ * (3(q+2) + 1.5 (q+2)(q+3)/2 + 6) x 8 bytes per variant, 0.9 GB for 2^20 variants at q = 10); sh_glm_batch cuts host batches into
+ * 2^18-variant chunks.  A variant's result does not depend on what else is in its batch or on the batch size. */
 int sh_glm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 
 /* ---------------------------------------------------------------------------------------------
