@@ -419,7 +419,21 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (!c || !U || !S || !y || !C) return fail(SH_EINVAL, "null argument");
     if (k < 1 || D < 1) return fail(SH_ESHAPE, "k and D must be >= 1");
     if (h2 < 0.0 || h2 >= 1.0 || std::isnan(h2)) return fail(SH_EH2, "h2 outside [0,1): reference returns no 'beta' (KeyError)");
-    if (n_limbs == 0) n_limbs = 5;
+    if (n_limbs == 0) {
+        // Automatic limb count: the smallest L in {4, 5} whose TYPICAL a-posteriori bound (an AF-0.5 variant, section 3 of DESIGN.md) is at most a
+        // quarter of lmm_tol, so that the extra-limb pass stays the exception; a variant whose own bound exceeds lmm_tol gets the extra limbs
+        // whichever L was chosen.  The base-256 digits do not depend on where the main pass stops, only how many of them it contracts does:
+        // L = 4 is 20 % less int8 work than L = 5.  SEERHIP_LMM_LIMBS=n forces a count.
+        const char *fe = std::getenv("SEERHIP_LMM_LIMBS");
+        if (fe && std::atoi(fe) > 0) n_limbs = std::atoi(fe);
+        else {
+            const int rc4 = sh_lmm_setup(c, U, S, k, y, C, D, h2, continuous, pret, lrtt, 4);
+            if (rc4 != SH_OK) return rc4;
+            const double typ = c->trace_M > 0 ? c->fin.err_norm * (0.5 * c->N) / (0.25 * c->trace_M) : 0.0;
+            if (c->E > 0 && typ <= 0.25 * c->lmm_tol) return SH_OK;
+            n_limbs = 5;
+        }
+    }
     if (n_limbs < 3 || n_limbs > 7) return fail(SH_EINVAL, "n_limbs must be 3..7");
     if (c->N > 262143) return fail(SH_EINVAL, "more than 262143 samples: the int32 partial sums of k_lmm_quadform_i8 could overflow");
     HIPCHK(hipSetDevice(c->device));

@@ -216,8 +216,9 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
 // pipeline over two wave-uniform buffers therefore needs the wait for buffer A to sit BEFORE the loads of buffer B are issued; left alone,
 // the scheduler hoists B's loads above A's first use and the wait then covers both.  pipe_zero(x) is a zero the compiler cannot see
 // through, computed from one of A's SGPRs: added to B's index, it orders B's loads behind A's arrival and keeps them scalar.
-__device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x))); return z; }
-__device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x))); return z; }
+// (s_and_b32 writes SCC: declared, or a compare scheduled across the asm loses its result)
+__device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x)) : "scc"); return z; }
+__device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x)) : "scc"); return z; }
 
 // e^-x for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 (two-part ln 2), |r| <= 0.3466, Taylor to degree 13 (remainder 4e-18), 2^k by v_ldexp
 __device__ __forceinline__ double exp_neg(double x)
@@ -2149,7 +2150,12 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
             double A[NH], det;
             for (int a = 0; a < NH; ++a) A[a] = acc[a];
             if (!ldl_factor<PC>(A, SING_TOL, &det)) { pinv_list[atomicAdd(pinv_count, 1)] = (int)v; s_ctl = 2; }
-            else { for (int a = 0; a < NH; ++a) s_fac[a] = A[a]; for (int a = 0; a < PC; ++a) s_dinv[a] = 1.0 / A[sidx(a, a)]; s_ctl = 1; }
+            else {
+                for (int a = 0; a < NH; ++a) s_fac[a] = A[a]; for (int a = 0; a < PC; ++a) s_dinv[a] = 1.0 / A[sidx(a, a)]; s_ctl = 1;
+                // F(beta) as THIS kernel evaluates it: the step-halving test compares F values to 4 ulp, and the rounds' F (info_pass_bin: logs
+                // folded into a product; another summation order) differs from this kernel's by more than that
+                Fcur = -(acc[NH] + 0.5 * log(det));
+            }
         }
         __syncthreads();
         while (s_ctl != 2) {
@@ -2976,11 +2982,11 @@ static hipError_t launch_firth(hipStream_t st, int which, int64_t n, const uint6
     const int S = glm_split_waves(P.NB64);
     const dim3 grid((unsigned)((n + 63) / 64)), blk(64), blks(64 * S);
     if (which == 0) hipLaunchKernelGGL(k_firth_init<Q>, grid, blk, 0, st, in_list, in_count, P, fw, next_eval, next_eval_count);
-    else if (which == 1 && P.rec_o) hipLaunchKernelGGL((k_firth_eval<Q, true>), grid, dim3(64 * std::min(S, FIRTH_EVAL_THREADS / 64)), glm_split_lds(std::min(S, FIRTH_EVAL_THREADS / 64)), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
+    else if (which == 1 && P.rec_o && (P.firth_lean & 1)) hipLaunchKernelGGL((k_firth_eval<Q, true>), grid, dim3(64 * std::min(S, FIRTH_EVAL_THREADS / 64)), glm_split_lds(std::min(S, FIRTH_EVAL_THREADS / 64)), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
                                             next_eval_count, step_list, step_count, out, flags, plist, pcount);
     else if (which == 1) hipLaunchKernelGGL((k_firth_eval<Q, false>), grid, blks, glm_split_lds(S), st, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval,
                                             next_eval_count, step_list, step_count, out, flags, plist, pcount);
-    else if (which == 2 && P.rec_o) hipLaunchKernelGGL((k_firth_step<Q, true>), grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
+    else if (which == 2 && P.rec_o && (P.firth_lean & 2)) hipLaunchKernelGGL((k_firth_step<Q, true>), grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
     else if (which == 2) hipLaunchKernelGGL((k_firth_step<Q, false>), grid, blks, glm_split_lds(S), st, T, Vpad, y, W, P, fw, in_list, in_count, next_eval, next_eval_count);
     else hipLaunchKernelGGL(k_firth_blk<Q>, dim3((unsigned)std::min<int64_t>(n, 2048)), dim3(256), 0, st, T, Vpad, V, y, W, P, fw, out, flags, plist, pcount);
     return hipGetLastError();

@@ -50,6 +50,7 @@ struct GlmParams {
     const float *wfp, *yf, *w0f;  // packed-fp32 passes (pass32_pk): wfp = per pair of samples a record of Q + 2 float2 (standardised covariates, y, w0;
                                   // each (even sample, odd sample)); yf, w0f = y and w0 as float arrays (the odd last sample); null = unpacked passes
     const double *rec;            // per sample a record of Q + 1 doubles (standardised covariates, then y): k_glm_score / k_glm_ll
+    int firth_lean;               // bit 0: k_firth_eval<Q, true>, bit 1: k_firth_step<Q, true> (both when rec_o is set; SEERHIP_FIRTH_LEAN=1/2 selects one for A/B)
     const double *rec_o;          // the same with the covariates as given, y in {0, 1} only: the Firth rounds (info_pass_bin); null = info_pass
     double null_h[16], null_g[16];
 };
