@@ -7,7 +7,8 @@
 # tools/summarize_r02.py then collapses them into profiles/r02/.  C3's PMC passes use tools/gpu_probe_lmm.py: torch.linalg.eigh
 # (rocSOLVER) segfaults under counter collection, and the probe has the same kernels at N = 5000 without an eigensolver.
 # NOTE: gpurun MERGES the box's gpurun_out/ into the local one: clear the local gpurun_out/r02 before a new run, or summarise on the box only
-# (the script does: $O/summary), otherwise tools/summarize_r02.py adds up the counter files of two runs.  PMC=0 skips the counter passes.
+# (the script does: $O/summary)
+# C3's counter passes run the probe at L = 4 limbs, what the automatic choice gives on the bench's kinship (LMM_L overrides)., otherwise tools/summarize_r02.py adds up the counter files of two runs.  PMC=0 skips the counter passes.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CFGS=${CFGS:-"C3 C2 C2N5000 C4"}
@@ -18,7 +19,7 @@ done
 pmc() {  # cfg group counters...
   local c=$1 g=$2; shift 2
   if [ "$c" = "C3" ]; then
-    V=262144 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_${c}_$g -- python $R/tools/gpu_probe_lmm.py > $O/pmc_${c}_$g.log 2>&1
+    L=${LMM_L:-4} V=262144 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_${c}_$g -- python $R/tools/gpu_probe_lmm.py > $O/pmc_${c}_$g.log 2>&1
   else
     rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_${c}_$g -- python $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --no-parity > $O/pmc_${c}_$g.log 2>&1
   fi
