@@ -1325,6 +1325,127 @@ __device__ __forceinline__ void glm_emit(int status, double bse1, double llf, do
     if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
 }
 
+// ---- the fp64 restart, one WORKGROUP per listed variant (the default; k_glm_slow above is kept behind SEERHIP_SLOW=wave) ----------------
+// The restart list is short in every ordinary batch (nothing on the benchmark rows, a handful of separated or ill-conditioned k-mers in real
+// data), and with a lane per variant each of its ~8 iterations is a walk over N / S samples by one wavefront, then k_glm_final's walk over all
+// N: 1.5-4 ms for a single listed variant, whatever the batch.  Here 256 threads share a variant's samples (thread t: t, t + 256, ...),
+// sums by xor-shuffle then waves 0..3 (blk_sum), the p x p algebra on thread 0: the same iteration and decisions as k_glm_slow followed by
+// k_glm_final<Q, false> -- statsmodels' Newton from the reference's start vector (ridge 1e-10, |step|_inf <= 1e-8, 35 iterations, the
+// perfect-prediction callback), then llf, bse[1] and the notes at the final beta.  ~25 us per iteration.  Every listed variant goes through
+// this kernel whatever the list's length, so its result does not depend on what else is in the batch.
+template <int NA> __device__ __forceinline__ void blk_sum(double (&a)[NA], double *red, int tid);      // defined with the Firth workgroup kernels below
+template <int Q>
+__global__ __launch_bounds__(256) void k_glm_slow_blk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+                                                     const double *__restrict__ y, const double *__restrict__ W, GlmParams P, GlmWork wk,
+                                                     double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                     int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2, NA = NH + PC + 1;      // packed information, score, log-likelihood
+    __shared__ double s_beta[PC], s_red[4 * NA], s_mx[4];
+    __shared__ int s_ctl;                                            // 0 = another Newton pass, 1 = evaluation pass at the final beta, 2 = variant done
+    const int cnt = *wk.slow_count, tid = threadIdx.x, N = P.N;
+    const double nobs = (double)N;
+    for (int idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const int64_t v = wk.slow_list[idx];
+        int it = 0, status = 0, reps = 0;                            // thread-0 state
+        double llf = NAN, bse1 = NAN;
+        __syncthreads();
+        if (tid == 0) { for (int a = 0; a < PC; ++a) s_beta[a] = 0.0; s_beta[0] = P.ymean_logit; s_ctl = 0; }
+        __syncthreads();
+        while (s_ctl != 2) {
+            const bool want_ll = s_ctl == 1;
+            double acc[NA], beta[PC], mx = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[a] = 0.0;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) beta[a] = s_beta[a];
+            for (int i = tid; i < N; i += 256) {
+                const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
+                double x[PC];
+                x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
+#pragma unroll
+                for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
+                double eta = 0.0;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
+                const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
+                const double yi = y[i], r = yi - mu;
+                mx = fmax(mx, fabs(r));
+                if (want_ll) {
+                    const double lm = log(mu);                                                   // as info_pass
+                    acc[NH + PC] += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                }
+#pragma unroll
+                for (int a = 0; a < PC; ++a) {
+                    const double wa = wgt * x[a];
+                    acc[NH + a] = fma(r, x[a], acc[NH + a]);
+#pragma unroll
+                    for (int c = 0; c <= a; ++c) acc[sidx(a, c)] = fma(wa, x[c], acc[sidx(a, c)]);
+                }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m));
+            blk_sum<NA>(acc, s_red, tid);                            // (its barriers also order the s_mx accesses below)
+            if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
+            __syncthreads();
+            if (tid == 0) {
+                const double maxdev = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
+                double H[NH], g[PC], det;
+#pragma unroll
+                for (int a = 0; a < NH; ++a) H[a] = acc[a] / nobs;
+#pragma unroll
+                for (int a = 0; a < PC; ++a) g[a] = acc[NH + a] / nobs;
+                if (!want_ll) {                                      // a Newton step (k_glm_slow)
+                    if (it > 0 && maxdev <= 1e-8) { status = 1; s_ctl = 2; }                    // _check_perfect_pred
+                    else {
+#pragma unroll
+                        for (int a = 0; a < PC; ++a) H[sidx(a, a)] -= 1e-10;                    // optimizer.py:415-423
+                        if (!ldl_factor<PC>(H, 0.0, &det)) { status = 2; s_ctl = 2; }
+                        else {
+                            ldl_solve<PC>(H, g);
+                            bool moving = false;
+#pragma unroll
+                            for (int a = 0; a < PC; ++a) { s_beta[a] = beta[a] + g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
+                            ++it;
+                            if (!moving || it >= 35) s_ctl = 1;
+                        }
+                    }
+                } else {                                             // evaluation at the final beta (k_glm_final<Q, false>)
+                    if (maxdev <= 1e-8) { status = 1; s_ctl = 2; }                              // callback after the last update
+                    else {
+                        llf = acc[NH + PC];
+                        if (!ldl_factor<PC>(H, 4.0e-16, &det)) { status = 2; s_ctl = 2; }
+                        else {
+                            double e[PC];
+#pragma unroll
+                            for (int a = 0; a < PC; ++a) e[a] = (a == 1) ? 1.0 : 0.0;
+                            ldl_solve<PC>(H, e);
+                            bse1 = sqrt(e[1] / nobs);                // Hinv = inv(-Hessian/nobs)/nobs, no ridge (SM:base/model.py:533-534)
+                            ldl_solve<PC>(H, g);
+                            double smax = 0.0; bool finite = true;
+#pragma unroll
+                            for (int a = 0; a < PC; ++a) { smax = fmax(smax, fabs(g[a])); finite = finite && isfinite(g[a]); }
+                            s_ctl = 2;
+                            if (finite) {
+#pragma unroll
+                                for (int a = 0; a < PC; ++a) s_beta[a] = beta[a] + g[a];
+                                if (smax > 5e-7 && ++reps < 6) s_ctl = 1;                      // llf and bse belong to a beta this far from the fixed point: again
+                            }
+                        }
+                    }
+                }
+                if (s_ctl == 2) {
+                    double b[PC];
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) b[a] = s_beta[a];
+                    glm_emit<Q>(status, bse1, llf, b, false, v, V, P, out, flags, firth_list, firth_count);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- kernel 3: phase C, fp64 evaluation at the final beta + the decisions of model.py:332-344, 384 --------------------------
 template <int Q, bool DELTA>
 __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
@@ -1619,12 +1740,8 @@ __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmP
 #pragma unroll
             for (int a = 0; a < NH; ++a) H[a] = (H[a] + (double)P.ch_hf[(int64_t)a * Vpad + v]) / nobs;
             double det;
-            if (!ldl_factor<PC>(H, 1.0e-5, &det)) {                  // (nearly) singular: the plain fp64 pass decides (k_glm_final<Q, false>, state 2)
-                emit = false; wk.state[v] = 2;
-#pragma unroll
-                for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }
-#pragma unroll
-                for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
+            if (!ldl_factor<PC>(H, 1.0e-5, &det)) {                  // (nearly) singular: the all-fp64 restart decides (an exactly singular design must be SEEN as such)
+                emit = false; go_slow = true;
             } else {
                 double e[PC];
 #pragma unroll
@@ -2933,8 +3050,11 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
         } else hipLaunchKernelGGL((k_glm_fast<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
     }
     else if (which == 4) {
-        const int S = std::min(4, glm_split_waves(P.NB64));      // 400+ VGPRs per lane: at most four wavefronts per block
-        hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
+        static const bool wave_form = [] { const char *e = getenv("SEERHIP_SLOW"); return e && std::string(e) == "wave"; }();
+        if (wave_form) {
+            const int S = std::min(4, glm_split_waves(P.NB64));  // 400+ VGPRs per lane: at most four wavefronts per block
+            hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
+        } else hipLaunchKernelGGL(k_glm_slow_blk<Q>, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     }
     else if (which == 5) {
         if (Q > 0 && P.a0 && P.w0 && P.zz && P.ws) {
