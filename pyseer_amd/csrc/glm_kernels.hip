@@ -1914,7 +1914,7 @@ struct FirthWork {
 // A variant still iterating after `firth_handoff` accepted steps leaves the rounds and is finished by one workgroup (k_firth_blk).
 // The rule looks at the variant alone, so which kernel finishes a variant -- and hence the order of its sums -- does not depend
 // on what else is in the batch.  Ordinary variants converge in 5-14 steps; (quasi-)separated ones need hundreds.
-// (GlmParams.firth_handoff: 16, or 0 for the routed variants of an ordinary run at N >= 2048, see sh_glm_setup)
+// (GlmParams.firth_handoff: 16, or 0 for the routed variants of an ordinary run at N >= 768, see sh_glm_setup)
 template <int PC> __host__ __device__ constexpr int fw_beta() { return 0; }
 template <int PC> __host__ __device__ constexpr int fw_cand() { return PC; }
 template <int PC> __host__ __device__ constexpr int fw_fac() { return 2 * PC; }
