@@ -518,3 +518,53 @@ def test_prefilter_compaction_changes_nothing(dedup, monkeypatch):
     for f in got:
         close(got[f][~firth], want[f][~firth], rtol=1e-6, atol=1e-12, what=f)
         close(got[f][firth], want[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, what=f + "(firth)")
+
+
+@pytest.mark.parametrize("N,q", [(1000, 10), (333, 3)])
+def test_logistic_fit_paths_agree(N, q, monkeypatch):
+    """The logistic fit has one product path (rounds of lean kernels: carrier-sum first step, packed fp32 Newton rounds, chord rounds,
+    finishing kernels, workgroup restarts) and switches that route variants through its alternatives.  Every route must land on the
+    same fixed point: the default against the oracle, the alternatives against the default to 2e-8 (the exact fp64 Newton step each
+    takes last is certified <= 5e-7, i.e. quadratically below that); bse to 5e-7 (the correction-form information matrix carries the
+    single-precision rounding of w - w0, ~1e-7 at these sample counts)."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(77 + N)
+    V = 900
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.4 + 1.2 * W[:, 0] - 0.7 * W[:, 1]
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    af = np.concatenate([rng.uniform(0.03, 0.97, V - V // 6), rng.uniform(0.004, 0.03, V // 6)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K[: V // 10] = (rng.random((V // 10, N)) < (0.15 + 0.6 * y)[None, :] * rng.uniform(0.3, 1.0, V // 10)[:, None]).astype(np.uint8)   # real effects
+    K = K[(K.mean(axis=1) >= 0.01) & (K.mean(axis=1) <= 0.99)]
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W, False, 1.0, 1.0, nl, nf)
+    bits = pack_variants(K)
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(N); e.glm_setup(y, W, False, nl, nf); r = e.glm_batch(bits); e.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return r
+    base = run()
+    firth = (want["notes"] & 0x7C) != 0
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
+        close(base[f][~firth], want[f][~firth], what=f)
+    assert ((base["flags"] & 0x1FF) == want["notes"]).all()
+    routes = [dict(SEERHIP_CHORD="0"),                               # the three-kernel form
+              dict(SEERHIP_CHORD_ENTER="5e-2"),                      # early hand-over: several chord rounds per variant
+              dict(SEERHIP_CHORD_N32="2"),                           # stragglers of the Newton rounds restarted in fp64 (workgroup kernel)
+              dict(SEERHIP_CHORD_N32="2", SEERHIP_SLOW="wave"),      # ... by the lane-per-variant kernels
+              dict(SEERHIP_BITDOT="0"),                              # first step by a pass, k_glm_final instead of the finishing kernels
+              dict(SEERHIP_FIN_ROUNDS="0"), dict(SEERHIP_PK="0"), dict(SEERHIP_WARM="0"), dict(SEERHIP_NEWTON="1")]
+    for env in routes:
+        r = run(**env)
+        assert (r["flags"] == base["flags"]).all(), env
+        for f in ("pvalue", "kbeta", "bse", "intercept"):
+            close(r[f][~firth], base[f][~firth], rtol=5e-7 if f == "bse" else 2e-8, atol=1e-12, what="%s under %s" % (f, env))
+        close(r["betas"][~firth], base["betas"][~firth], rtol=2e-8, atol=1e-10, what="betas under %s" % env)
