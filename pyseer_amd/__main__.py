@@ -22,7 +22,8 @@ import pandas as pd
 from . import __version__
 from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
 from .input import (load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
-                    iter_packed_blocks, iter_packed_blocks_native, iter_packed_blocks_cached, PackedCacheWriter)
+                    iter_packed_blocks, iter_packed_blocks_native, iter_packed_blocks_native_multi, iter_packed_blocks_cached,
+                    PackedCacheWriter)
 from .lmm import initialise_lmm, mask_like_fit_lmm
 from .model import fit_null, covariate_block
 from .utils import format_output
@@ -36,7 +37,8 @@ def get_options(argv=None):
     ph.add_argument('--phenotype-column', default=None, help='Phenotype file column to use [Default: last column]')
     va = parser.add_argument_group('Variants')
     vg = va.add_mutually_exclusive_group(required=True)
-    vg.add_argument('--kmers', default=None, help='Kmers file')
+    vg.add_argument('--kmers', default=None, nargs='+',
+                    help='Kmers file; several files are tested as one stream in the order given and read concurrently (one gzip stream inflates serially)')
     vg.add_argument('--vcf', default=None, help='VCF file (not supported by this build)')
     vg.add_argument('--pres', default=None, help='Presence/absence .Rtab matrix as produced by roary and piggy')
     va.add_argument('--burden', help='(not supported by this build)')
@@ -244,13 +246,17 @@ def main(argv=None):
         lineage_dict = None
 
     all_strains = set(p.index)
-    var_type, var_file = ("kmers", options.kmers) if options.kmers else ("Rtab", options.pres)
+    kmer_files = list(options.kmers) if options.kmers else []
+    if len(kmer_files) > 1 and (options.python_reader or options.load_packed or options.save_packed or options.packed_cache):
+        _die('Several --kmers files need the native reader and cannot be combined with a packed cache\n')
+    var_type, var_file = ("kmers", kmer_files[0]) if kmer_files else ("Rtab", options.pres)
     native = (var_type == "kmers") and not options.python_reader
     if native and not options.uncompressed and not options.load_packed:
-        with open(var_file, "rb") as fh:                   # the reference's gzip.open raises on plain text (input.py:271-276)
-            if fh.read(2) != b"\x1f\x8b":
-                sys.stderr.write("Not a gzipped file (%s): use --uncompressed for plain-text k-mers\n" % var_file)
-                sys.exit(1)
+        for vf in (kmer_files or [var_file]):
+            with open(vf, "rb") as fh:                     # the reference's gzip.open raises on plain text (input.py:271-276)
+                if fh.read(2) != b"\x1f\x8b":
+                    sys.stderr.write("Not a gzipped file (%s): use --uncompressed for plain-text k-mers\n" % vf)
+                    sys.exit(1)
     if not native:
         infile, sample_order = open_variant_file(var_type, var_file, None, None, options.uncompressed)
     patterns = open(options.output_patterns, 'wb') if options.output_patterns else None
@@ -322,6 +328,9 @@ def main(argv=None):
     if options.load_packed:
         blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
+    elif native and len(kmer_files) > 1:
+        blocks = iter_packed_blocks_native_multi(p, kmer_files, options.min_af, options.max_af, options.block_size,
+                                                 want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
     elif native:
         if options.save_packed:
             cache_out = PackedCacheWriter(options.save_packed, [str(x) for x in p.index])

@@ -237,3 +237,40 @@ def test_lines_longer_than_the_pad_and_blocks_spanning_many_slabs(tmp_path, monk
     monkeypatch.setenv("SEERHIP_READER_SLAB", str(1 << 24)); monkeypatch.setenv("SEERHIP_READER_PAD", str(1 << 20))
     big = [(n, b.copy()) for n, b, c in NativeKmerReader(str(tmp_path / "u.gz"), samples2, 7)]
     assert sum((g[0] for g in big), []) == ref[0] and np.array_equal(np.concatenate([g[1] for g in big]), ref[1])
+
+
+def test_several_files_are_one_stream_in_the_order_given(tmp_path):
+    """`--kmers a.gz b.txt.gz c.gz`: every file has its own reader thread (one gzip stream inflates serially), the consumer drains them
+    in the order given.  Same variants, same order, same rows as the concatenated file; a small read-ahead budget makes the readers of
+    the later files wait without changing anything; an unreadable file is reported when its turn comes."""
+    import pytest
+    from pyseer_amd.input import iter_packed_blocks_native_multi
+    samples = ["s%03d" % i for i in range(150)]
+    p = pd.Series(np.arange(len(samples), dtype=float), index=samples)
+    texts = [_kmer_text(samples, n, seed) if n else b"" for n, seed in ((700, 1), (3, 2), (1500, 3), (0, 4), (260, 5))]
+    paths = []
+    for i, t in enumerate(texts):
+        path = str(tmp_path / ("part%d.gz" % i))
+        with open(path, "wb") as fh:
+            fh.write(_bgzf(t) if i == 2 else gzip.compress(t))
+        paths.append(path)
+    whole = str(tmp_path / "whole.gz")
+    with open(whole, "wb") as fh:
+        fh.write(gzip.compress(b"".join(texts)))
+
+    def flat(blocks):
+        names, rows, st = [], [], []
+        for b in blocks:
+            names += list(b.names); st += list(b.status)
+            full = np.zeros((len(b.names), b.bits.shape[1]), dtype=np.uint8)
+            on = [i for i, s in enumerate(b.status) if s == 0]
+            full[on] = b.bits[[b.row_of[i] for i in on]]
+            rows.append(full)
+        return names, st, (np.concatenate(rows) if rows else np.zeros((0, 0), dtype=np.uint8))
+    want = flat(iter_packed_blocks_native(p, whole, 0.01, 0.99, 64))
+    assert len(want[0]) == 700 + 3 + 1500 + 260
+    for budget in (2 << 30, 1):                              # 1 byte: at most one block of a later file is parsed ahead
+        got = flat(iter_packed_blocks_native_multi(p, paths, 0.01, 0.99, 64, ahead_bytes=budget))
+        assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
+    with pytest.raises(IOError):
+        list(iter_packed_blocks_native_multi(p, [paths[0], str(tmp_path / "missing.gz"), paths[4]], 0.01, 0.99, 64))

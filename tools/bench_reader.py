@@ -48,4 +48,31 @@ for tag, path, env in (("plain", "k.txt", None), ("gzip_zlib", "k.gz", "zlib"), 
         if want is None: want = cs
         assert cs == want, (tag, cs, want)
     res[tag + "_kmers_per_s"] = best; res[tag + "_text_MBps"] = best * len(text) / V / 1e6
+# the same gzip text cut into NF files at line boundaries and read as one stream (--kmers a.gz b.gz ...): one reader thread per file
+import pandas as pd
+from pyseer_amd.input import iter_packed_blocks_native_multi
+NF = int(os.environ.get("FILES", 4))
+lines = text.splitlines(True)
+paths = []
+for i in range(NF):
+    path = d + "/part%d.gz" % i
+    open(path, "wb").write(gzip.compress(b"".join(lines[i * len(lines) // NF:(i + 1) * len(lines) // NF]), 6))
+    paths.append(path)
+ph = pd.Series(np.zeros(N), index=names)
+best = 0.0
+for rep in range(2):
+    t0 = time.time(); tot = 0
+    for blk in iter_packed_blocks_native_multi(ph, paths, 0.0, 1.0, BS):
+        tot += len(blk.names)
+    best = max(best, tot / (time.time() - t0))
+    assert tot == V
+res["gzip_fast_%d_files_kmers_per_s" % NF] = best
+from pyseer_amd.input import iter_packed_blocks_native
+best = 0.0
+for rep in range(2):                                        # the single file through the same block construction (AF filter, names), for comparison
+    t0 = time.time(); tot = 0
+    for blk in iter_packed_blocks_native(ph, d + "/k.gz", 0.0, 1.0, BS):
+        tot += len(blk.names)
+    best = max(best, tot / (time.time() - t0))
+res["gzip_fast_1_file_blocks_kmers_per_s"] = best
 print(json.dumps(res))
