@@ -1141,6 +1141,85 @@ __global__ __launch_bounds__(256) void k_glm_score(const uint64_t *__restrict__ 
     P.ch_md[v] = maxdev;
 }
 
+// k_glm_score for the chord rounds after the first: their lists are short (nothing on the benchmark rows), and a pass by one wavefront is as
+// long as its 5000 dependent samples (1.8 ms).  SCORE_SPLIT wavefronts share a variant's samples -- contiguous runs of 64-sample words, the
+// last one also the partial word -- and wavefront 0 adds the partial scores in a fixed order.  As with k_glm_pass32_split the kernel is
+// chosen by the round, never by the list length.
+#define SCORE_SPLIT 8
+template <int Q>
+__global__ __launch_bounds__(64 * SCORE_SPLIT) void k_glm_score_split(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P,
+                                                                      const int *__restrict__ list, const int *__restrict__ cnt)
+{
+    constexpr int PC = Q + 2, RS = Q + 1, S = SCORE_SPLIT;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    __shared__ double part[S - 1][PC + 1][64];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + lane, v);
+    const int N = P.N, NB64 = P.NB64;
+    const double *__restrict__ R = P.rec;
+    double beta[PC], g[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
+    double maxdev = 0.0;
+    auto one = [&](const double (&rc)[RS], bool xb) {
+        double eta = beta[0] + (xb ? beta[1] : 0.0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
+        const double mu = (double)sigmoid_fast((float)eta);
+        const double r = rc[Q] - mu;
+        maxdev = fmax(maxdev, fabs(r));
+        g[0] += r; g[1] += xb ? r : 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, rc[j], g[2 + j]);
+    };
+    const int wd0 = (int)((int64_t)NB64 * wv / S), wd1 = (int)((int64_t)NB64 * (wv + 1) / S);
+    double ra[RS], rb[RS];
+    {
+        const int i0 = min(wd0 * 64, N - 1);
+#pragma unroll
+        for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)i0 * RS + k];
+    }
+    for (int wd = wd0; wd < wd1; ++wd) {
+        const uint64_t w = T[(int64_t)wd * Vpad + v];
+        const int lim = min(64, N - wd * 64);
+        if (lim == 64) {
+            for (int b = 0; b < 64; b += 2) {
+                const int i = wd * 64 + b, i2 = min(i + 2, N - 1);
+                const int za = pipe_zero(ra[0]);
+#pragma unroll
+                for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
+                one(ra, (w >> b) & 1ull);
+                const int zb = pipe_zero(rb[0]);
+#pragma unroll
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
+                one(rb, (w >> (b + 1)) & 1ull);
+            }
+        } else {
+            for (int b = 0; b < lim; ++b) {
+#pragma unroll
+                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(wd * 64 + b) * RS + k];
+                one(ra, (w >> b) & 1ull);
+            }
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int a = 0; a < PC; ++a) part[wv - 1][a][lane] = g[a];
+        part[wv - 1][PC][lane] = maxdev;
+    }
+    __syncthreads();
+    if (wv != 0 || !on) return;
+    for (int s2 = 0; s2 < S - 1; ++s2) {
+#pragma unroll
+        for (int a = 0; a < PC; ++a) g[a] += part[s2][a][lane];
+        maxdev = fmax(maxdev, part[s2][PC][lane]);
+    }
+#pragma unroll
+    for (int a = 0; a < PC; ++a) P.ch_g[(int64_t)a * Vpad + v] = g[a];
+    P.ch_md[v] = maxdev;
+}
+
 template <int Q>
 __global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
                                                   int *__restrict__ next, int *__restrict__ next_cnt, int last_round)
@@ -3037,7 +3116,8 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                                    P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
             }
             for (int r = 0; r < nc; ++r) {
-                hipLaunchKernelGGL(k_glm_score<Q>, g256, b256, 0, st, T, Vpad, y, W, P, P.ch_list[2 + (r & 1)], cc + r);
+                if (r == 0) hipLaunchKernelGGL(k_glm_score<Q>, g256, b256, 0, st, T, Vpad, y, W, P, P.ch_list[2 + (r & 1)], cc + r);
+                else hipLaunchKernelGGL(k_glm_score_split<Q>, grid, dim3(64 * SCORE_SPLIT), 0, st, T, Vpad, P, P.ch_list[2 + (r & 1)], cc + r);
                 hipLaunchKernelGGL(k_glm_chord<Q>, grid, blk, 0, st, Vpad, P, wk, P.ch_list[2 + (r & 1)], cc + r, P.ch_list[2 + ((r + 1) & 1)], cc + r + 1,
                                    r == nc - 1 ? 1 : 0);
             }
