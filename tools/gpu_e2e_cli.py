@@ -20,13 +20,24 @@ with open(d + "/pheno.tsv", "w") as f:
     f.write("samples\tbinary\n")
     for i in range(N):
         f.write("%s\t%d\n" % (names[i], y[i]))
+NF = int(os.environ.get("FILES", 4))                        # the same lines also as NF files, for `--kmers part0.gz part1.gz ...`
+tok = np.array([n + ":1" for n in names], dtype=object)
+parts = [gzip.open(d + "/part%d.gz" % i, "wt", compresslevel=4) for i in range(NF)]
 with gzip.open(d + "/kmers.gz", "wt", compresslevel=4) as f:
     for v in range(V):
         af = rng.uniform(0.02, 0.98)
         idx = np.nonzero(rng.random(N) < af)[0]
-        f.write("".join(rng.choice(list("ACGT"), 31)) + " | " + " ".join(names[i] + ":1" for i in idx) + "\n")
+        line = "".join(rng.choice(list("ACGT"), 31)) + " | " + " ".join(tok[idx]) + "\n"
+        f.write(line); parts[v * NF // V].write(line)
+for fh in parts:
+    fh.close()
 print("inputs written in %.1f s (%.1f MB gz)" % (time.time() - t0, os.path.getsize(d + "/kmers.gz") / 1e6))
 env = dict(os.environ); env["PYTHONPATH"] = ROOT
+t0 = time.time()
+r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers"] + [d + "/part%d.gz" % i for i in range(NF)] + ["--phenotypes", d + "/pheno.tsv", "--lmm",
+                    "--similarity", d + "/sim.tsv", "--block_size", "65536"], env=env, stdout=open(d + "/out_parts.tsv", "w"), stderr=subprocess.PIPE)
+dt = time.time() - t0
+print("CLI %d files, block 65536: rc %d %.1f s total -> %.0f k-mers/s end to end" % (NF, r.returncode, dt, V / dt))
 for extra in ([], ["--block_size", "65536", "--save-packed", d + "/kmers.pk"], ["--block_size", "65536", "--load-packed", d + "/kmers.pk"],
               ["--save-lmm", d + "/lmm.npz", "--block_size", "65536", "--load-packed", d + "/kmers.pk"]):
     t0 = time.time()
@@ -35,6 +46,9 @@ for extra in ([], ["--block_size", "65536", "--save-packed", d + "/kmers.pk"], [
     dt = time.time() - t0
     print("CLI", extra, "rc", r.returncode, "%.1f s total -> %.0f k-mers/s end to end" % (dt, V / dt))
     print("   ", r.stderr.decode().strip().splitlines()[-4:])
+    if extra == ["--block_size", "65536", "--save-packed", d + "/kmers.pk"]:
+        same = open(d + "/out.tsv").read() == open(d + "/out_parts.tsv").read()
+        print("    output of the %d-file run identical to the one-file run at the same block size: %s" % (NF, same))
 
 # ---- steady state from a packed cache: BIGV synthetic variants written straight into the cache format (no text involved)
 BIGV = int(os.environ.get("BIGV", 0))
