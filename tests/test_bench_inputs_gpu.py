@@ -211,3 +211,24 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["parity_checked"] == 64 and max(d["parity_max_rel_dev"].values()) < 1e-9
     assert abs(d["value"] - 2 * 65536 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                                  # N = 1 only
+
+
+def test_automatic_limb_count_follows_the_tolerance(c3, monkeypatch):
+    """sh_lmm_setup(n_limbs = 0) takes the smallest L in {4, 5} whose typical a-posteriori bound is at most a quarter of the tolerance:
+    4 on the benchmark's kinship at the default 1e-8, 5 when the tolerance is tightened 100x or the extra-limb pass is off; an
+    explicit count and SEERHIP_LMM_LIMBS override it.  Whatever was chosen, the reported typical bound respects the rule."""
+    from pyseer_amd.engine import Engine
+
+    def limbs(n_limbs=0, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = Engine(c3["N"]); e.lmm_setup(c3["U"], c3["S"], c3["y"], c3["C"], c3["h2"], n_limbs=n_limbs); info = e.lmm_info(); e.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return info
+    a = limbs()
+    assert a["n_limbs"] == 4 and a["bound_rel_typical"] <= 0.25e-8, a
+    b = limbs(SEERHIP_LMM_TOL="1e-10")
+    assert b["n_limbs"] == 5 and b["bound_rel_typical"] <= 0.25e-10 * 1.0001, b
+    assert limbs(SEERHIP_LMM_TOL="0")["n_limbs"] == 5            # no extra-limb pass: nothing would catch a variant over the bound
+    assert limbs(n_limbs=6)["n_limbs"] == 6 and limbs(SEERHIP_LMM_LIMBS="5")["n_limbs"] == 5
