@@ -84,7 +84,9 @@ int     sh_set_af_filter(sh_ctx *ctx, double min_af, double max_af);
  * U: n x k row-major (lmm.U; arr_0 of the --save-lmm cache), S: k (lmm.S), y: n (lmm.Y),
  * C: n x D row-major covariates with the intercept LAST (lmm.X, pyseer/lmm.py:95-99), h2 (lmm.py:115).
  * continuous selects the prefilter test (model.py:52-55 vs :57-68); pret/lrtt = filter_pvalue/lrt_pvalue
- * (compared with >=, lmm.py:174,201).  n_limbs = 4..7 int8 limbs of the fixed-point kernel matrix (0 = default 5).
+ * (compared with >=, lmm.py:174,201).  n_limbs = 3..7 int8 limbs of the fixed-point kernel matrix; 0 = automatic:
+ * the smallest of 4 and 5 whose typical a-posteriori bound on x^T K^-1 x is at most a quarter of the tolerance of sh_set_lmm_tol (1e-8; a variant
+ * whose own bound exceeds the tolerance is re-contracted with the extra limbs whichever count was chosen; sh_lmm_info / sh_lmm_bound report both).
  * With pret < 1 a pre-filtered variant is not fitted and carries NaN statistics (fit_lmm); with pret >= 1 every AF-passing variant
  * carries its statistics (fit_lmm_block) and masking by the prefilter flag is the caller's.
  * ------------------------------------------------------------------------------------------- */
