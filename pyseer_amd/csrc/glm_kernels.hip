@@ -789,8 +789,12 @@ __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_ele
 template <int Q, bool DELTA>
 __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
                                           const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
-                                          int part = 0, int nparts = 1)
+                                          int part = 0, int nparts = 1, double *hdl = nullptr)
 {
+    // hdl (DELTA): [2 + 2Q][64] doubles of LDS, zeroed by the caller.  The intercept and variant rows of X^T (W - W0) X are summed in single
+    // precision WITHIN a 64-sample word and in double precision across words: for a variant with a large effect (|beta| ~ 4) the differences
+    // w - w0 of its carriers are ~0.2 each, their running sum reaches hundreds, and 2500 fp32 additions at that magnitude put 1e-6 on the
+    // variant's own diagonal entry, i.e. on bse (measured on near-separating variants at N = 5000: 1.7e-6 against the fp64 restatement).
     // part / nparts: this wavefront's share of the samples (k_glm_pass32_split): whole 64-sample words [wd0, wd1); the last part also takes
     // the partial word and the odd sample
     constexpr int PC = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE;
@@ -873,6 +877,15 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
             for (int cb = 0; cb < NCB; ++cb) { za[cb] = zc[cb]; zb[cb] = zd[cb]; }
         }
         w = wn;
+        if (DELTA && hdl) {
+            hdl[lane] += (double)(h00.x + h00.y); hdl[64 + lane] += (double)(h10.x + h10.y);
+            h00 = v2f{0.0f, 0.0f}; h10 = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                hdl[(2 + j) * 64 + lane] += (double)(hz0[j].x + hz0[j].y); hdl[(2 + Q + j) * 64 + lane] += (double)(hz1[j].x + hz1[j].y);
+                hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f};
+            }
+        }
     }
     for (int pr = nwords * 32; tail && pr < nfull; ++pr) {                    // the last partial word, plainly
         if (pr == nwords * 32) w = T[(int64_t)(pr >> 5) * Vpad + v];
@@ -914,6 +927,13 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
     }
 #pragma unroll
     for (int a = 0; a < PC; ++a) g[a] = (double)gs[a];
+    if (DELTA && hdl) {
+        h00s = (float)(hdl[lane] + (double)h00s); h10s = (float)(hdl[64 + lane] + (double)h10s);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            hz0s[j] = (float)(hdl[(2 + j) * 64 + lane] + (double)hz0s[j]); hz1s[j] = (float)(hdl[(2 + Q + j) * 64 + lane] + (double)hz1s[j]);
+        }
+    }
     H[sidx(0, 0)] = h00s; H[sidx(1, 0)] = h10s; H[sidx(1, 1)] = h10s;
 #pragma unroll
     for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0s[j]; H[sidx(2 + j, 1)] = hz1s[j]; }
@@ -1777,11 +1797,14 @@ __global__ __launch_bounds__(64, 2) void k_glm_dpass_pk(const uint64_t *__restri
     int64_t v;
     const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
     __shared__ float tr[FastCols<Q>::LDS_FLOATS];
+    __shared__ double hdl[(2 + 2 * Q) * 64];
+#pragma unroll
+    for (int k = 0; k < 2 + 2 * Q; ++k) hdl[k * 64 + threadIdx.x] = 0.0;     // a lane only ever touches its own column
     double beta[PC], g[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
     float H[NH];
-    pass32_pk<Q, true>(T, Vpad, v, P, Wf, beta, H, g, tr);
+    pass32_pk<Q, true>(T, Vpad, v, P, Wf, beta, H, g, tr, 0, 1, hdl);
     if (!on) return;
 #pragma unroll
     for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];

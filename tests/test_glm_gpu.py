@@ -568,3 +568,36 @@ def test_logistic_fit_paths_agree(N, q, monkeypatch):
         for f in ("pvalue", "kbeta", "bse", "intercept"):
             close(r[f][~firth], base[f][~firth], rtol=5e-7 if f == "bse" else 2e-8, atol=1e-12, what="%s under %s" % (f, env))
         close(r["betas"][~firth], base["betas"][~firth], rtol=2e-8, atol=1e-10, what="betas under %s" % env)
+
+
+@pytest.mark.parametrize("N,q,V,seed", [(1000, 10, 30000, 1), (5000, 10, 6000, 2)])
+def test_strong_effects_and_awkward_covariates_sweep(N, q, V, seed):
+    """A sweep the round kernels were tuned against after it found them out (tools/gpu_glm_sweep.py): a binary covariate, an un-centred one
+    (2000 +- 10), a U-shaped allele-frequency spectrum and 15 % of the variants built FROM the phenotype (|beta| up to 5, some
+    near-separating).  The correction-form information matrix sums w - w0 in single precision; for such variants those differences are
+    large, which is why the intercept / variant rows are summed per 64-sample word and in fp64 across words (1.7e-6 on bse before)."""
+    from oracle import oracle as orc
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(seed)
+    W = rng.standard_normal((N, q)); W[:, 0] = rng.random(N) < 0.3; W[:, 1] = 2000 + 10 * W[:, 1]
+    eta = -0.5 + 0.9 * W[:, 0] + 0.5 * W[:, 2]
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    af = np.concatenate([rng.uniform(0.02, 0.98, V // 2), rng.beta(0.3, 0.3, V - V // 2)])
+    K = (rng.random((V, N)) < af[:, None])
+    eff = rng.random(V) < 0.15
+    K[eff] = rng.random((int(eff.sum()), N)) < (0.05 + 0.8 * y)[None, :] * rng.uniform(0.1, 1.0, int(eff.sum()))[:, None]
+    K = K.astype(np.uint8)
+    K = K[(K.mean(axis=1) >= 0.01) & (K.mean(axis=1) <= 0.99)]
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    want = orc.fixed_effects_batch(y, K.astype(float), W, False, 1.0, 1.0, nl, nf)
+    e = Engine(N); e.glm_setup(y, W, False, nl, nf); r = e.glm_batch(pack_variants(K)); e.close()
+    firth = (want["notes"] & 0x7C) != 0                     # Firth rows have their own tests (tie semantics, DESIGN.md section 6)
+    assert ((r["flags"] & 0x1FF)[~firth] == want["notes"][~firth]).all()
+    assert (np.abs(want["kbeta"][~firth]) > 3).sum() > 20    # the strong effects are really there
+    close(r["prep"][~firth], want["prep"][~firth], rtol=1e-12, what="prep")
+    close(r["kbeta"][~firth], want["kbeta"][~firth], rtol=1e-8, atol=1e-12, what="kbeta")
+    close(r["intercept"][~firth], want["intercept"][~firth], rtol=1e-7, atol=1e-12, what="intercept")
+    close(r["bse"][~firth], want["bse"][~firth], rtol=6e-7, what="bse")
+    close(r["pvalue"][~firth], want["pvalue"][~firth], rtol=1e-6, atol=1e-300, what="pvalue")
