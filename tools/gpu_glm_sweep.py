@@ -9,7 +9,7 @@ from pyseer_amd.model import fit_null
 N = int(os.environ.get("N", 1000)); q = int(os.environ.get("Q", 10)); V = int(os.environ.get("V", 100000)); seed = int(os.environ.get("SEED", 1))
 rng = np.random.default_rng(seed)
 W = rng.standard_normal((N, q)); W[:, 0] = rng.random(N) < 0.3; W[:, 1] = 2000 + 10 * W[:, 1]       # a binary and an un-centred column
-eta = -0.5 + 0.9 * W[:, 0] + 0.5 * W[:, 2]
+eta = -0.5 + 0.9 * W[:, 0] + 0.5 * W[:, min(2, q - 1)]
 y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
 af = np.concatenate([rng.uniform(0.02, 0.98, V // 2), rng.beta(0.3, 0.3, V - V // 2)])
 K = (rng.random((V, N)) < af[:, None])
