@@ -6,21 +6,23 @@ import numpy as np
 from oracle import oracle as orc
 from pyseer_amd.engine import Engine, pack_variants
 from pyseer_amd.model import fit_null
-N = int(os.environ.get("N", 1000)); q = int(os.environ.get("Q", 10)); V = int(os.environ.get("V", 100000)); seed = int(os.environ.get("SEED", 1))
+N = int(os.environ.get("N", 1000)); q = int(os.environ.get("Q", 10)); V = int(os.environ.get("V", 100000)); seed = int(os.environ.get("SEED", 1)); CONT = int(os.environ.get("CONT", 0))
 rng = np.random.default_rng(seed)
 W = rng.standard_normal((N, q)); W[:, 0] = rng.random(N) < 0.3; W[:, 1] = 2000 + 10 * W[:, 1]       # a binary and an un-centred column
 eta = -0.5 + 0.9 * W[:, 0] + 0.5 * W[:, min(2, q - 1)]
 y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+if CONT:
+    y = eta + rng.standard_normal(N)
 af = np.concatenate([rng.uniform(0.02, 0.98, V // 2), rng.beta(0.3, 0.3, V - V // 2)])
 K = (rng.random((V, N)) < af[:, None])
 eff = rng.random(V) < 0.15                                        # some real effects, some near-separating
-K[eff] = rng.random((int(eff.sum()), N)) < (0.05 + 0.8 * y)[None, :] * rng.uniform(0.1, 1.0, int(eff.sum()))[:, None]
+K[eff] = rng.random((int(eff.sum()), N)) < (0.05 + 0.8 * (y > np.median(y)))[None, :] * rng.uniform(0.1, 1.0, int(eff.sum()))[:, None]
 K = K.astype(np.uint8)
 K = K[(K.mean(axis=1) >= 0.01) & (K.mean(axis=1) <= 0.99)]
 e0 = np.zeros((0, 0))
-nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
-t0 = time.time(); want = orc.fixed_effects_batch(y, K.astype(float), W, False, 1.0, 1.0, nl, nf); t1 = time.time()
-e = Engine(N); e.glm_setup(y, W, False, nl, nf); r = e.glm_batch(pack_variants(K)); e.close()
+nl = fit_null(y, W, e0, bool(CONT)).llf; nf = np.nan if CONT else fit_null(y, W, e0, False, firth=True)
+t0 = time.time(); want = orc.fixed_effects_batch(y, K.astype(float), W, bool(CONT), 1.0, 1.0, nl, nf); t1 = time.time()
+e = Engine(N); e.glm_setup(y, W, bool(CONT), nl, nf); r = e.glm_batch(pack_variants(K)); e.close()
 firth = (want["notes"] & 0x7C) != 0
 out = {"N": N, "q": q, "variants": int(K.shape[0]), "oracle_s": round(t1 - t0, 1), "firth_rows": int(firth.sum()),
        "note_mismatches": int(((r["flags"] & 0x1FF) != want["notes"]).sum())}

@@ -30,7 +30,7 @@ for h2_force in (None, 0.9, 0.99):
     af = Kv.mean(axis=1); Kv = Kv[(af > 0.01) & (af < 0.99)]
     wb, ws, wf, wp = orc.LmmOracle(U, S, y, C).block(h2, Kv.astype(float))
     print("h2 = %.4f  S range %.3g .. %.3g  Sd_max/Sd_min = %.3g" % (h2, S.min(), S.max(), (h2 * S.max() + 1 - h2) / (h2 * S.min() + 1 - h2)))
-    for L in (4, 5, 6):
+    for L in (0, 4, 5, 6):                                    # 0 = the automatic choice
         e = Engine(N); e.lmm_setup(U, S, y, C, h2, n_limbs=L)
         r = e.lmm_batch(pack_variants(Kv)); e.close()
         ok = np.isfinite(ws) & (ws > 1e-7)
