@@ -364,7 +364,9 @@ def main():
     # sanity: the timed work produced finite statistics (row 2 = beta / kbeta; AF-filtered rows of the fixed-effects configs are NaN by contract)
     fin = torch.isfinite(out[2])
     if not lmm:
-        fin = fin | ((fl & 1) != 0)
+        # NaN by contract: rows outside the AF window (note bit 0) and rows whose fit_firth returned None (firth-fail, bit 6: with the reference's
+        # literal step-halving rule a few 1e-4 of forced-Firth fits exhaust step_limit on a last-bit tie)
+        fin = fin | ((fl & 1) != 0) | ((fl & 64) != 0)
     frac_finite = float(fin.double().mean().item())
     per_rank = [float(Vs) * args.steps / dt_local]
     fin_all = [frac_finite]

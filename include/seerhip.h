@@ -163,6 +163,9 @@ typedef struct sh_reader sh_reader;
 sh_reader  *sh_reader_open(const char *path, const char *const *sample_names, int n_samples);
 void        sh_reader_close(sh_reader *r);
 const char *sh_reader_error(void);
+/* how many readers the caller is about to run at once (`--kmers a.gz b.gz ...` = one per file, pyseer/__main__.py:526 reads ONE): readers
+ * opened afterwards share the usable CPUs (cgroup quota) between them instead of starting a full worker pool each.  Process-wide hint. */
+void        sh_reader_set_concurrency(int n_readers);
 /* parses up to max_variants lines; returns how many (0 = end of file, -1 = error, -2 = the variant names of this block need more
  * than names_cap bytes: nothing was consumed, sh_reader_names_needed() gives the size to retry with -- the reference has no limit on
  * name length, and unitig names run to tens of kilobases).  bits: max_variants*row_bytes;

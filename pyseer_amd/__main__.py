@@ -23,7 +23,7 @@ from . import __version__
 from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
 from .input import (load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
                     iter_packed_blocks, iter_packed_blocks_native, iter_packed_blocks_native_multi, iter_packed_blocks_cached,
-                    PackedCacheWriter)
+                    PackedCacheWriter, packed_cache_complete)
 from .lmm import initialise_lmm, mask_like_fit_lmm
 from .model import fit_null, covariate_block
 from .utils import format_output
@@ -299,7 +299,7 @@ def main(argv=None):
         printed += 1
         out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
 
-    cache_out = None
+    cache_out, cache_stamp = None, None
     if options.packed_cache and native and not options.load_packed and not options.save_packed:
         # the automatic form of --save-packed / --load-packed: one file next to the input, tied to it by size + mtime (a sidecar stamp),
         # and to the run by the sample list the cache itself stores
@@ -312,18 +312,26 @@ def main(argv=None):
             fresh = _os.path.exists(side) and open(side + ".stamp").read().strip() == stamp
         except (IOError, OSError):
             fresh = False
+        if fresh and not packed_cache_complete(side):
+            sys.stderr.write("Packed cache %s is incomplete (an interrupted run); parsing %s again\n" % (side, var_file))
+            fresh = False
         if fresh:
             try:
                 next(iter(iter_packed_blocks_cached(p, side, options.min_af, options.max_af, 1)), None)    # header + sample list check
                 options.load_packed = side
-            except (ValueError, IOError):
+            except ValueError:
                 sys.stderr.write("Packed cache %s was written for other samples; parsing %s again\n" % (side, var_file))
                 fresh = False
+            except IOError as ex:
+                sys.stderr.write("Packed cache %s cannot be used (%s); parsing %s again\n" % (side, ex, var_file))
+                fresh = False
         if not fresh:
-            try:
-                open(side + ".stamp", "w").write(stamp + "\n")
+            # the cache is written to a temporary name and renamed when the run has read the whole input; the stamp follows the rename
+            # (PackedCacheWriter.close), so an interrupted run leaves neither
+            if _os.access(_os.path.dirname(_os.path.abspath(side)) or ".", _os.W_OK):
                 options.save_packed = side
-            except (IOError, OSError):
+                cache_stamp = (side + ".stamp", stamp)
+            else:
                 sys.stderr.write("Cannot write a packed cache next to %s; continuing without\n" % var_file)
     if options.load_packed:
         blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
@@ -333,7 +341,7 @@ def main(argv=None):
                                                  want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
     elif native:
         if options.save_packed:
-            cache_out = PackedCacheWriter(options.save_packed, [str(x) for x in p.index])
+            cache_out = PackedCacheWriter(options.save_packed, [str(x) for x in p.index], stamp=cache_stamp)
         blocks = iter_packed_blocks_native(p, var_file, options.min_af, options.max_af, options.block_size,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples,
                                            save_to=cache_out)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sh_sim_accumulate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "sh_sim_finish": (C.c_int, [C.c_void_p, c_dp]),
     "sh_reader_open": (C.c_void_p, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
+    "sh_reader_set_concurrency": (None, [C.c_int]),
     "sh_reader_close": (None, [C.c_void_p]),
     "sh_reader_error": (C.c_char_p, []),
     "sh_reader_next": (C.c_int64, [C.c_void_p, C.c_int64, c_u8p, C.c_int64, C.POINTER(C.c_int32), C.c_char_p, C.c_int64,

@@ -680,7 +680,7 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     const int64_t Vpad = (V + 511) / 512 * 512;
     int rc = ensure_ws(c, Vpad); if (rc) return rc;
     hipStream_t st = c->stream;
-    if (Vpad > c->cap_ref) {
+    if (Vpad > c->cap_ref || (c->E > 0 && !c->d_T3)) {                // (a context set up again with extra limbs after batches without them has no T3 / q3 yet)
         hipFree(c->d_flip); hipFree(c->d_T3); hipFree(c->d_q3); hipFree(c->d_rlist);
         c->d_flip = nullptr; c->d_T3 = nullptr; c->d_q3 = nullptr; c->d_rlist = nullptr;
         HIPCHK(dmalloc(&c->d_flip, Vpad)); HIPCHK(dmalloc(&c->d_rlist, Vpad));

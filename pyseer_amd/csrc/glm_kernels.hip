@@ -21,134 +21,7 @@
 #endif
 
 #include "glm_common.h"
-
-// ---- LDL^T of a packed symmetric P x P matrix, in place (no pivoting; tolerates indefinite matrices) ----------------
-// returns false when a pivot is exactly zero (or NaN-free tiny relative to its diagonal when rel_tol > 0).
-template <int P>
-__device__ __forceinline__ bool ldl_factor(double (&A)[P * (P + 1) / 2], double rel_tol, double *det)
-{
-    bool ok = true;
-    double dt = 1.0;
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        double v[P];
-        const double ajj = A[sidx(j, j)];
-        double d = ajj;
-#pragma unroll
-        for (int k = 0; k < j; ++k) { v[k] = A[sidx(j, k)] * A[sidx(k, k)]; d = fma(-A[sidx(j, k)], v[k], d); }
-        if (d == 0.0 || fabs(d) <= rel_tol * fabs(ajj)) ok = false;
-        A[sidx(j, j)] = d;
-        dt *= d;
-        const double inv = 1.0 / d;
-#pragma unroll
-        for (int i = j + 1; i < P; ++i) {
-            double s = A[sidx(i, j)];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s = fma(-A[sidx(i, k)], v[k], s);
-            A[sidx(i, j)] = s * inv;
-        }
-    }
-    *det = dt;
-    return ok;
-}
-
-template <int P>
-__device__ __forceinline__ void ldl_solve(const double (&A)[P * (P + 1) / 2], double (&b)[P])
-{
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-#pragma unroll
-        for (int k = 0; k < i; ++k) b[i] = fma(-A[sidx(i, k)], b[k], b[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i) b[i] = b[i] / A[sidx(i, i)];
-#pragma unroll
-    for (int i = P - 1; i >= 0; --i) {
-#pragma unroll
-        for (int k = i + 1; k < P; ++k) b[i] = fma(-A[sidx(k, i)], b[k], b[i]);
-    }
-}
-
-
-// ---- sample-split blocks: S wavefronts share the same 64 variants (lane = variant) and each walks every S-th 64-sample word --------
-// The list-driven kernels (Firth rounds, the fp64 restart of the Newton iteration) see anything from one to 10^5 variants per
-// launch; with one wavefront per 64 variants a short list is bound by the latency of one lane walking all N samples (3 ms per
-// pass at N = 5000, however few variants there are).  S depends only on N (glm_split_waves), never on the length of a list, so a
-// variant's partial sums are combined in the same order whatever else is in its batch: results do not depend on batch composition.
-// Partial sums go through LDS in chunks of XW_CH accumulators: wave 0 adds waves 1..S-1 in that order.
-#define XW_CH 16
-extern __shared__ double xw_lds[];
-struct XWave { int w, lane, S; };
-// readfirstlane: the wavefront index is uniform within a wavefront, but the compiler cannot know it; without this every address
-// derived from it (the sample index, hence the covariate rows) is treated as divergent and loaded per lane instead of through SGPRs
-__device__ __forceinline__ XWave xwave()
-{
-    return XWave{__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), (int)(blockDim.x >> 6)};
-}
-
-// wavefronts per 64 variants in the list-driven kernels: a function of the sample count only, so that results do not depend
-// on what else is in a batch.  SEERHIP_SPLIT=1|2|4|8 overrides it (A/B timing).
-static int glm_split_waves(int NB64)
-{
-    static const int forced = [] { const char *e = getenv("SEERHIP_SPLIT"); return e ? atoi(e) : 0; }();
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
-    return NB64 >= 64 ? 8 : NB64 >= 8 ? 4 : NB64 >= 4 ? 2 : 1;      // measured at N = 500 ... 5000
-}
-static size_t glm_split_lds(int S) { return S > 1 ? (size_t)((S - 1) * XW_CH + 2) * 64 * sizeof(double) : 0; }
-
-template <int NA>
-__device__ __forceinline__ void xw_sum(const XWave &x, double (&a)[NA])            // block-uniform call; total valid in wave 0
-{
-    if (x.S == 1) return;
-#pragma unroll
-    for (int c0 = 0; c0 < NA; c0 += XW_CH) {
-        if (x.w > 0) {
-#pragma unroll
-            for (int k = 0; k < XW_CH; ++k) if (c0 + k < NA) xw_lds[((x.w - 1) * XW_CH + k) * 64 + x.lane] = a[c0 + k];
-        }
-        __syncthreads();
-        if (x.w == 0) {
-            for (int ww = 1; ww < x.S; ++ww) {
-#pragma unroll
-                for (int k = 0; k < XW_CH; ++k) if (c0 + k < NA) a[c0 + k] += xw_lds[((ww - 1) * XW_CH + k) * 64 + x.lane];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ void xw_sum_max(const XWave &x, double &sum, double &mx)  // sum and max of two scalars, as xw_sum
-{
-    if (x.S == 1) return;
-    if (x.w > 0) { xw_lds[((x.w - 1) * XW_CH + 0) * 64 + x.lane] = sum; xw_lds[((x.w - 1) * XW_CH + 1) * 64 + x.lane] = mx; }
-    __syncthreads();
-    if (x.w == 0) {
-        for (int ww = 1; ww < x.S; ++ww) {
-            sum += xw_lds[((ww - 1) * XW_CH + 0) * 64 + x.lane];
-            mx = fmax(mx, xw_lds[((ww - 1) * XW_CH + 1) * 64 + x.lane]);
-        }
-    }
-    __syncthreads();
-}
-
-template <int NA>
-__device__ __forceinline__ void xw_bcast(const XWave &x, double (&a)[NA], bool &flag)   // wave 0 -> every wave (NA <= XW_CH)
-{
-    static_assert(NA <= XW_CH, "broadcast area is one chunk plus the flag row");
-    if (x.S == 1) return;
-    if (x.w == 0) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k) xw_lds[k * 64 + x.lane] = a[k];
-        xw_lds[NA * 64 + x.lane] = flag ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    if (x.w > 0) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k) a[k] = xw_lds[k * 64 + x.lane];
-        flag = xw_lds[NA * 64 + x.lane] != 0.0;
-    }
-    __syncthreads();
-}
+#include "glm_device.h"
 
 // ---- one pass over the samples at beta: X^T W X (packed), optional score, log-likelihood, max |mu - y| --------------
 // column order of the design: 0 = intercept, 1 = variant, 2.. = W columns (model.py:286-297)
@@ -210,38 +83,6 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
         }
     }
     H[sidx(1, 1)] = H[sidx(1, 0)];
-}
-
-// Scalar loads return out of order, so the only wait the compiler can place for them is "all of them" (s_waitcnt lgkmcnt(0)).  A software
-// pipeline over two wave-uniform buffers therefore needs the wait for buffer A to sit BEFORE the loads of buffer B are issued; left alone,
-// the scheduler hoists B's loads above A's first use and the wait then covers both.  pipe_zero(x) is a zero the compiler cannot see
-// through, computed from one of A's SGPRs: added to B's index, it orders B's loads behind A's arrival and keeps them scalar.
-// (s_and_b32 writes SCC: declared, or a compare scheduled across the asm loses its result)
-__device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x)) : "scc"); return z; }
-__device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x)) : "scc"); return z; }
-
-// e^-x for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 (two-part ln 2), |r| <= 0.3466, Taylor to degree 13 (remainder 4e-18), 2^k by v_ldexp
-__device__ __forceinline__ double exp_neg(double x)
-{
-    const double u = -fmin(x, 800.0);
-    const double kf = rint(u * 1.4426950408889634074);
-    double r = fma(kf, -6.93147180369123816490e-01, u);
-    r = fma(kf, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                       // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);                     // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);                    // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);                    // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);                   // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
 }
 
 // ---- info_pass for y in {0, 1}, leaner and with the sample's record (covariates, y) fetched one sample ahead ----------------------
@@ -631,18 +472,6 @@ __device__ __forceinline__ void final_pass_mfma(const uint64_t *__restrict__ T, 
 
 // beta workspace: SoA, bw[a * Vpad + v]; state[v]: 0 = nothing more to fit here, 1 = beta ready for the final pass
 struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *tile_list; int *tile_count; };
-
-// wave-aggregated append: one atomic per wavefront; callable from divergent code (the leader is one of the active lanes)
-__device__ __forceinline__ void list_push(bool p, int *__restrict__ list, int *__restrict__ count, int v)
-{
-    const unsigned long long m = __ballot(p);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == lead) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, lead);
-    if (p) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
-}
 
 // ---- kernel 1: a1 prefilter + routing + phase A (fast Newton) ---------------------------------------------------------------
 template <int Q, bool CHORD>
@@ -1955,9 +1784,12 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
             const bool noise_step = stepmax < P.firth_accept;
             if (state == 3) {
             } else if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !noise_step) {    // step halving, model.py:467-474
+                // once beta + 0.5 (cand - beta) returns cand bit for bit every later comparison repeats this one: the reference walks on to
+                // j > step_limit and gives up (model.py:471-473); same verdict, without the walk
+                bool moved = false;
 #pragma unroll
-                for (int a = 0; a < PC; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
-                if (++halvings > 1000) { failed = true; state = 3; }
+                for (int a = 0; a < PC; ++a) { const double nc = beta[a] + 0.5 * (cand[a] - beta[a]); moved = moved || (nc != cand[a]); cand[a] = nc; }
+                if (++halvings > 1000 || !moved) { failed = true; state = 3; }
             } else {
                 double sn = 0.0;
 #pragma unroll
@@ -2007,24 +1839,6 @@ __global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T
 // in the other phase.  Per-variant state lives in HBM, SoA over the slot index: beta, cand, the LDL^T factor of I(beta),
 // F(beta), I11, the previous step norm, counters.
 // =====================================================================================================================
-struct FirthWork {
-    double *st;                 // [FW_ND(PC)][cap]
-    int *iter, *halv, *var;     // [cap] accepted steps (-1 = initial evaluation pending), halvings of the current step, variant index
-    int64_t cap;
-    int *blk_list, *blk_count;  // slots handed to k_firth_blk after GlmParams.firth_handoff accepted steps
-};
-// A variant still iterating after `firth_handoff` accepted steps leaves the rounds and is finished by one workgroup (k_firth_blk).
-// The rule looks at the variant alone, so which kernel finishes a variant -- and hence the order of its sums -- does not depend
-// on what else is in the batch.  Ordinary variants converge in 5-14 steps; (quasi-)separated ones need hundreds.
-// (GlmParams.firth_handoff: 16, or 0 for the routed variants of an ordinary run at N >= 768, see sh_glm_setup)
-template <int PC> __host__ __device__ constexpr int fw_beta() { return 0; }
-template <int PC> __host__ __device__ constexpr int fw_cand() { return PC; }
-template <int PC> __host__ __device__ constexpr int fw_fac() { return 2 * PC; }
-template <int PC> __host__ __device__ constexpr int fw_fcur() { return 2 * PC + PC * (PC + 1) / 2; }
-template <int PC> __host__ __device__ constexpr int fw_i11() { return fw_fcur<PC>() + 1; }
-template <int PC> __host__ __device__ constexpr int fw_snp() { return fw_fcur<PC>() + 2; }
-template <int PC> __host__ __device__ constexpr int fw_nd() { return fw_fcur<PC>() + 3; }
-
 template <int Q>
 __global__ __launch_bounds__(64) void k_firth_init(const int *__restrict__ firth_list, const int *__restrict__ firth_count, GlmParams P,
                                                    FirthWork fw, int *__restrict__ eval_list, int *__restrict__ eval_count)
@@ -2109,13 +1923,18 @@ __global__ __launch_bounds__(LEAN ? FIRTH_EVAL_THREADS : 512) void k_firth_eval(
             accept = false;
             const int h = fw.halv[s] + 1;
             fw.halv[s] = h;
-            if (h > 1000) failed = true;
+            bool moved = false;                                      // the halving map at its fixed point: see k_firth_eval2 (firth_rounds.hip)
+            double nc[PC];
+#pragma unroll
+            for (int a = 0; a < PC; ++a) {
+                const double b = fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
+                nc[a] = b + 0.5 * (cand[a] - b);
+                moved = moved || (nc[a] != cand[a]);
+            }
+            if (h > 1000 || !moved) failed = true;
             else {
 #pragma unroll
-                for (int a = 0; a < PC; ++a) {
-                    const double b = fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
-                    fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = b + 0.5 * (cand[a] - b);
-                }
+                for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = nc[a];
                 next_eval[atomicAdd(next_eval_count, 1)] = s;
             }
         } else {
@@ -2358,9 +2177,14 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
         // thread-0 state
         double Fcur = 0.0, snp = 0.0;
         int iter = 0, halv = 0;
+        // a slot handed over in the middle of a step halving (k_firth_eval2 after FIRTH_HALV_HANDOFF rejections): its pending candidate and
+        // halving count are in the state; the first pass below skips the score and goes straight to the comparison, against F(beta) as
+        // THIS kernel evaluates it
+        bool pending = fw.halv[s] > 0;
         __syncthreads();
         if (tid == 0) {
             for (int a = 0; a < PC; ++a) s_beta[a] = fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
+            if (pending) { for (int a = 0; a < PC; ++a) s_cand[a] = fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s]; halv = fw.halv[s]; }
             Fcur = fw.st[(int64_t)fw_fcur<PC>() * cap + s]; snp = fw.st[(int64_t)fw_snp<PC>() * cap + s]; iter = fw.iter[s];
         }
         __syncthreads();
@@ -2382,7 +2206,7 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
             double U[PC], beta[PC];
 #pragma unroll
             for (int a = 0; a < PC; ++a) { U[a] = 0.0; beta[a] = s_beta[a]; }
-            for (int i = tid; i < N; i += 256) {
+            for (int i = tid; i < N && !pending; i += 256) {
                 const uint64_t w64 = T[(int64_t)(i >> 6) * Vpad + v];
                 double x[PC];
                 x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> (i & 63)) & 1ull);
@@ -2405,14 +2229,17 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
 #pragma unroll
                 for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
             }
-            blk_sum<PC>(U, s_red, tid);
-            if (tid == 0) {
-                double A[NH];
-                for (int a = 0; a < NH; ++a) A[a] = s_fac[a];
-                ldl_solve<PC>(A, U);                                                   // var_covar_mat . U, model.py:463
-                for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + U[a];
-                halv = 0;
+            if (!pending) {
+                blk_sum<PC>(U, s_red, tid);
+                if (tid == 0) {
+                    double A[NH];
+                    for (int a = 0; a < NH; ++a) A[a] = s_fac[a];
+                    ldl_solve<PC>(A, U);                                               // var_covar_mat . U, model.py:463
+                    for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + U[a];
+                    halv = 0;
+                }
             }
+            pending = false;
             // ---- penalised likelihood at cand; accept / halve / converge / fail (k_firth_eval)
             for (;;) {
                 __syncthreads();
@@ -2428,8 +2255,10 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
                         for (int a = 0; a < PC; ++a) { const double d = s_cand[a] - s_beta[a]; stepmax = fmax(stepmax, fabs(d)); sn = fma(d, d, sn); }
                         bool failed = false, conv = false;
                         if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !(stepmax < P.firth_accept)) {   // step halving, model.py:467-474
-                            if (++halv > 1000) failed = true;
-                            else { for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); s_ctl = 0; }
+                            bool moved = false;                                          // fixed point of the halving map = the reference's 1000 identical comparisons
+                            for (int a = 0; a < PC; ++a) { const double nc = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); moved = moved || (nc != s_cand[a]); s_cand[a] = nc; }
+                            if (++halv > 1000 || !moved) failed = true;
+                            else s_ctl = 0;
                         } else {
                             sn = sqrt(sn);
                             conv = (iter > 0) && (snp < 1e-4);                           // the PREVIOUS step, model.py:477-479
@@ -2656,8 +2485,11 @@ __global__ __launch_bounds__(256) void k_glm_firth_pinv(const uint64_t *__restri
                 if (tid == 0) {
                     Fcand = -(ll + 0.5 * log(slow_det<PC>(I)));
                     if (!(Fcand > Fcur + P.firth_noise * fabs(Fcur))) s_ctl = 1;
-                    else if (++halvings > 1000) { failed = true; s_ctl = 2; }
-                    else { for (int a = 0; a < PC; ++a) s_cand[a] = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); s_ctl = 0; }
+                    else {
+                        bool moved = false;                                              // fixed point of the halving map: see k_firth_eval2
+                        for (int a = 0; a < PC; ++a) { const double nc = s_beta[a] + 0.5 * (s_cand[a] - s_beta[a]); moved = moved || (nc != s_cand[a]); s_cand[a] = nc; }
+                        if (++halvings > 1000 || !moved) { failed = true; s_ctl = 2; } else s_ctl = 0;
+                    }
                 }
                 __syncthreads();
                 if (s_ctl != 0) break;
@@ -3223,7 +3055,7 @@ extern "C" hipError_t shk_firth_launch(hipStream_t st, int Q, int which, int64_t
                                        int *step_list, int *step_count, double *out, uint32_t *flags, int *plist, int *pcount,
                                        int *blk_list, int *blk_count)
 {
-    FirthWork fw{fst, fiter, fhalv, fvar, fcap, blk_list, blk_count};
+    FirthWork fw{fst, fiter, fhalv, fvar, fcap, blk_list, blk_count, nullptr, nullptr};
 #define FIRTH_CASE(q) case q: return launch_firth<q>(st, which, n, T, Vpad, V, y, W, P, fw, in_list, in_count, next_eval, next_eval_count, step_list, step_count, out, flags, plist, pcount);
     switch (Q) {
         FIRTH_CASE(0) FIRTH_CASE(1) FIRTH_CASE(2) FIRTH_CASE(3) FIRTH_CASE(4) FIRTH_CASE(5) FIRTH_CASE(6) FIRTH_CASE(7)

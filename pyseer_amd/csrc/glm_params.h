@@ -14,11 +14,12 @@ struct GlmParams {
     const double *ws;             // N x q covariates standardised per column (the fast Newton path iterates in these coordinates), or null
     const double *wstd;           // [2q] column means, then column scales, of that standardisation
     const double *ztz, *zty;      // Z^T Z (packed lower, (q+1) x (q+1)) and Z^T y for Z = [1, W]: the variant-independent part of the OLS normal equations
+    int firth_halv_handoff;       // rejected halvings of one step after which a variant leaves the rounds for k_firth_blk (SEERHIP_FIRTH_HALV_HANDOFF, default 6)
     int firth_handoff;            // accepted Firth steps after which a variant leaves the rounds for k_firth_blk (SEERHIP_FIRTH_HANDOFF)
     int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
     // Firth step halving (model.py:465-474).  Default: an increase of F within firth_noise * |F| (4 ulp) is evaluation noise, and a step
-    // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_FIRTH_STRICT=1 sets both to 0: the reference's
-    // literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
+    // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_FIRTH_LITERAL=1 / SEERHIP_FIRTH_STRICT=1 set both
+    // to 0: the reference's literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
     double firth_noise, firth_accept;
     // Warm start of the fast Newton phase: the maximum-likelihood fit WITHOUT the variant column, [b0, bz...] in the coordinates that phase
     // iterates in (standardised covariates), computed once per run (sh_glm_setup).  The likelihood is concave, so the iteration reaches the
@@ -51,6 +52,8 @@ struct GlmParams {
                                   // each (even sample, odd sample)); yf, w0f = y and w0 as float arrays (the odd last sample); null = unpacked passes
     const double *rec;            // per sample a record of Q + 1 doubles (standardised covariates, then y): k_glm_score / k_glm_ll
     int firth_lean;               // bit 0: k_firth_eval<Q, true>, bit 1: k_firth_step<Q, true> (both when rec_o is set; SEERHIP_FIRTH_LEAN=1/2 selects one for A/B)
+    const double *rec_f;          // Firth round kernels (firth_rounds.hip): per sample Q covariates as given, then s = 1 - 2 y
+    const float *rec_pf;          // per PAIR of samples Q float2 = (even, odd) standardised covariates: k_firth_step2 (staged through LDS)
     const double *rec_o;          // the same with the covariates as given, y in {0, 1} only: the Firth rounds (info_pass_bin); null = info_pass
     double null_h[16], null_g[16];
 };

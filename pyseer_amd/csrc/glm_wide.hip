@@ -641,9 +641,13 @@ __global__ __launch_bounds__(256) void k_glm_wide_firth_blk(const uint64_t *__re
                 for (int a = 0; a < pc; ++a) stepmax = fmax(stepmax, fabs(s_cand[a] - s_beta[a]));
                 if (!(Fcand > Fcur + P.firth_noise * fabs(Fcur)) || stepmax < P.firth_accept) break;   // noise steps accepted outright, see k_glm_firth
                 __syncthreads();
+                // fixed point of the halving map (every later comparison repeats this one up to step_limit, model.py:471-473): same verdict now
+                bool moved = false;
+                for (int a = 0; a < pc; ++a) moved = moved || ((s_beta[a] + 0.5 * (s_cand[a] - s_beta[a])) != s_cand[a]);
+                __syncthreads();
                 if (tid < pc) s_cand[tid] = s_beta[tid] + 0.5 * (s_cand[tid] - s_beta[tid]);
                 __syncthreads();
-                if (++halvings > 1000) { failed = true; break; }
+                if (++halvings > 1000 || !moved) { failed = true; break; }
             }
             if (failed) break;
             double sn = 0.0;
@@ -744,9 +748,10 @@ __global__ __launch_bounds__(64) void k_glm_wide_firth(const uint64_t *__restric
             for (int a = 0; a < pc; ++a) stepmax = fmax(stepmax, fabs(cand[a] - beta[a]));
             // steps below 1e-10 are accepted outright: F(new) > F(old) is rounding noise there (see k_glm_firth)
             if (!(Fcand > Fcur + P.firth_noise * fabs(Fcur)) || stepmax < P.firth_accept) break;       // step halving, model.py:467-474
+            bool moved = false;                                       // fixed point of the halving map: the reference's remaining comparisons repeat this one
 #pragma unroll 1
-            for (int a = 0; a < pc; ++a) cand[a] = beta[a] + 0.5 * (cand[a] - beta[a]);
-            if (++halvings > 1000) { failed = true; break; }
+            for (int a = 0; a < pc; ++a) { const double nc = beta[a] + 0.5 * (cand[a] - beta[a]); moved = moved || (nc != cand[a]); cand[a] = nc; }
+            if (++halvings > 1000 || !moved) { failed = true; break; }
         }
         if (failed) break;
         double sn = 0.0;

@@ -132,7 +132,12 @@ struct Decoder {
     bool read_gzip_header()
     {
         // needs the whole header in the input (the reader maps the file)
-        if (members > 0 && (in_end - in < 2 || in[0] != 0x1f || in[1] != 0x8b)) { state = DONE; return false; }   // trailing padding: ignored
+        if (members > 0 && (in_end - in < 2 || in[0] != 0x1f || in[1] != 0x8b)) {
+            // after the last member only zero padding is accepted (python's gzip module, which the reference reads through, skips zero bytes
+            // and raises on anything else)
+            for (const uint8_t *p = in; p < in_end; ++p) if (*p) return fail("trailing garbage after the last gzip member");
+            state = DONE; return false;
+        }
         if (in_end - in < 18) return fail("truncated gzip header");
         if (in[0] != 0x1f || in[1] != 0x8b) return fail("not a gzip member");
         if (in[2] != 8) return fail("unknown gzip compression method");
@@ -288,7 +293,10 @@ struct Decoder {
                         refill();                                              // e was looked up in bits that stay where they are
                     }
                     drop(e & 0x1F);
-                    if (e & F_EOB) { state = last_block ? TRAILER : BLOCK_HEAD; goto out_codes; }
+                    if (e & F_EOB) {
+                        if (bitcnt < 0) { fail("truncated deflate stream"); goto out_codes; }      // an end-of-block code read from bits past the input
+                        state = last_block ? TRAILER : BLOCK_HEAD; goto out_codes;
+                    }
                     if ((e >> 16) == 0) { fail("invalid literal/length symbol"); goto out_codes; }
                     {
                         const int xb = (e >> 8) & 0x1F;

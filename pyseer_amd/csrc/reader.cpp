@@ -152,7 +152,11 @@ static bool put_slab(sh_reader *r, Slab &&sl)
 static char *get_buf(sh_reader *r)                                // nullptr when the reader is being closed
 {
     std::unique_lock<std::mutex> lk(r->mu);
-    if (r->free_bufs.empty() && r->all_bufs.size() < 64) {        // the consumer may hold many slabs for one large block: grow on demand
+    // Grow on demand, without a cap: sh_reader_next keeps every slab of the block it is cutting until it returns, so a block whose text spans
+    // more slabs than any fixed number of buffers would leave the producer waiting for a buffer and the consumer waiting for a slab (round 2
+    // capped at 64: --block_size 65536 at N = 5000, ~2 GB of text per block, hung).  What bounds the memory is the block the caller asked
+    // for plus the look-ahead of `depth` slabs (put_slab), not this function.
+    if (r->free_bufs.empty()) {
         char *b = (char *)malloc(r->pad_bytes + r->slab_bytes + 1024);
         if (b) { r->all_bufs.push_back(b); return b; }
     }
@@ -295,9 +299,28 @@ static void produce_bgzf(sh_reader *r)
     }
 }
 
+// Parser / CRC workers per reader: the CPUs this process may really use -- hardware threads cut by the cgroup CPU quota (a GPU box shows 256
+// CPUs under a quota of 16) -- shared between the readers that run at once (sh_reader_set_concurrency: `--kmers a.gz b.gz ...` opens one
+// reader per file, and 8 x 47 workers on 16 CPUs was the oversubscription the writer and the bench already avoid), at most 48, at least 2.
+static std::atomic<int> g_reader_concurrency{1};
+static int reader_threads()
+{
+    long t = (long)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32]; long per = 0;
+        if (fscanf(f, "%31s %ld", q, &per) == 2 && q[0] != 'm' && per > 0) { const long qq = atol(q); if (qq > 0) t = std::min(t, (qq + per - 1) / per); }
+        fclose(f);
+    }
+    t = std::min<long>(48, t);
+    const int share = std::max(1, g_reader_concurrency.load());
+    return (int)std::max<long>(2, (t + share - 1) / share);
+}
+
 extern "C" {
 
 const char *sh_reader_error(void) { return g_rerr.c_str(); }
+
+void sh_reader_set_concurrency(int n_readers) { g_reader_concurrency.store(n_readers < 1 ? 1 : n_readers); }
 
 sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int n_samples)
 {
@@ -305,8 +328,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     sh_reader *r = new sh_reader();
     r->n = n_samples;
     r->index.build(sample_names, n_samples);
-    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-    int nt = std::min(48, hw);
+    int nt = reader_threads();
     if (const char *te = std::getenv("SEERHIP_READER_THREADS")) nt = std::max(1, std::atoi(te));
     r->pool.reset(new ParPool(nt - 1));
     const char *sel = std::getenv("SEERHIP_READER");
@@ -330,7 +352,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     if (const char *pb = std::getenv("SEERHIP_READER_PAD")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
-    if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, hw / 2) - 1)));
+    if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
     r->producer = std::thread([r] {
         if (r->mode == 0) produce_plain(r); else if (r->mode == 1) produce_gzip(r); else produce_bgzf(r);
     });

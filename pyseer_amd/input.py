@@ -471,13 +471,19 @@ def iter_packed_blocks_native_multi(p, paths, min_af, max_af, block_size, want_p
             self.room = threading.Semaphore(0)
             self.held = 0
             self.lock = threading.Lock()
-            self.t = threading.Thread(target=self.work, args=(path,), daemon=True)
+            self.reader, self.open_error = None, None
+            try:
+                self.reader = NativeKmerReader(path, samples, block_size)
+            except BaseException as ex:       # re-raised in the consumer, in file order
+                self.open_error = ex
+            self.t = threading.Thread(target=self.work, daemon=True)
             self.t.start()
 
-        def work(self, path):
+        def work(self):
             try:
-                reader = NativeKmerReader(path, samples, block_size)
-                for raw in reader.raw_blocks():
+                if self.open_error is not None:
+                    raise self.open_error
+                for raw in self.reader.raw_blocks():
                     nb = int(raw[0].nbytes) + int(raw[2].nbytes if hasattr(raw[2], "nbytes") else len(raw[2]))
                     while True:
                         with self.lock:
@@ -502,7 +508,15 @@ def iter_packed_blocks_native_multi(p, paths, min_af, max_af, block_size, want_p
                 self.room.release()
                 yield raw
 
-    feeds = [Feed(path) for path in paths]
+    # one look-ahead budget and one pool of parser threads for all the files (round 2 gave every file 2 GB and a full pool: 16 GB and ~380
+    # threads for 8 files under a 16-CPU quota)
+    ahead_bytes = max(64 << 20, int(ahead_bytes) // max(1, len(paths)))
+    from . import _abi
+    _abi.load().sh_reader_set_concurrency(len(paths))
+    try:
+        feeds = [Feed(path) for path in paths]                       # every reader is opened here, under the shared-pool hint
+    finally:
+        _abi.load().sh_reader_set_concurrency(1)
     for f in feeds:
         for bits, counts, blob, off in f.blocks():
             yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
@@ -518,8 +532,13 @@ _PK_MAGIC = b"SEERPK01"
 
 
 class PackedCacheWriter(object):
-    def __init__(self, path, samples):
-        self._f = open(path, "wb")
+    """Writes to `path + ".part"` and renames onto `path` in close(), after the terminator and an fsync: a run that is interrupted or fails
+    leaves no `path` at all (round 2 wrote in place, and a truncated cache with a valid header was accepted by every later run until it
+    died in the middle of its output).  `stamp` = (sidecar path, text): written only once the cache itself is in place."""
+
+    def __init__(self, path, samples, stamp=None):
+        self._path, self._tmp, self._stamp = path, path + ".part", stamp
+        self._f = open(self._tmp, "wb")
         names = "\n".join(samples).encode()
         self._f.write(_PK_MAGIC + np.array([len(samples), row_bytes_for(len(samples))], dtype="<u4").tobytes()
                       + np.array([len(names)], dtype="<u8").tobytes() + names)
@@ -533,10 +552,47 @@ class PackedCacheWriter(object):
         self._f.write(np.ascontiguousarray(bits, dtype=np.uint8).tobytes())
 
     def close(self):
+        import os
         if self._f is not None:
             self._f.write(np.array([0, 0], dtype="<u8").tobytes())
+            self._f.flush()
+            os.fsync(self._f.fileno())
             self._f.close()
             self._f = None
+            os.replace(self._tmp, self._path)
+            if self._stamp is not None:
+                with open(self._stamp[0], "w") as f:
+                    f.write(self._stamp[1] + "\n")
+
+    def abort(self):
+        """Drop what was written (the run did not finish): no cache, no stamp."""
+        import os
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+            try:
+                os.remove(self._tmp)
+            except OSError:
+                pass
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+
+def packed_cache_complete(path):
+    """True if `path` ends with the terminator close() writes (nv = 0, name_bytes = 0): a cheap test that the file was written to its end."""
+    import os
+    try:
+        if os.path.getsize(path) < 8 + 8 + 8 + 16:
+            return False
+        with open(path, "rb") as f:
+            f.seek(-16, 2)
+            return f.read(16) == b"\0" * 16
+    except (IOError, OSError):
+        return False
 
 
 def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False):
@@ -558,14 +614,19 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
                                  % (len(stored), n))
             if int(rb) != row_bytes_for(n):
                 raise IOError("packed cache row width mismatch")
+            def need(nbytes):
+                b = f.read(nbytes)
+                if len(b) != nbytes:
+                    raise IOError("truncated packed cache %s (delete it, or run without --load-packed)" % path)
+                return b
             while True:
-                nv, nb = (int(x) for x in np.frombuffer(f.read(16), dtype="<u8"))
+                nv, nb = (int(x) for x in np.frombuffer(need(16), dtype="<u8"))
                 if nv == 0:
                     return
-                off = np.frombuffer(f.read(8 * (nv + 1)), dtype="<i8")
-                counts = np.frombuffer(f.read(4 * nv), dtype="<i4")
-                blob = f.read(nb)
-                bits = np.frombuffer(f.read(nv * int(rb)), dtype=np.uint8).reshape(nv, int(rb))
+                off = np.frombuffer(need(8 * (nv + 1)), dtype="<i8")
+                counts = np.frombuffer(need(4 * nv), dtype="<i4")
+                blob = need(nb)
+                bits = np.frombuffer(need(nv * int(rb)), dtype=np.uint8).reshape(nv, int(rb))
                 yield blob, off, counts, bits
 
     def merged():

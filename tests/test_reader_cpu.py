@@ -274,3 +274,84 @@ def test_several_files_are_one_stream_in_the_order_given(tmp_path):
         assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
     with pytest.raises(IOError):
         list(iter_packed_blocks_native_multi(p, [paths[0], str(tmp_path / "missing.gz"), paths[4]], 0.01, 0.99, 64))
+
+
+def test_block_larger_than_any_fixed_number_of_slabs_does_not_hang(tmp_path, monkeypatch):
+    """sh_reader_next holds every slab of the block it is cutting, and the producer's buffer pool used to be capped at
+    64: a block spanning more slabs than that left producer and consumer waiting for each other.  Smallest slabs, one block for the whole
+    file (gzip and BGZF-free plain gzip mode both go through get_buf); run in a child process so that a hang fails the test instead of the
+    suite."""
+    import subprocess
+    import sys
+    samples = ["s%d" % i for i in range(300)]
+    rng = np.random.default_rng(5)
+    lines = []
+    for v in range(9000):
+        car = np.flatnonzero(rng.random(300) < 0.5)
+        lines.append("K%06d | %s" % (v, " ".join("s%d:1" % i for i in car)))
+    path = str(tmp_path / "big.gz")
+    with gzip.open(path, "wt", compresslevel=1) as fh:
+        fh.write("\n".join(lines) + "\n")
+    text_bytes = sum(len(x) + 1 for x in lines)
+    assert text_bytes > 80 * 70000                                 # more than 64 of the smallest slabs in ONE block
+    code = ("import sys, numpy as np\n"
+            "from pyseer_amd.input import NativeKmerReader\n"
+            "s = ['s%d' % i for i in range(300)]\n"
+            "n = 0; c = 0\n"
+            "for names, bits, counts in NativeKmerReader(sys.argv[1], s, 10000):\n"
+            "    n += len(names); c += int(counts.sum())\n"
+            "print(n, c)\n")
+    env = dict(os.environ, SEERHIP_READER_SLAB="70000", SEERHIP_READER_PAD="32768",
+               PYTHONPATH=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    out = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n, c = (int(x) for x in out.stdout.split())
+    assert n == 9000 and c == sum(x.count(":1") for x in lines)
+
+
+def test_trailing_garbage_after_the_last_gzip_member_is_an_error_zero_padding_is_not(tmp_path):
+    samples = ["s0", "s1", "s2"]
+    body = gzip.compress(b"AAAA | s0:1 s2:1\nCCCC | s1:1\n")
+    ok = str(tmp_path / "padded.gz"); bad = str(tmp_path / "garbage.gz")
+    open(ok, "wb").write(body + b"\0" * 700)
+    open(bad, "wb").write(body + b"not gzip at all")
+    got = [n for n, b, c in NativeKmerReader(ok, samples, 10)]
+    assert sum(got, []) == ["AAAA", "CCCC"]
+    try:
+        list(NativeKmerReader(bad, samples, 10))
+        raise AssertionError("trailing garbage went unnoticed")
+    except (IOError, OSError, ValueError, RuntimeError) as ex:
+        assert "garbage" in str(ex) or "gzip" in str(ex)
+
+
+def test_packed_cache_is_written_atomically_and_truncation_is_reported(tmp_path):
+    """the cache appears under its name only when close() has written the terminator; an interrupted writer leaves
+    nothing; a truncated file (older version, disk full) is reported as such, not as a reshape error."""
+    from pyseer_amd.input import PackedCacheWriter, iter_packed_blocks_cached, packed_cache_complete, row_bytes_for
+    samples = ["s%d" % i for i in range(20)]
+    p = pd.Series(np.arange(20, dtype=float), index=samples)
+    rb = row_bytes_for(20)
+    path = str(tmp_path / "k.seerpack")
+    stamp = (path + ".stamp", "123 456")
+    w = PackedCacheWriter(path, samples, stamp=stamp)
+    blob = b"AAAACCCC"; off = np.array([0, 4, 8], dtype=np.int64)
+    bits = np.zeros((2, rb), dtype=np.uint8); bits[0, 0] = 3; bits[1, 1] = 1
+    w.write_block(blob, off, np.array([2, 1], dtype=np.int32), bits)
+    assert not os.path.exists(path) and not os.path.exists(stamp[0])       # nothing under the final names yet
+    w.abort()
+    assert not os.path.exists(path) and not os.path.exists(path + ".part") and not os.path.exists(stamp[0])
+    w = PackedCacheWriter(path, samples, stamp=stamp)
+    w.write_block(blob, off, np.array([2, 1], dtype=np.int32), bits)
+    w.close()
+    assert os.path.exists(path) and open(stamp[0]).read().strip() == "123 456" and packed_cache_complete(path)
+    blocks = list(iter_packed_blocks_cached(p, path, 0.0, 1.0, 100))
+    assert sum(len(b.names) for b in blocks) == 2
+    data = open(path, "rb").read()
+    cut = str(tmp_path / "cut.seerpack")
+    open(cut, "wb").write(data[:-30])
+    assert not packed_cache_complete(cut)
+    try:
+        list(iter_packed_blocks_cached(p, cut, 0.0, 1.0, 100))
+        raise AssertionError("truncation went unnoticed")
+    except IOError as ex:
+        assert "truncated" in str(ex)
