@@ -27,9 +27,15 @@ sys.path.insert(0, ROOT)
 N_SAMPLES = 5000
 INT8_DENSE_PEAK_TOPS = 5000.0      # gfx950 int8 MFMA dense (2x the ~2.5 PF bf16 dense peak, MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # gfx950 fp64 vector peak
+# the reference itself on one thread (measured with statsmodels 0.12.2 / numpy in the build container), variants/s at N = 5000
+REFERENCE_PER_CORE = {"logistic": 112.0, "firth": 1.0, "lmm": 303.0}
+GLM_KERNELS = {False: "k_glm_fast<Q,true> (prefilter, routing) + k_glm_bitdot + k_glm_solve32 + k_glm_pass32(_split) + k_glm_score(_split) / k_glm_chord + k_glm_ll + "
+                      "k_glm_dpass_pk + k_glm_finish (+ k_glm_slow_blk and the Firth kernels for routed rows)",
+               True: "k_glm_fast<Q,true> + k_glm_bitdot + k_firth_init2 + rounds of k_firth_eval2 / k_firth_step2 (+ k_firth_step<Q,true> behind the pivot guard, "
+                     "k_firth_blk past the hand-off)"}
 FP64_FLOP_PER_TEST = 5.0e7         # 2*k*N + 6k fp64 flop of the reference formulation, k=4999
 ALGO_BYTES_PER_TEST = 673          # ceil(N/8) in + 48 out
-PROFILE_DIRS = ("r02", "r01")      # committed rocprofv3 summaries, newest first
+PROFILE_DIRS = ("r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -130,8 +136,10 @@ def cpu_baseline_lmm(U, S, y, C, h2, N, block=1000, blocks_per_proc=3):
     return dict(value=r["variants"] / r["seconds"], unit="variants/s", cores=r["procs"], kind="port", host_logical_cpus=os.cpu_count(),
                 sample="%d synthetic k-mers x %d samples: %d worker processes (as pyseer --cpu; = the CPUs this container may use), one BLAS thread each, %d blocks of %d variants "
                        "per worker; fit_lmm_block restated with numpy (oracle/lmm_blas.py): U.T.dot(A) through OpenBLAS dgemm as the reference "
-                       "issues it; %.1f variants/s per core" % (r["variants"], N, r["procs"], blocks_per_proc, r["block"],
-                                                               r["variants"] / r["seconds"] / r["procs"]))
+                       "issues it, rows drawn before the clock starts; %.1f variants/s per core.  The reference itself (fit_lmm_block through "
+                       "numpy, SURVEY.md 3.3): %.0f variants/s on one thread" % (r["variants"], N, r["procs"], blocks_per_proc, r["block"],
+                                                               r["variants"] / r["seconds"] / r["procs"], REFERENCE_PER_CORE["lmm"]),
+                reference_per_core=REFERENCE_PER_CORE["lmm"])
 
 
 def cpu_baseline_glm(y, W, nl, nf, N, force_firth, target_s=12.0):
@@ -158,10 +166,13 @@ def cpu_baseline_glm(y, W, nl, nf, N, force_firth, target_s=12.0):
     while spent < target_s:
         spent += run(per); done += per
     what = "fit_firth on every variant (orc_firth_batch)" if force_firth else "fixed_effects_regression (orc_fixed_effects_batch)"
+    refpc = REFERENCE_PER_CORE["firth" if force_firth else "logistic"]
     return dict(value=done / spent, unit="variants/s", cores=ncores, kind="port",
                 host_logical_cpus=os.cpu_count(),
                 sample="%d synthetic k-mers x %d samples, %d covariates, %s, oracle/seer_oracle.c with OpenMP on %d threads (= the CPUs this "
-                       "container may use)" % (done, N, W.shape[1], what, ncores))
+                       "container may use): a C port, %.0fx faster per core than the reference itself, which runs %s variants/s on one thread "
+                       "(statsmodels / numpy, SURVEY.md 3.3)" % (done, N, W.shape[1], what, ncores, (done / spent / ncores) / refpc, refpc),
+                reference_per_core=refpc)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -194,27 +205,119 @@ def measured_flops(tag):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def fixed_effects_extra(dev, local, N, q=10, V=1 << 18, reps=3):
-    """Secondary numbers printed with the default (C3) line: logistic and Firth-on-everything at N samples; the first-class lines
-    are `--config C2 / C2N5000 / C4`."""
+def glm_roofline(cfg, q, Vs, kern_s, klaunch, rb):
+    """roofline object of a fixed-effects configuration: fp64 lane-flops counted by PMC over one batch (profiles/rNN/flops_<cfg>.json) x variants
+    per step / the HIP-event time of the fit's kernels per step, against the fp64 vector peak; traffic from the committed FETCH/WRITE passes."""
+    force = cfg == "C4"
+    tag = cfg.lower()
+    f64, f32, fsrc = measured_flops(tag)
+    traffic, traffic_src = measured_traffic(tag, Vs)
+    achieved = None if f64 is None else f64 * Vs / kern_s / 1e12
+    return {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": None if achieved is None else achieved / FP64_VECTOR_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "kernel": GLM_KERNELS[force], "kernel_ms": kern_s * 1e3, "launches": klaunch,
+            "ops": "fp64 lane-flops actually executed per variant (PMC: 64 x (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64)) x variants per step "
+                   "/ HIP-event time of those kernels per step; single-precision work (first Newton rounds, the Firth hat diagonal) is reported beside it, not added",
+            "fp64_flops_per_variant": f64, "fp32_flops_per_variant": f32, "flops_source": fsrc,
+            "hbm_algorithmic_GBps": (rb + (5 + q) * 8 + 4) * Vs / kern_s / 1e9}
+
+
+def glm_metric(cfg, N):
+    force = cfg == "C4"
+    return ("k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
+            "f64 (likelihood, information matrix, score) + f32 hat diagonal" if force
+            else "f64 (score, likelihood, final information matrix) + f32 Hessian in the first Newton phase")
+
+
+def glm_workload(cfg, Vs, N, q):
+    what = "Firth-penalised logistic regression on every variant (force_firth)" if cfg == "C4" else "logistic regression (Firth for routed variants)"
+    return {"workload": "%s: %s, %d synthetic k-mers x %d samples per step per GPU, %d covariates, inputs resident in HBM" % (cfg, what, Vs, N, q),
+            "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"}
+
+
+def fixed_effects_line(cfg, dev, local, steps=5, warmup=1, Vs=None, cpu=True, parity=True, env=None):
+    """One fixed-effects configuration measured the way the main line is (HIP events on the launch stream, inputs resident, oracle re-check
+    of the timed output, CPU baseline): the `extra` entries of the default (C3) line, so that the driver's run of `bench.py --gpus 1`
+    carries both halves of BASELINE's metric (LMM and fixed effects at N = 5000).  env: switches read by sh_glm_setup (e.g. the literal
+    Firth step-halving rule)."""
     import torch
     from pyseer_amd.engine import Engine, row_bytes_for
+    N = 1000 if cfg == "C2" else N_SAMPLES
+    q = 10
+    Vs = Vs or ((1 << 20) if cfg == "C2" else (1 << 18))
+    rb = row_bytes_for(N)
     y, W, nl, nf = synth_glm_inputs(N, q)
-    out = {}
-    for name, force in (("logistic", False), ("firth", True)):
+    saved = {}
+    for k, v in (env or {}).items():
+        saved[k] = os.environ.get(k); os.environ[k] = v
+    try:
         eng = Engine(N, device=local); eng.use_torch_stream(); eng.set_af_filter(0.01, 0.99)
-        eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=force)
-        bits = synth_bits(V, N, row_bytes_for(N), 4242, dev)
-        o = torch.empty((5 + q, V), dtype=torch.float64, device=dev); f = torch.empty((V,), dtype=torch.int32, device=dev)
-        eng.glm_batch_dev(bits, o, f); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.glm_batch_dev(bits, o, f)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        out[name] = {"variants_per_s": V / dt, "n_samples": N, "q": q, "variants": V}
-        eng.close()
-    return out
+        eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=(cfg == "C4"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    nb = min(steps + warmup, 4)
+    bits = [synth_bits(Vs, N, rb, 4242 + i, dev) for i in range(nb)]
+    out = torch.empty((5 + q, Vs), dtype=torch.float64, device=dev); fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
+    for i in range(warmup):
+        eng.glm_batch_dev(bits[i % nb], out, fl)
+    torch.cuda.synchronize()
+    eng.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.glm_batch_dev(bits[(warmup + i) % nb], out, fl)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, klaunch = eng.get_timing()
+    kern_s = kms / max(klaunch, 1) * 1e-3
+    metric, dtype = glm_metric(cfg, N)
+    res = {"metric": metric, "value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+           "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), "roofline": glm_roofline(cfg, q, Vs, kern_s, klaunch, rb)}
+    if env:
+        res["env"] = dict(env)
+    if parity:
+        n, devs = parity_glm(y, W, nl, nf, cfg == "C4", bits[(warmup + steps - 1) % nb], out, fl, N)
+        res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
+    eng.close()
+    del bits, out, fl
+    if cpu:
+        res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, cfg == "C4")
+    return res
+
+
+def lmm_variant_line(U, S, y, C, h2, dev, local, bits, steps, limbs=0, tol=None):
+    """The LMM step again with another limb count or refinement tolerance (tol = 1e-300: every variant's bound exceeds it, so every variant is
+    re-contracted with the extra limbs = 56 bits in all, the fp64-equivalent throughput; a tolerance of exactly 0 means "never" in the ABI), on
+    the main line's own rows; oracle re-check of its timed output."""
+    import torch
+    from pyseer_amd.engine import Engine
+    N = U.shape[0]
+    eng = Engine(N, device=local); eng.use_torch_stream()
+    eng.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=1.0, lrt_pvalue=1.0, n_limbs=limbs)
+    if tol is not None:
+        eng.set_lmm_tol(tol)
+    Vs = bits[0].shape[0]
+    out = torch.empty((5, Vs), dtype=torch.float64, device=dev); fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
+    eng.lmm_batch_dev(bits[0], out, fl); torch.cuda.synchronize()
+    eng.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.lmm_batch_dev(bits[i % len(bits)], out, fl)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, klaunch = eng.get_timing()
+    info = eng.lmm_info()
+    kern_s = kms / max(klaunch, 1) * 1e-3
+    n, devs = parity_lmm(U, S, y, C, h2, bits[(steps - 1) % len(bits)], out, N)
+    res = {"value": Vs * steps / dt, "unit": "variants/s", "ms_per_step": dt / steps * 1e3, "n_limbs": info["n_limbs"], "refine_tol": info.get("refine_tol"),
+           "kernel_ms": kern_s * 1e3, "frac_of_int8_peak_main_pass": 2.0 * info["int8_macs_per_variant"] * Vs / kern_s / 1e12 / INT8_DENSE_PEAK_TOPS,
+           "refined_last_batch": info.get("refined_last_batch"), "parity_checked": n, "parity_max_rel_dev": devs}
+    eng.close()
+    return res
 
 
 def rel_dev(got, want, floor=1e-300):
@@ -296,6 +399,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    # how many ranks the collective library really connected (the driver's "did RCCL see N ranks" check): an all-reduce of ones
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == world == dist.get_world_size(), (ranks_seen, world)
 
     from pyseer_amd.engine import Engine, row_bytes_for
     cfg = args.config
@@ -386,7 +497,9 @@ def main():
         kern_s = kms / max(klaunch, 1) * 1e-3
         res = {"value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "data": "synthetic", "world": world, "per_rank_value": per_rank, "finite_fraction": min(fin_all)}
+               "data": "synthetic", "world": world, "rccl_ranks_seen": ranks_seen, "collective_backend": args.backend if world > 1 else None,
+               "per_rank_value": per_rank, "finite_fraction": min(fin_all),
+               "distinct_rows_per_gpu": int(ndist) * int(Vs)}
         if lmm:
             int8_ops = 2.0 * info["int8_macs_per_variant"] * Vs
             achieved = int8_ops / kern_s / 1e12
@@ -405,40 +518,33 @@ def main():
                              "int8_macs_per_variant": info["int8_macs_per_variant"],
                              "fp64_equiv_tflops": FP64_FLOP_PER_TEST * Vs / kern_s / 1e12,
                              "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9},
-                "error_bound": {k: info[k] for k in ("quant_err_norm", "bound_rel_typical", "refined_last_batch") if k in info},
+                "error_bound": {k: info[k] for k in ("quant_err_norm", "quant_err_norm_power_iteration", "quant_err_norm_squarings", "bound_rel_typical",
+                                                     "refined_last_batch") if k in info},
             })
             if not args.no_parity:
                 n, devs = parity_lmm(U, S, y, C, h2, last, out, N)
                 res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
                 assert max(devs.values()) < 1e-6, "timed output deviates from the oracle: %s" % devs
             if world == 1 and not args.no_extra:
-                res["extra"] = {"fixed_effects_N5000": fixed_effects_extra(dev, local, N_SAMPLES),
-                                "fixed_effects_N1000": fixed_effects_extra(dev, local, 1000, V=1 << 20)}
+                # the rest of BASELINE's metric ("LMM and fixed-effects at N = 5000") on the same line: each entry is measured like a main line
+                # (event-timed kernels, counted roofline, oracle re-check, CPU baseline).  C4_literal: the reference's literal step-halving rule.
+                cpu = not args.no_cpu_baseline
+                nb3 = min(3, len(bits))
+                res["extra"] = {
+                    "C2N5000": fixed_effects_line("C2N5000", dev, local, cpu=cpu, parity=not args.no_parity),
+                    "C4": fixed_effects_line("C4", dev, local, cpu=cpu, parity=not args.no_parity),
+                    "C4_literal": fixed_effects_line("C4", dev, local, cpu=False, parity=not args.no_parity, env={"SEERHIP_FIRTH_LITERAL": "1"}),
+                    "C2": fixed_effects_line("C2", dev, local, steps=3, cpu=False, parity=False),
+                    "C3_five_limbs": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=5),
+                    "C3_all_refined_56bit": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=0, tol=1e-300),
+                }
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_lmm(U, S, y, C, h2, N)
         else:
             force = cfg == "C4"
-            tag = cfg.lower()
-            f64, f32, fsrc = measured_flops(tag)
-            traffic, traffic_src = measured_traffic(tag, Vs)
-            achieved = None if f64 is None else f64 * Vs / kern_s / 1e12
-            what = "Firth-penalised logistic regression on every variant (force_firth)" if force else "logistic regression (Firth for routed variants)"
-            res.update({
-                "metric": "k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
-                "dtype": "f64" if force else "f64 (score, likelihood, final information matrix) + f32 Hessian in the first Newton phase",
-                "config": {"workload": "%s: %s, %d synthetic k-mers x %d samples per step per GPU, %d covariates, inputs resident in HBM"
-                                       % (cfg, what, Vs, N, q),
-                           "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"},
-                "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": None if achieved is None else achieved / FP64_VECTOR_PEAK_TFLOPS,
-                             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                             "kernel": "k_firth_init + k_firth_eval/k_firth_step rounds + k_firth_blk" if force else "k_glm_fast + k_glm_slow + k_glm_final",
-                             "kernel_ms": kern_s * 1e3, "launches": klaunch,
-                             "ops": "fp64 lane-flops actually executed per variant (PMC: 64 x (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64)) x variants per step "
-                                    "/ HIP-event time of those kernels per step; fp32 work of the first Newton phase is reported beside it, not added",
-                             "fp64_flops_per_variant": f64, "fp32_flops_per_variant": f32, "flops_source": fsrc,
-                             "hbm_algorithmic_GBps": (rb + (5 + q) * 8 + 4) * Vs / kern_s / 1e9},
-            })
+            metric, dtype = glm_metric(cfg, N)
+            res.update({"metric": metric, "dtype": dtype, "config": glm_workload(cfg, Vs, N, q),
+                        "roofline": glm_roofline(cfg, q, Vs, kern_s, klaunch, rb)})
             if not args.no_parity:
                 n, devs = parity_glm(y, W, nl, nf, force, last, out, fl, N)
                 res["parity_checked"] = n; res["parity_max_rel_dev"] = devs

@@ -106,14 +106,21 @@ int sh_lmm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t
 int sh_lmm_info(sh_ctx *ctx, int *n_limbs, int64_t *int8_macs_per_variant, double *quant_scale);
 /* Accuracy of the fixed-point contraction that replaces the reference's fp64 U.T.dot(A) (pyseer/fastlmm/lmm_cov.py:186-193) and
  * computeAKA (:885-900).  The kernel matrix G is held as n_limbs int8 limbs; the only error of x^T K^-1 x is that quantisation, and for a
- * stored row with m' carriers it is bounded by err_norm * ulp * m', err_norm = spectral norm of the (symmetrised) quantisation error in
- * units of ulp, estimated at set-up by power iteration (x 1.25).  A variant whose relative bound err_norm*ulp*m'/xKx exceeds `tol`
+ * stored row with m' carriers it is bounded by err_norm * ulp * m', err_norm = an upper bound on the spectral norm of the (symmetrised)
+ * quantisation error in units of ulp, certified at set-up (sh_lmm_bound_estimate below).  A variant whose relative bound err_norm*ulp*m'/xKx exceeds `tol`
  * (default 1e-8, sh_set_lmm_tol; 0 = never) is contracted again with `extra_limbs` more limbs (up to 56 bits in all = fp64) inside the
  * same call.  bound_typical: the bound of a variant carried by half of the samples on an unstructured population; bound_max_last /
  * refined_last: the largest final bound and the number of re-contracted variants of the LAST batch (synchronises the stream). */
 int sh_set_lmm_tol(sh_ctx *ctx, double tol);
 int sh_lmm_bound(sh_ctx *ctx, double *err_norm_ulp, double *ulp, double *tol, int *extra_limbs, double *bound_typical,
                  double *bound_max_last, int64_t *refined_last);
+/* err_norm (sh_lmm_bound) is a CERTIFIED upper bound since round 3: |E|_2 <= trace(E^(2p))^(1/(2p)) with 2p = 2^(squarings+1), E^(2p) by repeated
+ * squaring on the fp64 matrix pipe (64th power at n <= 16384: within 4.4 % of the norm for a Wigner-like error matrix).  The power iteration of
+ * rounds 1-2 (which approaches the norm from below and can stall between near-equal or opposite eigenvalues) remains as the estimate reported here.
+ * The reference needs neither: it contracts in fp64 (pyseer/fastlmm/lmm_cov.py:186-193, 885-900). */
+int sh_lmm_bound_estimate(sh_ctx *ctx, double *power_iteration_ulp, int *squarings);
+/* The two norm routines of sh_lmm_setup on a caller-supplied symmetric n x n fp32 matrix (row-major): diagnostic / test entry. */
+int sh_spectral_bound_f32(sh_ctx *ctx, const float *A, int n, int squarings, double *upper, double *power_iteration);
 
 /* ---------------------------------------------------------------------------------------------
  * Fixed effects (replaces pyseer/model.py:202 fixed_effects_regression = a1 prefilter + statsmodels Logit newton /

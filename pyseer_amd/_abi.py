@@ -36,6 +36,8 @@ SIGNATURES = {
     "sh_lmm_share": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sh_set_lmm_tol": (C.c_int, [C.c_void_p, C.c_double]),
     "sh_lmm_bound": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, C.POINTER(C.c_int), c_dp, c_dp, C.POINTER(C.c_int64)]),
+    "sh_lmm_bound_estimate": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
+    "sh_spectral_bound_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, c_dp, c_dp]),
     "sh_glm_setup": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int]),
     "sh_glm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),

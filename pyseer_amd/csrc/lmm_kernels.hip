@@ -11,6 +11,7 @@
 //     xKx = sum_i x_i M_ii + x^T G x,   G = 2*strict_lower(M)             -> the dense contraction (k_lmm_quadform_i8)
 // x is exactly representable in int8, and G is held as L balanced base-256 int8 limbs of a fixed-point number, so the
 // contraction runs on v_mfma_i32_32x32x32_i8 with EXACT int32 accumulation; limbs are recombined in fp64.
+#include <utility>
 #include "common.h"
 #include "lmm_params.h"
 
@@ -775,8 +776,10 @@ extern "C" hipError_t shk_af_compact(hipStream_t st, int which, int64_t V, LmmLi
 
 // M = W diag(sgn) W^T on fp64 MFMA (v_mfma_f64_16x16x4_f64), lower 128x128 tiles only.  W: Np x kp row-major
 // (rows >= N and columns >= k are zero).  Block = 4 waves, each a 64x64 sub-tile (16 MFMA tiles, 64 f64 acc / lane).
+// mirror != 0: the off-diagonal tiles are also written transposed, so that M is the full symmetric matrix (the squaring chain of
+// shk_spectral_bound feeds M back in as W); sgn == nullptr: all signs +1.
 __global__ __launch_bounds__(256) void k_syrk_f64(const double *__restrict__ W, const double *__restrict__ sgn,
-                                                  int Np, int kp, double *__restrict__ M)
+                                                  int Np, int kp, double *__restrict__ M, int mirror = 0)
 {
     // blockIdx.x enumerates (bi >= bj)
     int t = blockIdx.x, bi = 0;
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double *__restrict__ W, 
     const double *Ai = W + (int64_t)(i0 + lr) * kp + lk;
     const double *Bj = W + (int64_t)(j0 + lr) * kp + lk;
     for (int kk = 0; kk < kp; kk += 4) {
-        const double sg = sgn[kk + lk];
+        const double sg = sgn ? sgn[kk + lk] : 1.0;
         double a[4], b[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) { a[x] = Ai[(int64_t)x * 16 * kp + kk] * sg; b[x] = Bj[(int64_t)x * 16 * kp + kk]; }
@@ -809,8 +812,10 @@ __global__ __launch_bounds__(256) void k_syrk_f64(const double *__restrict__ W, 
 #pragma unroll
         for (int y = 0; y < 4; ++y)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
                 M[(int64_t)(i0 + x * 16 + lk + 4 * r) * Np + (j0 + y * 16 + lr)] = acc[x][y][r];
+                if (mirror && bi != bj) M[(int64_t)(j0 + y * 16 + lr) * Np + (i0 + x * 16 + lk + 4 * r)] = acc[x][y][r];
+            }
 }
 
 // max |2 M_ij| over i > j (i, j < N)  ->  *amax (bit pattern of a non-negative double orders like uint64)
@@ -899,6 +904,42 @@ __global__ __launch_bounds__(256) void k_symv_f32(const float *__restrict__ A, i
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) y[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- a CERTIFIED upper bound on the spectral norm of a symmetric matrix: |A|_2 <= trace(A^(2p))^(1/(2p)) ------------------------------
+// (sum of lambda_i^(2p) >= lambda_max^(2p)).  A^(2p) by repeated squaring on the fp64 matrix pipe (k_syrk_f64, A symmetric so A A^T = A^2),
+// trace(A^(2p)) = |A^p|_F^2.  For the Wigner-like spectrum of a quantisation-error matrix the bound exceeds the norm by
+// (N C_p / 4^p)^(1/(2p)) (C_p the Catalan number): 34 % after 3 squarings (p = 8), 12 % after 4, 4.4 % after 5 (p = 32, N = 5000); a
+// spectrum with a few dominant eigenvalues is bounded tighter still.  Unlike the power iteration (which approaches the norm from below and
+// stalls between two near-equal or opposite eigenvalues) it cannot under-estimate: the only inexactness is fp64 rounding in the products
+// (relative N 2^-53 per squaring), covered by the factor the caller applies.
+__global__ __launch_bounds__(256) void k_f32_to_f64_sq(const float *__restrict__ A, int N, int Np, double *__restrict__ X)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Np * Np) return;
+    const int r = (int)(i / Np), c = (int)(i % Np);
+    X[i] = (r < N && c < N) ? (double)A[i] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_frob2(const double *__restrict__ X, int64_t n, double *__restrict__ out)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fma(X[i], X[i], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// X *= 2^e (exact): keeps the squaring chain inside the fp64 range whatever the scale of A
+__global__ __launch_bounds__(256) void k_scale_pow2(double *__restrict__ X, int64_t n, const double *__restrict__ frob2, int *__restrict__ exps, int step)
+{
+    // e = -floor(log2(|X|_F)) recomputed by every thread from the same value: block-uniform and exact
+    int e2; (void)frexp(sqrt(*frob2), &e2);
+    const int e = -(e2 - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) exps[step] = e;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) X[i] = ldexp(X[i], e);
 }
 
 // nrm[it] = |y| ; x = y / |y|     (one block)
@@ -1062,6 +1103,38 @@ hipError_t shk_lmm_build_G(hipStream_t st, const double *W, const double *sgn, i
             hipLaunchKernelGGL(k_pow_norm, dim3(1), dim3(1024), 0, st, py, px, N, nrm, it);
         }
     }
+    return hipGetLastError();
+}
+
+// the power iteration alone (the estimate reported beside the certificate; also sh_spectral_bound_f32)
+hipError_t shk_power_norm(hipStream_t st, const float *A, int N, int Np, double *px, double *py, double *nrm, int npow)
+{
+    hipLaunchKernelGGL(k_pow_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, px, N);
+    for (int it = 0; it < npow; ++it) {
+        hipLaunchKernelGGL(k_symv_f32, dim3((unsigned)N), dim3(256), 0, st, A, N, Np, px, py);
+        hipLaunchKernelGGL(k_pow_norm, dim3(1), dim3(1024), 0, st, py, px, N, nrm, it);
+    }
+    return hipGetLastError();
+}
+
+// Certified bound on |A|_2 for the symmetric N x N matrix A (fp32, row stride Np): nsq squarings.  X, Y: Np x Np doubles of scratch; work: 2 doubles +
+// (nsq + 1) ints on the device.  On return work[1] = |A_scaled^(2^nsq)|_F^2 and the ints hold the power-of-two exponents applied before each
+// squaring; the caller assembles  bound = (work[1])^(1 / 2^(nsq+1)) * 2^(-sum_k e_k / 2^k)  (shk_spectral_bound_value).
+hipError_t shk_spectral_bound(hipStream_t st, const float *A, int N, int Np, double *X, double *Y, int nsq, double *work, int *exps)
+{
+    const int nb = Np / 128;
+    const int64_t n2 = (int64_t)Np * Np;
+    hipLaunchKernelGGL(k_f32_to_f64_sq, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, A, N, Np, X);
+    double *cur = X, *nxt = Y;
+    for (int k = 0; k <= nsq; ++k) {
+        (void)hipMemsetAsync(work, 0, sizeof(double), st);
+        hipLaunchKernelGGL(k_frob2, dim3(1024), dim3(256), 0, st, cur, n2, work);
+        if (k == nsq) break;
+        hipLaunchKernelGGL(k_scale_pow2, dim3(1024), dim3(256), 0, st, cur, n2, work, exps, k);      // |cur|_F in [1, 2)
+        hipLaunchKernelGGL(k_syrk_f64, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, st, cur, (const double *)nullptr, Np, Np, nxt, 1);
+        std::swap(cur, nxt);
+    }
+    (void)hipMemcpyAsync(work + 1, work, sizeof(double), hipMemcpyDeviceToDevice, st);
     return hipGetLastError();
 }
 

@@ -102,9 +102,20 @@ class Engine(object):
         en = C.c_double(); ulp = C.c_double(); tol = C.c_double(); ex = C.c_int(); bt = C.c_double(); bm = C.c_double(); nr = C.c_int64()
         _abi.check(self._lib.sh_lmm_bound(self._h, C.byref(en), C.byref(ulp), C.byref(tol), C.byref(ex), C.byref(bt), C.byref(bm),
                                           C.byref(nr)))
+        est = C.c_double(); sq = C.c_int()
+        _abi.check(self._lib.sh_lmm_bound_estimate(self._h, C.byref(est), C.byref(sq)))
         return dict(n_limbs=nl.value, int8_macs_per_variant=macs.value, quant_scale=qs.value, quant_err_norm=en.value, ulp=ulp.value,
                     refine_tol=tol.value, extra_limbs=ex.value, bound_rel_typical=bt.value, bound_rel_max_last_batch=bm.value,
-                    refined_last_batch=nr.value)
+                    refined_last_batch=nr.value, quant_err_norm_power_iteration=est.value, quant_err_norm_squarings=sq.value)
+
+    def spectral_bound(self, A, squarings=5):
+        """(certified upper bound, power-iteration estimate) of the spectral norm of the symmetric matrix A, by the two device routines
+        sh_lmm_setup applies to the quantisation error (include/seerhip.h sh_spectral_bound_f32)."""
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        up = C.c_double(); pw = C.c_double()
+        _abi.check(self._lib.sh_spectral_bound_f32(self._h, A.ctypes.data_as(C.POINTER(C.c_float)), int(A.shape[0]), int(squarings),
+                                                   C.byref(up), C.byref(pw)))
+        return up.value, pw.value
 
     def set_lmm_tol(self, tol):
         """Relative bound on x^T K^-1 x above which a variant is contracted again with the extra limbs (include/seerhip.h)."""

@@ -48,23 +48,40 @@ class ShardedEngine(object):
         for e in self.engines:
             e.close()
 
-    def _each(self, fn):
+    def _each(self, fn, retry=False):
+        """fn(i, engine) on every context, one host thread each.  retry (the per-batch calls): a shard whose context failed is run once
+        more on a context that succeeded -- shards are independent and every context holds the same per-run state, so the result is the
+        same ("per-GPU shard failure -> re-run that shard"); the failed context is remembered in `failed_shards`.
+        Set-up calls do not retry: their failure is the caller's to see."""
         import threading
-        out = [None] * len(self.engines)
-        err = []
+        n = len(self.engines)
+        out = [None] * n
+        err = [None] * n
 
-        def run(i):
+        def run(i, j):
             try:
-                out[i] = fn(i, self.engines[i])
+                out[i] = fn(i, self.engines[j])
+                err[i] = None
             except BaseException as ex:      # re-raised in the caller's thread
-                err.append(ex)
-        th = [threading.Thread(target=run, args=(i,)) for i in range(len(self.engines))]
+                err[i] = ex
+        th = [threading.Thread(target=run, args=(i, i)) for i in range(n)]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        if err:
-            raise err[0]
+        bad = [i for i in range(n) if err[i] is not None]
+        if bad and retry:
+            good = [i for i in range(n) if err[i] is None]
+            for i in list(bad):
+                if not good:
+                    break
+                first = err[i]
+                self.failed_shards = getattr(self, "failed_shards", []) + [(i, self.devices[i], repr(first))]
+                run(i, good[len(self.failed_shards) % len(good)])
+                if err[i] is None:
+                    bad.remove(i)
+        if bad:
+            raise err[bad[0]]
         return out
 
     def set_af_filter(self, lo, hi):
@@ -84,7 +101,7 @@ class ShardedEngine(object):
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         world = len(self.engines)
         spans = [shard_bounds(bits.shape[0], r, world) for r in range(world)]
-        parts = self._each(lambda i, e: getattr(e, method)(bits[spans[i][0]:spans[i][1]]))
+        parts = self._each(lambda i, e: getattr(e, method)(bits[spans[i][0]:spans[i][1]]), retry=True)
         return {k_: np.concatenate([p[k_] for p in parts], axis=0) for k_ in parts[0]}
 
     def lmm_batch(self, bits):
@@ -104,4 +121,4 @@ class ShardedEngine(object):
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         world = len(self.engines)
         spans = [shard_bounds(bits.shape[0], r, world) for r in range(world)]
-        return np.concatenate(self._each(lambda i, e: e.lineage_batch(bits[spans[i][0]:spans[i][1]])), axis=0)
+        return np.concatenate(self._each(lambda i, e: e.lineage_batch(bits[spans[i][0]:spans[i][1]]), retry=True), axis=0)

@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel(a, b, floor=1e-300):
@@ -120,16 +121,25 @@ def test_c4_forced_firth_bench_inputs_vs_oracle():
     e.glm_setup(y, W, False, nl, nf, force_firth=True)
     r = e.glm_batch(bits)
     e.close()
-    w = orc.firth_batch(y, Kv, W)
+    ws = orc.firth_noise_variants(lambda: orc.firth_batch(y, Kv, W))
+    w = ws[0]
     ok = keep & (w["status"] == 0)
     assert ok.sum() >= 128
-    FA = 3e-7
+    # 1e-6 relative; the absolute slack of the halving test only on rows the tie detector identifies (tests/_firth_tol.py)
+    from _firth_tol import firth_rows_close
+    needed = 0
     for f in ("kbeta", "bse", "intercept"):
-        assert np.allclose(r[f][ok], w[f][ok], rtol=1e-6, atol=FA), (f, rel(r[f][ok], w[f][ok]))
-    assert np.allclose(r["betas"][ok], w["betas"][ok], rtol=1e-6, atol=FA)
+        good, nt = firth_rows_close(r[f], ws, f, ok)
+        needed += nt
+        assert good.all(), (f, rel(r[f][ok], w[f][ok]))
+    for j in range(q):
+        good, nt = firth_rows_close(r["betas"][:, j], [dict(b=v["betas"][:, j]) for v in ws], "b", ok)
+        needed += nt
+        assert good.all(), ("betas", j)
     lr = -2.0 * (nf - w["fitll"][ok])
     wp = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
-    assert np.allclose(r["pvalue"][ok], wp, rtol=2e-6, atol=1e-300), rel(r["pvalue"][ok], wp)
+    assert np.allclose(r["pvalue"][ok], wp, rtol=1e-6, atol=1e-300), rel(r["pvalue"][ok], wp)
+    print("C4 inputs: %d statistic values needed the tie detector" % needed)
     assert (((r["flags"][ok] >> 6) & 1) == 0).all()               # no firth-fail where the reference converges
     print("C4 inputs: max rel dev kbeta %.2e bse %.2e p %.2e on %d variants" % (
         rel(r["kbeta"][ok], w["kbeta"][ok]), rel(r["bse"][ok], w["bse"][ok]), rel(r["pvalue"][ok], wp), ok.sum()))
@@ -150,12 +160,21 @@ def test_c2n5000_logistic_bench_inputs_vs_oracle():
     e.glm_setup(y, W, False, nl, nf)
     r = e.glm_batch(bits)
     e.close()
-    w = orc.fixed_effects_batch(y, Kv[keep], W, False, 1.0, 1.0, nl, nf)
+    ws = orc.firth_noise_variants(lambda: orc.fixed_effects_batch(y, Kv[keep], W, False, 1.0, 1.0, nl, nf))
+    w = ws[0]
     firth = (w["notes"] & 0x7C) != 0
+    from _firth_tol import firth_rows_close
+    needed = 0
     for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
         g = r[f][keep]
         assert np.allclose(g[~firth], w[f][~firth], rtol=1e-6, atol=1e-300, equal_nan=True), f
-        assert np.allclose(g[firth], w[f][firth], rtol=2e-6, atol=1e-6 if f != "pvalue" else 1e-300, equal_nan=True), f
+        if f == "prep":
+            assert np.allclose(g[firth], w[f][firth], rtol=1e-6, atol=1e-300, equal_nan=True), f
+            continue
+        good, nt = firth_rows_close(g, ws, f, firth)                # Firth-routed rows: 1e-6 relative, slack only where the tie detector fires
+        needed += nt
+        assert good.all(), (f, np.argwhere(~good)[:4].tolist())
+    print("C2N5000 inputs: %d Firth-routed rows, %d statistic values needed the tie detector" % (int(firth.sum()), needed))
     assert ((r["flags"][keep] & 0x1FF) == w["notes"]).all()
     assert (r["flags"][~keep] & 1).all()                           # af-filter note outside the window
 
@@ -211,6 +230,30 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d["parity_checked"] == 64 and max(d["parity_max_rel_dev"].values()) < 1e-9
     assert abs(d["value"] - 2 * 65536 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                                  # N = 1 only
+    assert d["rccl_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
+
+
+def test_bench_one_rank_under_torchrun_equals_the_plain_launch():
+    """`python bench.py --gpus 1` and the same under `torch.distributed.run --nproc-per-node 1` (how the driver launches every N) measure the
+    same thing: kernel time per launch within 3 %, whole-job value within 6 % (one process start, one box; the value also holds the host's
+    launch overhead)."""
+    import json
+    import subprocess
+    env = dict(os.environ); env["PYTHONPATH"] = ROOT
+    tail = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--variants-per-step", "262144", "--no-extra", "--no-cpu-baseline"]
+    out = []
+    for head in ([sys.executable, os.path.join(ROOT, "bench.py")],
+                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                  "--master-port", "29519", os.path.join(ROOT, "bench.py")]):
+        r = subprocess.run(head + tail, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = out
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["rccl_ranks_seen"] == b["rccl_ranks_seen"] == 1
+    ka, kb = a["roofline"]["kernel_ms"], b["roofline"]["kernel_ms"]
+    print("plain %.3g variants/s (kernel %.2f ms), under torchrun %.3g (%.2f ms)" % (a["value"], ka, b["value"], kb))
+    assert abs(ka - kb) <= 0.03 * ka, (ka, kb)
+    assert abs(a["value"] - b["value"]) <= 0.06 * a["value"], (a["value"], b["value"])
 
 
 def test_automatic_limb_count_follows_the_tolerance(c3, monkeypatch):
@@ -232,3 +275,11 @@ def test_automatic_limb_count_follows_the_tolerance(c3, monkeypatch):
     assert b["n_limbs"] == 5 and b["bound_rel_typical"] <= 0.25e-10 * 1.0001, b
     assert limbs(SEERHIP_LMM_TOL="0")["n_limbs"] == 5            # no extra-limb pass: nothing would catch a variant over the bound
     assert limbs(n_limbs=6)["n_limbs"] == 6 and limbs(SEERHIP_LMM_LIMBS="5")["n_limbs"] == 5
+
+
+def test_lmm_setup_reports_a_certificate_above_the_power_iteration(c3):
+    from pyseer_amd.engine import Engine
+    e = Engine(c3["N"]); e.lmm_setup(c3["U"], c3["S"], c3["y"], c3["C"], c3["h2"]); info = e.lmm_info(); e.close()
+    assert info["quant_err_norm_squarings"] == 5
+    assert info["quant_err_norm"] >= info["quant_err_norm_power_iteration"] > 0
+    assert info["quant_err_norm"] <= 1.15 * info["quant_err_norm_power_iteration"]       # 4.4 % above the norm for a Wigner-like spectrum

@@ -93,7 +93,7 @@ def test_the_three_firth_modes_differ_only_where_documented(monkeypatch):
     log per sample, the reference's start vector).  Statistics agree to the noise floor of the halving test (3e-7 absolute) wherever two
     modes both converge; the only flag that may differ is firth-fail (with the filter bits that follow it); the default mode never fails
     where a literal mode converges -- a literal-mode failure on such a row is the reference's spurious step_limit exhaustion, which depends
-    on the last bit of F and therefore on the evaluation order (profiles/r03/firth_modes_vs_oracle.json)."""
+    on the last bit of F and therefore on the evaluation order (profiles/r03/firth_modes_vs_reference_restatement.json)."""
     from pyseer_amd.model import fit_null
     rng = np.random.default_rng(44)
     N, q, V = 700, 6, 2048

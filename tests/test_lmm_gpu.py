@@ -56,7 +56,7 @@ def test_lmm_reference_unit_pins(engine_mod):
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "lmm_N*.npz"))))
-@pytest.mark.parametrize("limbs", [5, 6])
+@pytest.mark.parametrize("limbs", [0, 4, 5, 6])          # 0 = the automatic count (what ships and what the bench times); 4 = its usual choice
 def test_lmm_golden_blocks(engine_mod, path, limbs):
     Engine, pack = engine_mod
     d = np.load(path)
@@ -595,3 +595,34 @@ def test_sharded_engine_across_real_devices(engine_mod):
     got = s.lmm_batch(bits); s.close()
     for k in want:
         assert np.array_equal(got[k], want[k], equal_nan=True), k
+
+
+def test_spectral_norm_certificate_cannot_underestimate():
+    """sh_lmm_setup bounds the quantisation error's spectral norm by trace(E^64)^(1/64) (repeated squaring on the fp64 matrix pipe).  On
+    matrices with known spectra -- including the two cases a power iteration is bad at: two near-equal top eigenvalues, and a top pair of
+    opposite sign (the iterate oscillates between the two eigenvectors) -- the certificate is never below the true norm and within the
+    factor its derivation gives ((n C_32 / 4^32)^(1/64) at worst); the 48-step power iteration (the round-2 estimate) does fall short."""
+    from pyseer_amd.engine import Engine
+    rng = np.random.default_rng(7)
+    n = 700
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    e = Engine(300)
+    worst_power = 1.0
+    for name, lam in (("wigner", None),
+                      ("near-equal top pair", np.concatenate([[1.0, 0.9995], rng.uniform(-0.6, 0.6, n - 2)])),
+                      ("opposite top pair", np.concatenate([[1.0, -1.0], rng.uniform(-0.3, 0.3, n - 2)])),
+                      ("slowly decaying", 1.0 / (1.0 + 0.002 * np.arange(n)) * np.where(np.arange(n) % 2, -1.0, 1.0))):
+        if lam is None:
+            A = rng.uniform(-0.25, 0.25, (n, n)); A = np.tril(A, -1); A = A + A.T        # the shape of a quantisation-error matrix
+        else:
+            A = (Q * lam) @ Q.T
+        A = ((A + A.T) / 2).astype(np.float32)
+        true = float(np.abs(np.linalg.eigvalsh(A.astype(np.float64))).max())
+        up, pw = e.spectral_bound(A, squarings=5)
+        worst_power = min(worst_power, pw / true)
+        print("%-20s true %.6g  certificate %.6g (x%.4f)  power iteration %.6g (x%.4f)" % (name, true, up, up / true, pw, pw / true))
+        assert up >= true * (1.0 - 1e-9), (name, up, true)
+        assert up <= true * float(n) ** (1.0 / 64) * 1.001, (name, up, true)             # trace(A^64) <= n |A|^64
+    e.close()
+    assert worst_power < 0.999                                                           # what the certificate is for
+

@@ -53,3 +53,36 @@ def test_two_rank_gloo_shard_and_gather():
         assert p.exitcode == 0
     assert np.array_equal(allr, want)
     assert cnt.tolist() == [101, nbig, 0, 2]
+
+
+def test_a_failed_shard_is_rerun_on_another_context():
+    """shards are independent, every context holds the same per-run state -> a shard whose context fails is run once more
+    on a healthy one and the batch comes back complete and in order; a shard that fails twice raises.  (Stub engines: no GPU here.)"""
+    import numpy as np
+    import pytest
+    from pyseer_amd.parallel import ShardedEngine
+
+    class Stub(object):
+        def __init__(self, fail_times):
+            self.fail_times, self.calls = fail_times, 0
+
+        def lmm_batch(self, bits):
+            self.calls += 1
+            if self.fail_times > 0:
+                self.fail_times -= 1
+                raise RuntimeError("device lost")
+            return {"beta": bits[:, 0].astype(float) * 2.0, "flags": np.zeros(bits.shape[0], dtype=np.uint32)}
+
+    se = object.__new__(ShardedEngine)
+    se.devices = [0, 1, 2]
+    se.engines = [Stub(0), Stub(1), Stub(0)]
+    bits = np.arange(10, dtype=np.uint8).reshape(10, 1).repeat(8, axis=1)
+    r = se.lmm_batch(bits)
+    assert np.array_equal(r["beta"], np.arange(10) * 2.0)                   # complete, in input order
+    assert len(se.failed_shards) == 1 and se.failed_shards[0][0] == 1
+    assert se.engines[1].calls == 1 and se.engines[0].calls + se.engines[2].calls == 3
+    r = se.lmm_batch(bits)                                                  # the context recovered: nothing to retry
+    assert np.array_equal(r["beta"], np.arange(10) * 2.0) and len(se.failed_shards) == 1
+    se.engines = [Stub(5), Stub(5)]; se.devices = [0, 1]
+    with pytest.raises(RuntimeError):
+        se.lmm_batch(bits)

@@ -43,4 +43,4 @@ for mode, env in (("noise", {}), ("literal", {"SEERHIP_FIRTH_LITERAL": "1"}), ("
                  "variants_per_s": V / dt}
 print(json.dumps(res, indent=1))
 d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r03"); os.makedirs(d, exist_ok=True)
-json.dump(res, open(os.path.join(d, "firth_modes_vs_oracle.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(d, "firth_modes_vs_reference_restatement.json"), "w"), indent=1)
