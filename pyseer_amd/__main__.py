@@ -95,6 +95,8 @@ def get_options(argv=None):
                     help='Parse k-mer files with the Python reader instead of the native C++ one')
     ot.add_argument('--python-sink', action='store_true', default=False,
                     help='Format every output row in Python (one result tuple per variant) instead of the native block sink')
+    ot.add_argument('--serial-sink', action='store_true', default=False,
+                    help='Format and write each block before the next one is tested [Default: on a worker thread, while the next block is on the GPU]')
     ot.add_argument('--lmm-lineage-per-variant', action='store_true', default=False,
                     help='With --lmm --lineage, fit the lineage effect of each variant itself. [Default: reproduce the reference, '
                          'which fits the LAST variant of each block for every variant of that block]')
@@ -251,6 +253,10 @@ def main(argv=None):
         _die('Several --kmers files need the native reader and cannot be combined with a packed cache\n')
     var_type, var_file = ("kmers", kmer_files[0]) if kmer_files else ("Rtab", options.pres)
     native = (var_type == "kmers") and not options.python_reader
+    if native or options.load_packed:
+        # blocks of the native reader / the packed cache hand every parsed row to the engine (input.py _block_from_raw): the AF window is applied
+        # on the device as well, so filtered rows are neither copied out on the host nor contracted on the GPU
+        eng.set_af_filter(options.min_af, options.max_af)
     if native and not options.uncompressed and not options.load_packed:
         for vf in (kmer_files or [var_file]):
             with open(vf, "rb") as fh:                     # the reference's gzip.open raises on plain text (input.py:271-276)
@@ -356,29 +362,48 @@ def main(argv=None):
     NOTE_AF, NOTE_FIRTH_FAIL = 1, 1 << 6
     q_out = 0
 
+    import time as _time
+    cli_timing = os.environ.get("SEERHIP_CLI_TIMING") is not None
+    tm = {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter()}
+
     def sink_block(blk, r):
         nonlocal prefilter, tested, printed
+        t_in = _time.perf_counter()
         nb = len(blk)
-        status = np.asarray(blk.status, dtype=np.int64)
+        status = np.asarray(blk.status)
         on = status == 0
-        j = np.asarray(blk.row_of, dtype=np.int64)[on]
+        row_of = np.asarray(blk.row_of, dtype=np.int64)
+        # blocks of the native reader / the packed cache: one engine row per variant, in place (row_of = 0, 1, 2, ...): whole-array selects
+        # instead of gathers through an index
+        ident = r is not None and isinstance(blk.row_of, np.ndarray) and nb == r["flags"].shape[0]
+        j = None if ident else row_of[on]
         flags = np.zeros(nb, dtype=np.uint32)
         flags[status == 1] = NOTE_AF | FLAG_PREFILTER
         keys = ("prep", "pvalue", "beta", "bse", "frac_h2") if options.lmm else ("prep", "pvalue", "kbeta", "bse", "intercept")
         cols = [np.asarray(blk.afs, dtype=np.float64)]
         for kname in keys:
-            c = np.full(nb, np.nan)
-            if r is not None:
-                c[on] = r[kname][j]
+            if ident:
+                c = np.where(on, r[kname], np.nan)
+            else:
+                c = np.full(nb, np.nan)
+                if r is not None:
+                    c[on] = r[kname][j]
             cols.append(c)
         betas = valid = None
         if r is not None:
-            flags[on] = r["flags"][j]
+            if ident:
+                flags = np.where(on, r["flags"], flags)
+            else:
+                flags[on] = r["flags"][j]
             if not options.lmm and r["betas"].shape[1]:
-                betas = np.full((nb, r["betas"].shape[1]), np.nan)
-                betas[on] = r["betas"][j]
-                valid = np.zeros(nb, dtype=np.uint8)
-                valid[on] = np.isfinite(r["kbeta"][j]) | np.isfinite(r["pvalue"][j])
+                if ident:
+                    betas = np.where(on[:, None], r["betas"], np.nan)
+                    valid = (on & (np.isfinite(r["kbeta"]) | np.isfinite(r["pvalue"]))).astype(np.uint8)
+                else:
+                    betas = np.full((nb, r["betas"].shape[1]), np.nan)
+                    betas[on] = r["betas"][j]
+                    valid = np.zeros(nb, dtype=np.uint8)
+                    valid[on] = np.isfinite(r["kbeta"][j]) | np.isfinite(r["pvalue"][j])
         pf = (flags & FLAG_PREFILTER) != 0
         ft = (flags & FLAG_FILTER) != 0
         lineage = None
@@ -393,7 +418,7 @@ def main(argv=None):
             else:
                 need = on & ~pf & (~ft if options.lmm else ((flags & NOTE_FIRTH_FAIL) == 0))
                 if need.any():
-                    lineage[need] = eng.lineage_batch(blk.bits[np.asarray(blk.row_of, dtype=np.int64)[need]])
+                    lineage[need] = eng.lineage_batch(blk.bits[row_of[need]])
         order = np.arange(nb)
         if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
             order = np.concatenate([order[pf], order[~pf]])
@@ -407,21 +432,70 @@ def main(argv=None):
         printed += int(sel.shape[0])
         if sel.shape[0]:
             blob, off = (blk.names_blob, blk.name_off) if getattr(blk, "names_blob", None) is not None else names_blob(blk.names)
-            text = formatter.format(blob, off, sel, cols, flags, betas, valid, lineage)
+            text = formatter.format_view(blob, off, sel, cols, flags, betas, valid, lineage)
+            t_w = _time.perf_counter()
             if hasattr(sys.stdout, "buffer"):
                 sys.stdout.flush()
                 sys.stdout.buffer.write(text)
             else:
-                sys.stdout.write(text.decode())
+                sys.stdout.write(bytes(text).decode())
+            tm["write"] += _time.perf_counter() - t_w
+        tm["sink"] += _time.perf_counter() - t_in
+
+    # Three stages run at once (round 3): the block reader (its own thread, `prefetched`), the engine call of block k on this thread (a ctypes
+    # call: the GIL is released while the rows go to the GPU and the statistics come back), and the sink of block k-1 on a worker thread
+    # (NaN masking, counters, native formatter, the write to stdout -- the reference does all of this per variant between two fits,
+    # pyseer/__main__.py:805-827).  One worker and a FIFO of depth 2: the output order is the input order.  The tuple path below (missing
+    # calls, --print-samples, --python-sink) and the lineage fits (a second engine call on the same context) stay on this thread, after the
+    # worker has drained.
+    import queue
+    import threading
+    sink_q = queue.Queue(maxsize=2)
+    sink_err = []
+    overlap = not options.lineage and not options.python_sink and not options.print_samples and not options.serial_sink
+
+    def sink_worker():
+        while True:
+            item = sink_q.get()
+            try:
+                if item is None:
+                    return
+                if not sink_err:
+                    blk_, r_ = item
+                    sink_block(blk_, mask_like_fit_lmm(r_) if (options.lmm and r_ is not None) else r_)
+            except BaseException as ex:          # re-raised on the main thread
+                sink_err.append(ex)
+            finally:
+                sink_q.task_done()
+    sink_thread = None
+    if overlap:
+        sink_thread = threading.Thread(target=sink_worker, daemon=True)
+        sink_thread.start()
+
+    def drain_sink():
+        if sink_thread is not None:
+            sink_q.join()
+        if sink_err:
+            raise sink_err[0]
 
     for blk in blocks:
+        t_e = _time.perf_counter()
         if options.lmm:
-            r = mask_like_fit_lmm(eng.lmm_batch(blk.bits)) if blk.bits.shape[0] else None
+            r = eng.lmm_batch(blk.bits) if blk.bits.shape[0] else None
         else:
             r = eng.glm_batch(blk.bits) if blk.bits.shape[0] else None
+        tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
         if not options.python_sink and not options.print_samples and 2 not in blk.status:
-            sink_block(blk, r)
+            if overlap:
+                if sink_err:
+                    raise sink_err[0]
+                sink_q.put((blk, r))
+            else:
+                sink_block(blk, mask_like_fit_lmm(r) if (options.lmm and r is not None) else r)
             continue
+        drain_sink()
+        if options.lmm and r is not None:
+            r = mask_like_fit_lmm(r)
         rows = []
         for i, name in enumerate(blk.names):
             st, af, ks, nks = blk.status[i], blk.afs[i], blk.kstrains[i], blk.nkstrains[i]
@@ -487,6 +561,17 @@ def main(argv=None):
         for x in rows:
             emit(x)
 
+    drain_sink()
+    if sink_thread is not None:
+        sink_q.put(None)
+        sink_thread.join()
+    if cli_timing:
+        loop = _time.perf_counter() - tm["t0"]
+        nrows = prefilter + tested
+        sys.stderr.write("[cli timing] %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; engine calls (H2D + GPU + D2H) %.2f s, sink (masking, "
+                         "counters, formatting, write) %.2f s of which write %.2f s; sink %s\n"
+                         % (tm["blocks"], nrows, loop, nrows / max(loop, 1e-9), tm["engine"], tm["sink"], tm["write"],
+                            "on a worker thread" if overlap else "serial"))
     if patterns is not None:
         patterns.close()
     if cache_out is not None:

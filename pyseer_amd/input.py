@@ -8,6 +8,7 @@ into packed bit rows.  VCF input needs pysam (absent here) and is not supported.
 import binascii
 import gzip
 import hashlib
+import os
 import sys
 
 import numpy as np
@@ -414,12 +415,16 @@ def _block_from_raw(n, samples, order, names, blob, off, bits, counts, min_af, m
     afs = counts.astype(np.float64) / n
     keep = (afs >= min_af) & (afs <= max_af)
     blk.names = names                                    # None = decode lazily from the blob
-    blk.afs = afs.tolist()
-    blk.status = np.where(keep, 0, 1).tolist()
-    blk.row_of = np.where(keep, np.cumsum(keep) - 1, -1).tolist()
+    # arrays, not lists (round 3: 262 144-element .tolist() calls and their np.asarray() twins in the sink were a third of a block's
+    # host time), and EVERY row goes to the engine in place: no compacted copy of the kept rows (170 MB per block at N = 5000).  The
+    # driver sets the engine's own AF window (sh_set_af_filter: same inclusive bounds on count / n, input.py:608), so rows outside it
+    # cost the GPU nothing; their statistics are masked by `status` in the sink either way.
+    blk.afs = afs
+    blk.status = np.where(keep, 0, 1).astype(np.int8)
     nv = int(counts.shape[0])
+    blk.row_of = np.arange(nv, dtype=np.int64)
     blk.ks = [None] * nv
-    blk.bits = bits if keep.all() else np.ascontiguousarray(bits[keep])
+    blk.bits = bits
     if want_samples:
         sp = [strains_from_bits(bits[i], order, samples) for i in range(nv)]
         blk.kstrains = [a for a, _ in sp]; blk.nkstrains = [b for _, b in sp]
@@ -603,31 +608,51 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
     n = len(samples)
 
     def raw_blocks():
+        # The cache is memory-mapped and a block's bit rows are a VIEW into the mapping (round 3: f.read() of a 170 MB block was a 40 ms copy
+        # per block, more than the GPU needs to test it): the engine's host-to-device copy reads the page cache directly.
+        import mmap
         with open(path, "rb") as f:
-            if f.read(8) != _PK_MAGIC:
+            size = os.fstat(f.fileno()).st_size
+            if size < 24:
                 raise IOError("%s is not a packed k-mer cache" % path)
-            ns, rb = np.frombuffer(f.read(8), dtype="<u4")
-            (ln,) = np.frombuffer(f.read(8), dtype="<u8")
-            stored = f.read(int(ln)).decode().split("\n")
-            if stored != samples:
-                raise ValueError("packed cache was written for a different sample list / order (%d vs %d samples)"
-                                 % (len(stored), n))
-            if int(rb) != row_bytes_for(n):
-                raise IOError("packed cache row width mismatch")
-            def need(nbytes):
-                b = f.read(nbytes)
-                if len(b) != nbytes:
-                    raise IOError("truncated packed cache %s (delete it, or run without --load-packed)" % path)
-                return b
-            while True:
-                nv, nb = (int(x) for x in np.frombuffer(need(16), dtype="<u8"))
-                if nv == 0:
-                    return
-                off = np.frombuffer(need(8 * (nv + 1)), dtype="<i8")
-                counts = np.frombuffer(need(4 * nv), dtype="<i4")
-                blob = need(nb)
-                bits = np.frombuffer(need(nv * int(rb)), dtype=np.uint8).reshape(nv, int(rb))
-                yield blob, off, counts, bits
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        try:
+            mm.madvise(mmap.MADV_SEQUENTIAL)
+        except (AttributeError, OSError):
+            pass
+        if mm[:8] != _PK_MAGIC:
+            raise IOError("%s is not a packed k-mer cache" % path)
+        ns, rb = np.frombuffer(mm, dtype="<u4", count=2, offset=8)
+        (ln,) = np.frombuffer(mm, dtype="<u8", count=1, offset=16)
+        pos = 24 + int(ln)
+        if pos > size:
+            raise IOError("truncated packed cache %s (delete it, or run without --load-packed)" % path)
+        stored = mm[24:pos].decode().split("\n")
+        if stored != samples:
+            raise ValueError("packed cache was written for a different sample list / order (%d vs %d samples)"
+                             % (len(stored), n))
+        if int(rb) != row_bytes_for(n):
+            raise IOError("packed cache row width mismatch")
+        rb = int(rb)
+
+        def need(nbytes):
+            nonlocal pos
+            if pos + nbytes > size:
+                raise IOError("truncated packed cache %s (delete it, or run without --load-packed)" % path)
+            at = pos
+            pos += nbytes
+            return at
+        while True:
+            at = need(16)
+            nv, nb = (int(x) for x in np.frombuffer(mm, dtype="<u8", count=2, offset=at))
+            if nv == 0:
+                return
+            off = np.frombuffer(mm, dtype="<i8", count=nv + 1, offset=need(8 * (nv + 1)))
+            counts = np.frombuffer(mm, dtype="<i4", count=nv, offset=need(4 * nv))
+            at = need(nb)
+            blob = mm[at:at + nb]
+            bits = np.frombuffer(mm, dtype=np.uint8, count=nv * rb, offset=need(nv * rb)).reshape(nv, rb)
+            yield blob, off, counts, bits
 
     def merged():
         acc, rows = [], 0

@@ -29,6 +29,11 @@ class RowFormatter(object):
 
     def format(self, blob, off, sel, cols, flags, betas=None, betas_valid=None, lineage=None):
         """cols: list of float64 arrays (one value per variant of the block); sel: int64 row order to print -> bytes."""
+        return bytes(self.format_view(blob, off, sel, cols, flags, betas, betas_valid, lineage))
+
+    def format_view(self, blob, off, sel, cols, flags, betas=None, betas_valid=None, lineage=None):
+        """As format(), but returns a view of the formatter's own buffer, valid until the next call: the driver writes it out at once, so the
+        text is never copied into a Python bytes object (23 MB per 262 144-row block)."""
         sel = np.ascontiguousarray(sel, dtype=np.int64)
         if sel.shape[0] == 0:
             return b''
@@ -54,7 +59,7 @@ class RowFormatter(object):
                                          sel.shape[0], cp, len(cols), bp, q, vp, lp, self._labels, self._nlab,
                                          flags.ctypes.data_as(_abi.c_u32p), self._buf, len(self._buf))
             if n >= 0:
-                return self._buf.raw[:n]
+                return memoryview(self._buf)[:n]
             if n == -1:
                 raise ValueError("sh_format_rows: bad arguments")
             self._buf = C.create_string_buffer(int(-n) + (1 << 16))

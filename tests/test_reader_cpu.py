@@ -25,8 +25,12 @@ def test_native_equals_python_on_reference_kmers():
     py = list(iter_packed_blocks(p, "kmers", fh, set(p.index), [], 0.01, 0.99, 0.05, False, 37))
     assert len(nat) == len(py) and sum(len(b.names) for b in nat) == 200
     for a, b in zip(nat, py):
-        assert a.names == b.names and a.status == b.status and a.row_of == b.row_of
-        assert np.array_equal(a.bits, b.bits) and np.allclose(a.afs, b.afs)
+        # the native path keeps arrays and hands every parsed row over in place (the engine applies the AF window itself); the Python
+        # restatement compacts the kept rows as the reference's iter_variants drops the filtered ones
+        assert a.names == b.names and list(a.status) == list(b.status)
+        kept = np.asarray(a.status) == 0
+        assert np.array_equal(np.asarray(a.bits)[np.asarray(a.row_of)[kept]], np.asarray(b.bits)[np.asarray(b.row_of, dtype=np.int64)[kept]])
+        assert np.allclose(a.afs, b.afs)
         assert a.patterns == b.patterns and a.kstrains == b.kstrains and a.nkstrains == b.nkstrains
         assert np.array_equal(a.last_k, np.asarray(b.last_k))
 

@@ -67,3 +67,25 @@ def test_small_buffer_is_regrown():
     f = RowFormatter(); f._buf = C.create_string_buffer(16)
     out = f.format(blob, off, np.arange(50), [np.zeros(50)], np.zeros(50, dtype=np.uint32))
     assert out.count(b"\n") == 50 and out.startswith(b"x" * 300 + b"\t0.00E+00\t\n")
+
+
+def test_native_number_format_equals_printf_on_a_sweep():
+    """The sink formats numbers without printf since round 3 (csrc/writer.cpp put_num: scale to [100, 1000) in 80-bit arithmetic, round,
+    leave every near-tie to snprintf).  '%.2E' % x is the reference's own formatting (pyseer/utils.py:60-75): random bit patterns, p-value
+    like magnitudes down to 1e-300, and the exact x.xx5 ties of short decimals must all agree."""
+    from pyseer_amd.sink import RowFormatter, names_blob
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 2 ** 63, 120000, dtype=np.int64).view(np.float64) * rng.choice([-1.0, 1.0], 120000)
+    raw = raw[np.isfinite(raw)]
+    mags = 10.0 ** (-300 * rng.random(60000)) * rng.choice([-1.0, 1.0], 60000)
+    ties = np.array([(m + 0.5) * 10.0 ** (e - 2) for m in range(100, 1000, 7) for e in range(-12, 13)])
+    ties = np.concatenate([ties, np.nextafter(ties, 0), np.nextafter(ties, np.inf)])
+    special = np.array([0.0, -0.0, 1.125, 1.135, 9.995, 999.5, 99.95, 0.125, 5e-324, 1.7976931348623157e308, 2.2250738585072014e-308, 1e22, 1e23, 1e-23])
+    x = np.concatenate([raw, mags, ties, special])
+    n = x.shape[0]
+    blob, off = names_blob(["v"] * n)
+    txt = RowFormatter().format(blob, off, np.arange(n), [x], np.zeros(n, dtype=np.uint32)).decode().split("\n")
+    got = [t.split("\t")[1] for t in txt[:n]]
+    want = ["%.2E" % v for v in x]
+    bad = [(v, g, w) for v, g, w in zip(x, got, want) if g != w]
+    assert not bad, bad[:5]
