@@ -21,7 +21,6 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 // pipe_zero (glm_device.h) that stays where it is written: the plain form has no side effects and may be hoisted to the load it reads from
-__device__ __forceinline__ int pipe_zero_after(double x, double after) { int z; asm volatile("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x)), "v"(after) : "scc"); return z; }
 __device__ __forceinline__ int pipe_zero_v(double x) { int z; asm volatile("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x)) : "scc"); return z; }
 __device__ __forceinline__ v2f pkfma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 

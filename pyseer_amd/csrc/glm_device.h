@@ -140,6 +140,16 @@ __device__ __forceinline__ void xw_bcast(const XWave &x, double (&a)[NA], bool &
 // through, computed from one of A's SGPRs: added to B's index, it orders B's loads behind A's arrival and keeps them scalar.
 // (s_and_b32 writes SCC: declared, or a compare scheduled across the asm loses its result)
 __device__ __forceinline__ int pipe_zero(double x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x)) : "scc"); return z; }
+// pipe_zero that stays BEHIND a piece of arithmetic: the plain form has no side effects, and the scheduler may hoist it up to the load it
+// reads from -- the wait it was meant to place late then sits right behind the load.  `after` is an unused vector operand: a result of the
+// arithmetic the fence has to follow.  Being volatile it also takes the "never clobbered" property from the kernel's global loads, so the
+// records it orders must be read through the constant address space (firth_rounds.hip) or they turn into per-lane vector loads.  Tried on
+// k_glm_pass32 / k_glm_dpass_pk / k_glm_score / k_glm_ll in round 3: no measurable change (3.150 vs 3.145 ms), those kernels are not
+// waiting for their records; not kept there.
+__device__ __forceinline__ int pipe_zero_after(double x, double after)
+{
+    int z; asm volatile("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__double2loint(x)), "v"(after) : "scc"); return z;
+}
 __device__ __forceinline__ int pipe_zero(float x) { int z; asm("s_and_b32 %0, %1, 0" : "=s"(z) : "s"(__float_as_int(x)) : "scc"); return z; }
 
 // e^-x for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 (two-part ln 2), |r| <= 0.3466, Taylor to degree 13 (remainder 4e-18), 2^k by v_ldexp

@@ -616,7 +616,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sigmoid_fast(float eta) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(eta * -1.4426950408889634f)); }
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 template <int Q, bool DELTA>
-__device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
+__device__ __forceinline__ void pass32_pk_f32(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
                                           const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
                                           int part = 0, int nparts = 1, double *hdl = nullptr)
 {
@@ -669,11 +669,15 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
         for (int j = 0; j < Q; ++j) { hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d.x), __float_as_uint(d.y), false, false);
         const float a0f = __uint_as_float(sw[0]), a1f = __uint_as_float(sw[1]);
+#ifndef P32_ABL_NO_MFMA                                                  /* timing ablation (results meaningless): the pass without its MFMAs */
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0f, bz[cb], acc[cb][0], 0, 0, 0);
             acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1f, bz[cb], acc[cb][1], 0, 0, 0);
         }
+#else
+        acc[0][0][0] += a0f * bz[0]; acc[0][1][0] += a1f * bz[NCB - 1];
+#endif
     };
     auto fetch_rec = [&](int pr, v2f (&rec)[RS]) {
 #pragma unroll
@@ -782,6 +786,254 @@ __device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_
                 for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
         }
     }
+}
+
+
+// ---- the same pass with the covariate block on the HALF-precision matrix pipe (round 3) ---------------------------------------------------
+// Measured in round 3 (timing build without the MFMAs): the four v_mfma_f32_32x32x2_f32 per pair of samples cost 1.2 of the 3.15 ms of
+// k_glm_pass32 -- on gfx950 an f32 MFMA runs on the vector ALUs' rate and its time ADDS to the VALU's.  The f16 MFMA
+// (v_mfma_f32_32x32x16_f16) runs on the matrix cores proper, 16x the MAC rate: 16 samples per issue instead of 2.
+//   A operand = the weights of 32 variants x 16 samples as halves; B = the products z_j z_k of those 16 samples (GlmParams.zz16, per 16-sample
+//   group and 32-column block one uint4 per lane, already in the B layout: lane (n = lane & 31, kg = lane >> 5) holds column n of samples
+//   8 kg .. 8 kg + 7); fp32 accumulation, the C layout of the f32 form, so the transposition at the end of the pass is unchanged.
+//   A lane computes its own variant's weight for all 16 samples (8 registers of half2, one per pair); four v_permlane32_swap turn them into
+//   the A operands of the two 32-variant halves (lanes 32..63 supply k = 8..15 of variants 0..31 and vice versa).
+//   Newton steering (DELTA = false): the weights and products rounded to half (2^-11 relative, random over 5000 terms: ~1e-5 on an entry
+//   of the Hessian, what its fp32 accumulation already carries).  The final information matrix (DELTA = true) needs single precision of
+//   the DIFFERENCES w - w0: both operands are split hi + lo (hi = half(x), lo = half(x - hi)) and three products are accumulated
+//   (hi hi, hi lo, lo hi: 2^-21 relative, the dropped lo lo term is 2^-22); the differences are scaled by 2^10 first so that their lo parts stay
+//   normal halves, and the sums are scaled back (exact).  Three f16 MFMAs cost 3/8 of one f32 MFMA per sample.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+#define P32_ASCALE 1024.0f
+template <int Q, bool DELTA>
+__device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
+                                          const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
+                                          int part = 0, int nparts = 1, double *hdl = nullptr)
+{
+    // hdl, part / nparts: as pass32_pk_f32 above
+    constexpr int PC = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE, NPART = DELTA ? 2 : 1;
+    const int N = P.N;
+    const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
+    constexpr int RS = Q + 2;
+    const v2f *__restrict__ Rp = (const v2f *)P.wfp;
+    const v4u *__restrict__ Z16 = (const v4u *)P.zz16;                        // [group][NCB][2 (hi, lo)][64 lanes] x 16 bytes
+    v16f acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][h][r] = 0.0f;
+    v2f bf[PC], gf[PC], h00 = {0.0f, 0.0f}, h10 = {0.0f, 0.0f}, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) { const float b = (float)beta[a]; bf[a] = v2f{b, b}; gf[a] = v2f{0.0f, 0.0f}; }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f}; }
+    const int nfull = N >> 1;
+    uint32_t Ah[8], Al[DELTA ? 8 : 1];                                        // this group's weights, one half2 per pair (hi, and lo for DELTA)
+    auto stash = [&](int slot, v2f d) {
+        if (DELTA) d = d * P32_ASCALE;
+        const v2h hh = __builtin_convertvector(d, v2h);
+        Ah[slot] = __builtin_bit_cast(uint32_t, hh);
+        if (DELTA) {
+            const v2h ll = __builtin_convertvector(d - __builtin_convertvector(hh, v2f), v2h);
+            Al[slot] = __builtin_bit_cast(uint32_t, ll);
+        }
+    };
+    auto pair = [&](const v2f (&rec)[RS], int slot, uint32_t two) {
+        const v2f xb = {(float)(two & 1u), (float)(two >> 1)};
+        v2f eta = pkfma(xb, bf[1], bf[0]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = pkfma(bf[2 + j], rec[j], eta);
+        v2f mu;
+        mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y);
+        const v2f wf = pkfma(-mu, mu, mu);
+        v2f d = wf;
+        if (DELTA) d = wf - rec[Q + 1];
+        else {
+            const v2f r = rec[Q] - mu;
+            gf[0] += r; gf[1] = pkfma(xb, r, gf[1]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) gf[2 + j] = pkfma(r, rec[j], gf[2 + j]);
+        }
+        const v2f dx = xb * d;
+        h00 += d; h10 += dx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
+        stash(slot, d);
+    };
+    auto fetch_rec = [&](int pr, v2f (&rec)[RS]) {
+#pragma unroll
+        for (int k = 0; k < RS; ++k) rec[k] = Rp[(int64_t)pr * RS + k];
+    };
+    auto fetch_bz = [&](int grp, v4u (&bz)[NCB][NPART]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int q2 = 0; q2 < NPART; ++q2) bz[cb][q2] = Z16[(((int64_t)grp * NCB + cb) * 2 + q2) * 64 + lane];
+    };
+    // the 16 samples stashed in Ah / Al against the group's product columns
+    auto flush = [&](const v4u (&bz)[NCB][NPART]) {
+        v4u a0, a1, l0, l1;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(Ah[q2], Ah[4 + q2], false, false);
+            a0[q2] = sw[0]; a1[q2] = sw[1];
+            if (DELTA) {
+                const auto sl = __builtin_amdgcn_permlane32_swap(Al[q2], Al[4 + q2], false, false);
+                l0[q2] = sl[0]; l1[q2] = sl[1];
+            }
+        }
+        const v8h A0 = __builtin_bit_cast(v8h, a0), A1 = __builtin_bit_cast(v8h, a1);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const v8h Bh = __builtin_bit_cast(v8h, bz[cb][0]);
+            acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bh, acc[cb][0], 0, 0, 0);
+            acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bh, acc[cb][1], 0, 0, 0);
+            if (DELTA) {
+                const v8h Bl = __builtin_bit_cast(v8h, bz[cb][NPART - 1]);
+                const v8h L0 = __builtin_bit_cast(v8h, l0), L1 = __builtin_bit_cast(v8h, l1);
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, Bl, acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, Bl, acc[cb][1], 0, 0, 0);
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(L0, Bh, acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(L1, Bh, acc[cb][1], 0, 0, 0);
+            }
+        }
+    };
+    // Records: two buffers in turn, pair p + 1 fetched while pair p is computed (scalar loads, ordered by pipe_zero).  The lane's B operands of
+    // a 16-sample group come from L2 (the table is 1.3 MB at N = 5000) one group ahead.  A 64-sample word holds 32 pairs = 4 groups.
+    v2f ra[RS], rb[RS];
+    v4u zc[NCB][NPART], zn[NCB][NPART];
+    const int nwords = nfull >> 5;                                            // whole words: pipelined
+    const int plast = nfull > 0 ? nfull - 1 : 0;
+    const int glast = (N + 15) / 16 - 1;
+    const int wd0 = (int)((int64_t)nwords * part / nparts), wd1 = (int)((int64_t)nwords * (part + 1) / nparts);
+    const bool tail = part == nparts - 1;
+    fetch_rec(min(wd0 * 32, plast), ra); fetch_bz(min(wd0 * 4, glast), zc);
+    uint64_t w = T[(int64_t)min(wd0, (N - 1) >> 6) * Vpad + v];
+    for (int wd = wd0; wd < wd1; ++wd) {
+        const uint64_t wn = T[(int64_t)min(wd + 1, (N - 1) >> 6) * Vpad + v];
+#pragma unroll 1
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int grp = wd * 4 + g4;
+            fetch_bz(min(grp + 1, glast), zn);
+            const uint32_t wbits = (uint32_t)(w >> (16 * g4)) & 0xFFFFu;
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const int pr = grp * 8 + k;
+                fetch_rec(pr + 1 + pipe_zero(ra[0].x), rb);
+                pair(ra, k, (wbits >> (2 * k)) & 3u);
+                fetch_rec(min(pr + 2, plast) + pipe_zero(rb[0].x), ra);
+                pair(rb, k + 1, (wbits >> (2 * k + 2)) & 3u);
+            }
+            flush(zc);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int q2 = 0; q2 < NPART; ++q2) zc[cb][q2] = zn[cb][q2];
+        }
+        w = wn;
+        if (DELTA && hdl) {
+            hdl[lane] += (double)(h00.x + h00.y); hdl[64 + lane] += (double)(h10.x + h10.y);
+            h00 = v2f{0.0f, 0.0f}; h10 = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                hdl[(2 + j) * 64 + lane] += (double)(hz0[j].x + hz0[j].y); hdl[(2 + Q + j) * 64 + lane] += (double)(hz1[j].x + hz1[j].y);
+                hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f};
+            }
+        }
+    }
+    float h00s, h10s, gs[PC], hz0s[Q > 0 ? Q : 1], hz1s[Q > 0 ? Q : 1];
+    // The last partial word and the odd last sample (the last part only), plainly: groups of 8 pairs, absent pairs stashed as zeros (the table is
+    // zero behind sample N as well).  The odd sample is the first half of pair `nfull`; its record is not in the pair table (Wf / yf / w0f).
+    float odd_d = 0.0f;
+    bool odd_x = false;
+    if ((N & 1) && tail) {
+        const int i = N - 1;
+        odd_x = (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull;
+        float eta = bf[0].x + (odd_x ? bf[1].x : 0.0f);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j].x, Wf[(int64_t)i * Q + j], eta);
+        const float mu = sigmoid_fast(eta);
+        const float wf = mu * (1.0f - mu);
+        odd_d = DELTA ? wf - P.w0f[i] : wf;
+        if (!DELTA) {
+            const float r = P.yf[i] - mu;
+            gf[0].x += r; gf[1].x += odd_x ? r : 0.0f;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) gf[2 + j].x = fmaf(r, Wf[(int64_t)i * Q + j], gf[2 + j].x);
+        }
+        const float dx = odd_x ? odd_d : 0.0f;
+        h00.x += odd_d; h10.x += dx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0[j].x = fmaf(odd_d, zj, hz0[j].x); hz1[j].x = fmaf(dx, zj, hz1[j].x); }
+    }
+    if (tail) {
+        const int pend = nfull + (N & 1);                                     // pair slots in use, the odd sample's included
+        for (int p0 = nwords * 32; p0 < pend; p0 += 8) {
+            if (p0 == nwords * 32) w = T[(int64_t)min(p0 >> 5, (N - 1) >> 6) * Vpad + v];
+            fetch_bz(min(p0 >> 3, glast), zc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int pr = p0 + k;
+                if (pr < nfull) { fetch_rec(pr, ra); pair(ra, k, (uint32_t)(w >> (2 * (pr & 31))) & 3u); }
+                else if (pr == nfull && (N & 1)) stash(k, v2f{odd_d, 0.0f});
+                else stash(k, v2f{0.0f, 0.0f});
+            }
+            flush(zc);
+        }
+    }
+    h00s = h00.x + h00.y; h10s = h10.x + h10.y;
+#pragma unroll
+    for (int a = 0; a < PC; ++a) gs[a] = gf[a].x + gf[a].y;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { hz0s[j] = hz0[j].x + hz0[j].y; hz1s[j] = hz1[j].x + hz1[j].y; }
+#pragma unroll
+    for (int a = 0; a < PC; ++a) g[a] = (double)gs[a];
+    if (DELTA && hdl) {
+        h00s = (float)(hdl[lane] + (double)h00s); h10s = (float)(hdl[64 + lane] + (double)h10s);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            hz0s[j] = (float)(hdl[(2 + j) * 64 + lane] + (double)hz0s[j]); hz1s[j] = (float)(hdl[(2 + Q + j) * 64 + lane] + (double)hz1s[j]);
+        }
+    }
+    H[sidx(0, 0)] = h00s; H[sidx(1, 0)] = h10s; H[sidx(1, 1)] = h10s;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0s[j]; H[sidx(2 + j, 1)] = hz1s[j]; }
+    const float unscale = DELTA ? 1.0f / P32_ASCALE : 1.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * (STRIDE + 1) + cb * 32 + l31] = acc[cb][h][r] * unscale;
+        __syncthreads();
+        if (lh == h) {
+            const float *row = tr + l31 * (STRIDE + 1);
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
+        }
+    }
+}
+
+#ifndef P32_F16
+#define P32_F16 1                    /* 0: the covariate block of the packed passes on the f32 MFMA (round 2), for A/B */
+#endif
+template <int Q, bool DELTA>
+__device__ __forceinline__ void pass32_pk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
+                                          const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
+                                          int part = 0, int nparts = 1, double *hdl = nullptr)
+{
+#if P32_F16
+    pass32_pk_f16<Q, DELTA>(T, Vpad, v, P, Wf, beta, H, g, tr, part, nparts, hdl);
+#else
+    pass32_pk_f32<Q, DELTA>(T, Vpad, v, P, Wf, beta, H, g, tr, part, nparts, hdl);
+#endif
 }
 
 // ---- the fast phase as ROUNDS of lean kernels over lists of variants (GlmParams.chord_on) -------------------------------------
@@ -929,8 +1181,11 @@ __global__ __launch_bounds__(64) void k_glm_solve32(int64_t Vpad, GlmParams P, G
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
 
+#ifndef GLM_SCORE_BLOCKS
+#define GLM_SCORE_BLOCKS 1
+#endif
 template <int Q>
-__global__ __launch_bounds__(256) void k_glm_score(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
+__global__ __launch_bounds__(256, GLM_SCORE_BLOCKS) void k_glm_score(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
                                                    const double *__restrict__ W, GlmParams P, const int *__restrict__ list,
                                                    const int *__restrict__ cnt)
 {
@@ -1453,8 +1708,11 @@ __global__ __launch_bounds__(64, 2) void k_glm_final(const uint64_t *__restrict_
 //                 block (null_h, a0) and, for the variant's row, the carrier sums of k_glm_bitdot.
 //   k_glm_finish  fp64: assemble and factor the information matrix, bse, the exact Newton step (certificate: <= 5e-7, else the variant is
 //                 restarted by k_glm_slow), decisions and the output row.
+#ifndef GLM_LL_BLOCKS
+#define GLM_LL_BLOCKS 1
+#endif
 template <int Q>
-__global__ __launch_bounds__(256) void k_glm_ll(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y, GlmParams P,
+__global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y, GlmParams P,
                                                 const int *__restrict__ list, const int *__restrict__ cnt)
 {
     constexpr int PC = Q + 2, RS = Q + 1;

@@ -90,7 +90,10 @@ def similarity_matrix(p, var_type, infile, path, all_strains, sample_order, min_
                                     uncompressed, block_size, want_patterns=False)
     nblocks = 0
     for blk in blocks:
-        acc.add_packed(blk.bits)
+        st_arr = np.asarray(blk.status)
+        # blocks of the native reader carry every parsed row (the association driver lets the engine apply the AF window); here only the kept
+        # rows enter K = G G^T, as the reference's load_var_block drops the filtered ones (pyseer/input.py:693)
+        acc.add_packed(blk.bits if (st_arr == 0).all() or blk.bits.shape[0] != st_arr.shape[0] else np.ascontiguousarray(blk.bits[st_arr == 0]))
         for st, k in zip(blk.status, blk.ks):
             if st == 2:
                 acc.add_dense(k)

@@ -80,6 +80,42 @@ template <int NCH, int PK> static void runc(int waves_per_simd, double *o, doubl
     printf("%s, %d independent chain(s) per wave, W=%d: %.2f cycles per wave-instruction per SIMD at %.1f GHz\n", PK ? "v_pk_fma_f32" : "v_fma_f64", NCH, waves_per_simd,
            ms * 1e-3 * ghz * 1e9 / ((double)ITERS * 16 * waves_per_simd), ghz);
 }
+
+// conversions and selects (one kind per kernel, 16 independent instructions per iteration)
+template <int KIND>
+__global__ __launch_bounds__(256) void kv(double *out)
+{
+    double a[8]; unsigned u[8]; float f[8];
+    for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x + i; u[i] = threadIdx.x * 3 + i; f[i] = threadIdx.x + 0.5f * i; }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (KIND == 0) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+            if (KIND == 1) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[i]) : "v"(a[i]));
+            if (KIND == 2) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[i]) : "v"(f[i]));
+            if (KIND == 3) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[i]) : "v"(a[i]));
+            if (KIND == 4) asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(u[i]) : "v"(u[(i + 1) & 7]));
+            if (KIND == 5) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+            if (KIND == 6) asm volatile("v_lshrrev_b64 %0, 3, %1" : "=v"(a[i]) : "v"(a[(i + 1) & 7]));
+            if (KIND == 7) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(u[i]));
+            if (KIND == 8) asm volatile("v_max_f64 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            if (KIND == 9) asm volatile("v_cmp_eq_u64 vcc, %0, %1" :: "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc");
+        }
+    }
+    double s = 0; for (int i = 0; i < 8; ++i) s += a[i] + u[i] + f[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int KIND> static void runv(const char *name, int w, double *o)
+{
+    const int blocks = 256 * w;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kv<KIND>, dim3(blocks), dim3(256), 0, 0, o); hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL(kv<KIND>, dim3(blocks), dim3(256), 0, 0, o); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-18s W=%d: %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n", name, w, ms * 1e-3 * 2.4e9 / ((double)ITERS * 16 * w));
+}
 int main()
 {
     double *o; float *of; hipMalloc(&o, 8 << 20); hipMalloc(&of, 4 << 20);
@@ -89,5 +125,7 @@ int main()
         run<5>("v_rcp_f64", w, o, of, 2.4); run<7>("v_ldexp_f64 / v_rndne_f64", w, o, of, 2.4);
     }
     for (int w = 1; w <= 2; ++w) { runc<1, 0>(w, o, 2.4); runc<2, 0>(w, o, 2.4); runc<4, 0>(w, o, 2.4); runc<8, 0>(w, o, 2.4); runc<1, 1>(w, o, 2.4); runc<2, 1>(w, o, 2.4); runc<4, 1>(w, o, 2.4); }
+    for (int w = 1; w <= 2; ++w) { runv<0>("v_cvt_f64_u32", w, o); runv<1>("v_cvt_f32_f64", w, o); runv<2>("v_cvt_f64_f32", w, o); runv<3>("v_cvt_i32_f64", w, o);
+        runv<4>("v_bfe_u32", w, o); runv<5>("v_cndmask_b32", w, o); runv<6>("v_lshrrev_b64", w, o); runv<7>("v_cvt_f32_u32", w, o); runv<8>("v_max_f64", w, o); runv<9>("v_cmp_eq_u64", w, o); }
     return 0;
 }
