@@ -346,21 +346,46 @@ __global__ __launch_bounds__(512) void k_firth_step2(const uint64_t *__restrict_
     // L_s below the diagonal, row by row, as floats packed two per register pair: entry e = a (a - 1) / 2 + k  (a > k)
     v2f Lp[(NL + 1) / 2], dinv[(PC + 1) / 2];
     {
+        // The transform reads 78 fp64 state values per lane and is register-hungry (the compiler issues the loads first and spills around
+        // them).  The S wavefronts of a block need the same 64 variants' factors: wavefront 0 alone computes them and hands the packed floats
+        // to the others through LDS (the reduction area of xw_sum, idle until the end of the pass), so the spill code runs in one wavefront
+        // of eight (scratch traffic of a C4 batch 6 -> <1 GB).
+        extern __shared__ double xw_lds[];
+        float *lsh = (float *)xw_lds;                                            // [NL + PC + 2][64]
+        constexpr int NF = NL + 1 + PC + 1;
         float Lf[NL + 1], df[PC + 1];
-        Lf[NL] = 0.0f; df[PC] = 0.0f;
+        if (xw.S == 1 || xw.w == 0) {
+            Lf[NL] = 0.0f; df[PC] = 0.0f;
 #pragma unroll
-        for (int a = 0; a < PC; ++a) {
-            const double sa = (a >= 2) ? P.wstd[Q + a - 2] : 1.0;
+            for (int a = 0; a < PC; ++a) {
+                const double sa = (a >= 2) ? P.wstd[Q + a - 2] : 1.0;
+                const double isa = 1.0 / sa;
 #pragma unroll
-            for (int k = 0; k < a; ++k) {
-                double l = fw.st[(int64_t)(fw_fac<PC>() + sidx(a, k)) * cap + s];
-                if (a >= 2 && k == 0) l -= P.wstd[a - 2];
-                const double sk = (k >= 2) ? P.wstd[Q + k - 2] : 1.0;
-                Lf[a * (a - 1) / 2 + k] = (float)(l * sk / sa);
+                for (int k = 0; k < a; ++k) {
+                    double l = fw.st[(int64_t)(fw_fac<PC>() + sidx(a, k)) * cap + s];
+                    if (a >= 2 && k == 0) l -= P.wstd[a - 2];
+                    const double sk = (k >= 2) ? P.wstd[Q + k - 2] : 1.0;
+                    Lf[a * (a - 1) / 2 + k] = (float)(l * sk * isa);
+                }
+                const double d = fw.st[(int64_t)(fw_fac<PC>() + sidx(a, a)) * cap + s];
+                df[a] = (float)((sa * sa) / d);
             }
-            const double d = fw.st[(int64_t)(fw_fac<PC>() + sidx(a, a)) * cap + s];
-            df[a] = (float)((sa * sa) / d);
+            if (xw.S > 1) {
+#pragma unroll
+                for (int e = 0; e < NL + 1; ++e) lsh[e * 64 + xw.lane] = Lf[e];
+#pragma unroll
+                for (int e = 0; e < PC + 1; ++e) lsh[(NL + 1 + e) * 64 + xw.lane] = df[e];
+            }
         }
+        if (xw.S > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < NL + 1; ++e) Lf[e] = lsh[e * 64 + xw.lane];
+#pragma unroll
+            for (int e = 0; e < PC + 1; ++e) df[e] = lsh[(NL + 1 + e) * 64 + xw.lane];
+            __syncthreads();                                                     // the area is the reduction's again
+        }
+        (void)NF;                                                               // the launcher sizes the area: NF x 64 floats
 #pragma unroll
         for (int e = 0; e < (NL + 1) / 2; ++e) Lp[e] = v2f{Lf[2 * e], Lf[2 * e + 1]};
 #pragma unroll
@@ -522,7 +547,9 @@ static hipError_t launch_firth2(hipStream_t st, int which, int64_t n, const uint
         hipLaunchKernelGGL(k_firth_eval2<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, V, P, fw, in_list, in_count, next_eval, next_eval_count,
                            step_list, step_count, out, flags, plist, pcount);
     else {
-        hipLaunchKernelGGL(k_firth_step2<Q>, grid, blks, glm_split_lds(S), st, T, Vpad, P, fw, in_list, in_count, next_eval, next_eval_count);
+        // dynamic LDS: the reduction area of xw_sum, which also carries the factor from wavefront 0 to the others ((NL + PC + 2) x 64 floats)
+        const size_t lds = S > 1 ? std::max(glm_split_lds(S), (size_t)(((Q + 2) * (Q + 1) / 2 + Q + 4) * 64 * sizeof(float))) : 0;
+        hipLaunchKernelGGL(k_firth_step2<Q>, grid, blks, lds, st, T, Vpad, P, fw, in_list, in_count, next_eval, next_eval_count);
     }
     return hipGetLastError();
 }
