@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
 #pragma unroll 1
     for (int s = 0; s < total; ++s) {
         if (s > 0) sync_refill(s);
-        if (cst == 0) {
+        if ((ABL & 256) ? s == 0 : cst == 0) {                     // ABL 256: timing ablation without the per-segment zeroing
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -549,6 +549,7 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
 #pragma unroll
             for (int jt = 0; jt < QF_JT; ++jt) {
                 int part[4];
+                if (ABL & 128) { tot[jt] += (double)(acc[0][jt][0] + acc[1][jt][1] + acc[2][jt][2] + acc[3][jt][3]); continue; }   // timing ablation: no epilogue
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const uint32_t w = (uint32_t)(wb[it >> 1][jt] >> ((it & 1) * 32 + 4 * lh));
@@ -585,6 +586,8 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
         for (int jt = 0; jt < QF_JT; ++jt) qo[32 * jt] = tot[jt];
     }
 }
+
+#include "lmm_quadform_wide.inc"
 
 // ---------------------------------------------------------------------------------------------
 // Per-variant finalisation: a1 prefilter + A5 statistics + a7 filters (pyseer/lmm.py:160-217, 244-258).
@@ -1036,7 +1039,8 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
 hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q,
                             const int *nlimit)
 {
-    const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(64 * QF_WAVES);
+    const bool wide = variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 50 || variant == 441 || variant == 162 || variant == 35;   // 128 x 128 wave tiles, one wavefront per SIMD
+    const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(wide ? 256 : 64 * QF_WAVES);
     const size_t lds = QF_NST * QF_STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1049,6 +1053,18 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<23>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<407>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<407>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     switch (variant) {          // 30 + mask = timing ablations (results meaningless); 64 = the extra-limb pass (same code, its own name in profiles)
@@ -1060,6 +1076,18 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
     case 38: hipLaunchKernelGGL(k_lmm_quadform_i8<8>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
     case 37: hipLaunchKernelGGL(k_lmm_quadform_i8<7>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
     case 64: hipLaunchKernelGGL(k_lmm_quadform_i8<64>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
+    case 158: hipLaunchKernelGGL(k_lmm_quadform_i8<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // no epilogue
+    case 286: hipLaunchKernelGGL(k_lmm_quadform_i8<256>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // no zeroing
+    case 414: hipLaunchKernelGGL(k_lmm_quadform_i8<384>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // neither
+    case 4: hipLaunchKernelGGL(k_lmm_quadform_i8w<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;        // wide wave tile
+    case 5: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, DMA burst
+    case 6: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // wide, s_memtime profile
+    case 7: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // wide, s_memtime profile 2
+    case 50: hipLaunchKernelGGL(k_lmm_quadform_i8w<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;      // wide, no barrier
+    case 35: hipLaunchKernelGGL(k_lmm_quadform_i8w<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;       // wide, no DMA
+    case 162: hipLaunchKernelGGL(k_lmm_quadform_i8w<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, no epilogue
+    case 441: hipLaunchKernelGGL(k_lmm_quadform_i8w<407>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, MFMAs only
+    case 437: hipLaunchKernelGGL(k_lmm_quadform_i8<407>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // MFMAs only
     default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
     }
     return hipGetLastError();
