@@ -66,7 +66,8 @@ struct sh_ctx {
     uint8_t *d_flip = nullptr; uint64_t *d_T3 = nullptr; double *d_q3 = nullptr; int *d_rlist = nullptr, *d_rcount = nullptr;
     unsigned long long *d_bmax = nullptr; int64_t cap_ref = 0;
     int qf_split = 1;             // 1: one block per (variant tile, limb) (SEERHIP_QF_SPLIT=0: one block per tile loops over the limbs)
-    int qf_variant = 0;           // hot-kernel variant (SEERHIP_QF=1 selects the first-generation kernel, for A/B runs)
+    int qf_variant = 4;           // hot-kernel variant: 4 = k_lmm_quadform_i8w (one wavefront per SIMD; the launcher falls back to 0 where its conditions do not
+                                  // hold), SEERHIP_QF=0 = k_lmm_quadform_i8 (two wavefronts per SIMD), other values = timing ablations (lmm_kernels.hip)
     // ---- GLM state
     GlmState glm;
     // ---- per-batch workspace (grown on demand)
@@ -553,7 +554,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     HIPCHK(dmalloc(&c->d_vv, N)); HIPCHK(dmalloc(&c->d_mdiag, N)); HIPCHK(dmalloc(&c->d_yc, N));
     HIPCHK(dmalloc(&c->d_y1, c->NB64p)); HIPCHK(dmalloc(&c->d_y0, c->NB64p));
     if (DP) HIPCHK(dmalloc(&c->d_Qb, (size_t)N * DP));
-    HIPCHK(hipMalloc((void **)&c->d_G, gbytes));
+    HIPCHK(hipMalloc((void **)&c->d_G, gbytes + (256u << 10)));       // + 256 KB: k_lmm_quadform_i8w's DMA cursor runs four stages past the last limb
     HIPCHK(dmalloc(&d_W, (size_t)Np * kp)); HIPCHK(dmalloc(&d_sgn, kp)); HIPCHK(dmalloc(&d_M, (size_t)Np * Np)); HIPCHK(dmalloc(&d_amax, 1));
     hipStream_t st = c->stream;
     HIPCHK(hipMemcpyAsync(d_W, W.data(), sizeof(double) * (size_t)Np * kp, hipMemcpyHostToDevice, st));
@@ -641,7 +642,7 @@ int sh_lmm_share(sh_ctx *dst, sh_ctx *src)
     HIPCHK(dmalloc(&c->d_vv, N)); HIPCHK(dmalloc(&c->d_mdiag, N)); HIPCHK(dmalloc(&c->d_yc, N));
     HIPCHK(dmalloc(&c->d_y1, c->NB64p)); HIPCHK(dmalloc(&c->d_y0, c->NB64p));
     if (src->DP) HIPCHK(dmalloc(&c->d_Qb, (size_t)N * src->DP));
-    HIPCHK(hipMalloc((void **)&c->d_G, src->g_bytes)); HIPCHK(dmalloc(&c->d_tab, src->tab_doubles));
+    HIPCHK(hipMalloc((void **)&c->d_G, src->g_bytes + (256u << 10))); HIPCHK(dmalloc(&c->d_tab, src->tab_doubles));
     auto cp = [&](void *d, const void *s_, size_t n) { return hipMemcpyPeerAsync(d, dst->device, s_, src->device, n, dst->stream); };
     HIPCHK(cp(c->d_vv, src->d_vv, sizeof(double) * N)); HIPCHK(cp(c->d_mdiag, src->d_mdiag, sizeof(double) * N));
     HIPCHK(cp(c->d_yc, src->d_yc, sizeof(double) * N));

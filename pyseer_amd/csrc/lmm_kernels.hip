@@ -1039,7 +1039,11 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
 hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q,
                             const int *nlimit)
 {
-    const bool wide = variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 50 || variant == 441 || variant == 162 || variant == 35;   // 128 x 128 wave tiles, one wavefront per SIMD
+    // the wide kernel's conditions: one limb per block, at least four row tiles (its DMA cursor runs four stages past the stream), 32-bit offsets
+    const bool wide_ok = lsplit == L && NR >= 4 && (uint64_t)NR * 2 * (uint64_t)Vpad * 8 < (1ull << 32) && (uint64_t)(L + 1) * NR * (NR + 1) * QF_TILE_BYTES < (1ull << 32);
+    const bool wide_var = variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 50 || variant == 441 || variant == 162 || variant == 35;
+    if (wide_var && !wide_ok) variant = 0;
+    const bool wide = wide_var && wide_ok;                            // 128 x 128 wave tiles, one wavefront per SIMD
     const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(wide ? 256 : 64 * QF_WAVES);
     const size_t lds = QF_NST * QF_STAGE_BYTES;
     static bool attr_set = false;
@@ -1061,6 +1065,8 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<16, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1083,6 +1089,8 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
     case 5: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, DMA burst
     case 6: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // wide, s_memtime profile
     case 7: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // wide, s_memtime profile 2
+    case 8: hipLaunchKernelGGL((k_lmm_quadform_i8w<16, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // profile, no barrier
+    case 9: hipLaunchKernelGGL((k_lmm_quadform_i8w<1, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;  // profile, no DMA
     case 50: hipLaunchKernelGGL(k_lmm_quadform_i8w<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;      // wide, no barrier
     case 35: hipLaunchKernelGGL(k_lmm_quadform_i8w<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;       // wide, no DMA
     case 162: hipLaunchKernelGGL(k_lmm_quadform_i8w<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, no epilogue
