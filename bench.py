@@ -514,7 +514,7 @@ def main():
                 "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                              "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                              "traffic_source": traffic_src,
-                             "kernel": "k_lmm_quadform_i8", "kernel_ms": kern_s * 1e3, "launches": klaunch,
+                             "kernel": "k_lmm_quadform_i8w", "kernel_ms": kern_s * 1e3, "launches": klaunch,
                              "ops": "int8 multiply-adds x2 actually issued per variant (sh_lmm_info) x variants per launch",
                              "int8_macs_per_variant": info["int8_macs_per_variant"],
                              "fp64_equiv_tflops": FP64_FLOP_PER_TEST * Vs / kern_s / 1e12,

@@ -45,7 +45,7 @@ def main(src, dst):
                 if not k.startswith("k_"):                    # torch's data-generation kernels are not the subject
                     continue
                 rows.append((os.path.basename(d), k, c, len(v), sum(v), sum(v) / len(v)))
-                dominant = ("quadform_i8<0>" in k or k.endswith("k_lmm_quadform_i8")) if cfg == "C3" else any(g in k for g in GLM)
+                dominant = ("quadform_i8<0>" in k or "quadform_i8w<0, 0, 0>" in k or k.endswith("k_lmm_quadform_i8") or k.endswith("k_lmm_quadform_i8w")) if cfg == "C3" else any(g in k for g in GLM)
                 if dominant:
                     tot[c] += sum(v)
         if rows:                                              # a run with PMC=0 has no counter passes: bench line and kernel stats only
@@ -55,7 +55,7 @@ def main(src, dst):
                     f.write("%s,%s,%s,%d,%.6g,%.6g\n" % r)
         tag = "lmm" if cfg == "C3" else cfg.lower()
         if "FETCH_SIZE" in tot:
-            json.dump({"kernels": "k_lmm_quadform_i8" if cfg == "C3" else "all k_glm_* / k_firth_* kernels of one step",
+            json.dump({"kernels": "k_lmm_quadform_i8w" if cfg == "C3" else "all k_glm_* / k_firth_* kernels of one step",
                        "variants_per_dispatch": V, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot.get("WRITE_SIZE"),
                        "fetch_correction": 2.0,
                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r03.sh) on %s; gfx950: FETCH_SIZE "
