@@ -523,6 +523,28 @@ def test_complemented_rows_change_nothing_but_rounding(engine_mod, monkeypatch):
             assert _dev(a[f], b[f]) < 1e-9, (N, f, _dev(a[f], b[f]))
 
 
+@pytest.mark.parametrize("N,V,limbs", [(520, 700, 0), (1100, 1536, 5), (2049, 600, 4)])
+def test_one_wave_and_two_wave_contractions_agree_bit_for_bit(engine_mod, monkeypatch, N, V, limbs):
+    """k_lmm_quadform_i8w (one wavefront per SIMD, the default where its conditions hold: here N >= 512) and k_lmm_quadform_i8 (SEERHIP_QF=0, read
+    when the context is created; also the fallback for fewer than four row tiles) are the same exact integer contraction with the same fp64
+    recombination: every output double must be identical, whatever the shape (V not a multiple of the block, several launches' worth of tiles)."""
+    Engine, pack = engine_mod
+    U, S, covar, y, Kv = _random_lmm(N, 1, 77 + N, V)
+    Kv[: V // 8] = (np.random.default_rng(3).random((V // 8, N)) < 0.9).astype(np.uint8)      # majority-carrier rows (stored complemented)
+    bits = pack(Kv)
+    out = []
+    for qf in ("4", "0"):
+        monkeypatch.setenv("SEERHIP_QF", qf)
+        e = Engine(N)
+        e.lmm_setup(U, S, y, covar, 0.33, n_limbs=limbs)
+        out.append(e.lmm_batch(bits)); e.close()
+    monkeypatch.delenv("SEERHIP_QF")
+    a, b = out
+    assert np.array_equal(a["flags"], b["flags"])
+    for f in ("prep", "beta", "bse", "pvalue", "frac_h2"):
+        assert np.array_equal(a[f].view(np.uint64), b[f].view(np.uint64)), (N, f)
+
+
 def test_covariates_without_intercept_through_the_abi(engine_mod):
     """pyseer always appends the intercept (lmm.py:95-99); the C ABI does not require it.  Without it U~^T 1 != 0, rows must not be
     complemented, and the statistics still follow the oracle."""
