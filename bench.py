@@ -502,6 +502,7 @@ def main():
                "per_rank_value": per_rank, "finite_fraction": min(fin_all),
                "distinct_rows_per_gpu": int(ndist) * int(Vs)}
         if lmm:
+            info = eng.lmm_info()                         # after the timed launches: the MACs the contraction kernel actually issued per variant
             int8_ops = 2.0 * info["int8_macs_per_variant"] * Vs
             achieved = int8_ops / kern_s / 1e12
             traffic, traffic_src = measured_traffic("lmm", Vs)

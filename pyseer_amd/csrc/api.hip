@@ -20,7 +20,7 @@ hipError_t shk_repack_bits(hipStream_t, const uint8_t *, int64_t, int64_t, int64
 hipError_t shk_lmm_linear(hipStream_t, int, const uint64_t *, int64_t, int, int, const double *, const double *,
                           const double *, const double *, const uint64_t *, const uint64_t *, int, const double *, LmmLinOut);
 hipError_t shk_lmm_build_tab(hipStream_t, const double *, const double *, const double *, const double *, int, int, int, int, double *);
-hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *, const int *);
+hipError_t shk_lmm_quadform(hipStream_t, int, const int8_t *, const uint64_t *, int64_t, int, int, int, double *, const int *, int, int64_t *);
 hipError_t shk_lmm_refine(hipStream_t, int64_t, int64_t, int, int, int, int, const int8_t *, const uint64_t *, uint64_t *, double *, LmmLinOut,
                           const double *, LmmFinParams, double *, uint32_t *, LmmRefine);
 hipError_t shk_af_compact(hipStream_t, int, int64_t, LmmLinOut, LmmFinParams, int *, int *, const uint64_t *, int64_t, uint64_t *,
@@ -60,6 +60,7 @@ struct sh_ctx {
     int8_t *d_G = nullptr;
     double quant_scale = 0.0;
     size_t g_bytes = 0, tab_doubles = 0;
+    int64_t macs_issued = 0;      // int8 MACs per variant of the last main-pass contraction (sh_lmm_info)
     int E = 0;                    // extra (low) limbs stored below the L of the main pass; contracted only for variants whose bound exceeds lmm_tol
     bool complement = false;      // rows with more than N/2 carriers are stored complemented (needs the intercept in the covariate span)
     double err_norm_ulp = 0.0, err_norm_est_ulp = 0.0, lmm_tol = 1e-8, trace_M = 0.0; int err_norm_squarings = 0;
@@ -451,7 +452,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     HIPCHK(hipSetDevice(c->device));
     const int N = c->N, Np = c->Np;
     const int kp = (k + 3) & ~3;
-    c->lmm_ready = false;
+    c->lmm_ready = false; c->macs_issued = 0;
 
     // 1. orthonormal basis of the covariate space (modified Gram-Schmidt, twice): P = I - Qb Qb^T = I - X pinv(X)
     std::vector<double> Qb((size_t)N * D, 0.0);
@@ -618,8 +619,9 @@ int sh_lmm_info(sh_ctx *c, int *n_limbs, int64_t *macs, double *qscale)
 {
     if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
     if (n_limbs) *n_limbs = c->L;
-    // executed int8 MACs per variant in k_lmm_quadform_i8: L * sum_I 2(I+1) tiles * (128 rows * 64), NR = 2*NT row tiles
-    if (macs) *macs = (int64_t)c->L * (2 * c->NT) * (2 * c->NT + 1) * 128 * 64;
+    // executed int8 MACs per variant: as issued by the last main-pass launch (k_lmm_quadform_i8w drops the 32-row sub-tiles of the last row tile
+    // that are padding), else the full tiles of k_lmm_quadform_i8: L * sum_I 2(I+1) tiles * (128 rows * 64), NR = 2*NT row tiles
+    if (macs) *macs = c->macs_issued > 0 ? c->macs_issued : (int64_t)c->L * (2 * c->NT) * (2 * c->NT + 1) * 128 * 64;
     if (qscale) *qscale = c->quant_scale;
     return SH_OK;
 }
@@ -791,10 +793,10 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     if (compact && nk > 0) {
         const int64_t Vpad2 = (nk + 511) / 512 * 512;
         HIPCHK(shk_af_compact(st, 1, V, lo, KP, c->d_keep, nullptr, c->d_T, Vpad, c->d_T2, Vpad2, c->NB64p, (int)nk, nullptr, nullptr));
-        HIPCHK(shk_lmm_quadform(st, c->qf_variant, Gmain, c->d_T2, Vpad2, 2 * c->NT, c->L, lsplit, c->d_q2, nullptr));
+        HIPCHK(shk_lmm_quadform(st, c->qf_variant, Gmain, c->d_T2, Vpad2, 2 * c->NT, c->L, lsplit, c->d_q2, nullptr, c->N - (2 * c->NT - 1) * 128, &c->macs_issued));
         HIPCHK(shk_af_compact(st, 2, V, lo, KP, c->d_keep, nullptr, nullptr, Vpad, nullptr, Vpad2, lsplit, (int)nk, c->d_q2, c->d_q));
     } else if (!compact) {
-        HIPCHK(shk_lmm_quadform(st, c->qf_variant, Gmain, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q, nullptr));
+        HIPCHK(shk_lmm_quadform(st, c->qf_variant, Gmain, c->d_T, Vpad, 2 * c->NT, c->L, lsplit, c->d_q, nullptr, c->N - (2 * c->NT - 1) * 128, &c->macs_issued));
     }
     if (c->timing) { HIPCHK(hipEventRecord(e1, st)); c->tev.emplace_back(e0, e1); }
     LmmFinParams P = c->fin; P.min_af = c->min_af; P.max_af = c->max_af; P.af_on = c->af_on;

@@ -1037,13 +1037,18 @@ hipError_t shk_lmm_linear(hipStream_t st, int DP, const uint64_t *T, int64_t Vpa
 }
 
 hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const uint64_t *T, int64_t Vpad, int NR, int L, int lsplit, double *q,
-                            const int *nlimit)
+                            const int *nlimit, int rows_last, int64_t *macs_per_variant)
 {
     // the wide kernel's conditions: one limb per block, at least four row tiles (its DMA cursor runs four stages past the stream), 32-bit offsets
     const bool wide_ok = lsplit == L && NR >= 4 && (uint64_t)NR * 2 * (uint64_t)Vpad * 8 < (1ull << 32) && (uint64_t)(L + 1) * NR * (NR + 1) * QF_TILE_BYTES < (1ull << 32);
     const bool wide_var = variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 50 || variant == 441 || variant == 162 || variant == 35;
     if (wide_var && !wide_ok) variant = 0;
     const bool wide = wide_var && wide_ok;                            // 128 x 128 wave tiles, one wavefront per SIMD
+    // rows_last = valid rows (samples) of the last 128-row tile; the wide kernel contracts only the 32-row sub-tiles that hold any (4, 2, 1, or none:
+    // NR = 2 NT may exceed ceil(N / 128) by one).  The int8 MACs actually issued per variant go back to the caller (sh_lmm_info, the bench's roofline).
+    const int nit_last = !wide ? 4 : rows_last <= 0 ? 0 : rows_last <= 32 ? 1 : rows_last <= 64 ? 2 : 4;
+    if (macs_per_variant)
+        *macs_per_variant = (int64_t)L * ((int64_t)(NR - 1) * NR * 128 * 64 + (int64_t)2 * NR * 32 * nit_last * 64);
     const dim3 g((unsigned)(Vpad / QF_BN * lsplit)), b(wide ? 256 : 64 * QF_WAVES);
     const size_t lds = QF_NST * QF_STAGE_BYTES;
     static bool attr_set = false;
@@ -1085,16 +1090,16 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
     case 158: hipLaunchKernelGGL(k_lmm_quadform_i8<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // no epilogue
     case 286: hipLaunchKernelGGL(k_lmm_quadform_i8<256>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // no zeroing
     case 414: hipLaunchKernelGGL(k_lmm_quadform_i8<384>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // neither
-    case 4: hipLaunchKernelGGL(k_lmm_quadform_i8w<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;        // wide wave tile
-    case 5: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, DMA burst
-    case 6: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // wide, s_memtime profile
-    case 7: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // wide, s_memtime profile 2
-    case 8: hipLaunchKernelGGL((k_lmm_quadform_i8w<16, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break; // profile, no barrier
-    case 9: hipLaunchKernelGGL((k_lmm_quadform_i8w<1, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;  // profile, no DMA
-    case 50: hipLaunchKernelGGL(k_lmm_quadform_i8w<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;      // wide, no barrier
-    case 35: hipLaunchKernelGGL(k_lmm_quadform_i8w<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;       // wide, no DMA
-    case 162: hipLaunchKernelGGL(k_lmm_quadform_i8w<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, no epilogue
-    case 441: hipLaunchKernelGGL(k_lmm_quadform_i8w<407>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;    // wide, MFMAs only
+    case 4: hipLaunchKernelGGL(k_lmm_quadform_i8w<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;        // wide wave tile
+    case 5: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;    // wide, DMA burst
+    case 6: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break; // wide, s_memtime profile
+    case 7: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break; // wide, s_memtime profile 2
+    case 8: hipLaunchKernelGGL((k_lmm_quadform_i8w<16, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break; // profile, no barrier
+    case 9: hipLaunchKernelGGL((k_lmm_quadform_i8w<1, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;  // profile, no DMA
+    case 50: hipLaunchKernelGGL(k_lmm_quadform_i8w<16>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;      // wide, no barrier
+    case 35: hipLaunchKernelGGL(k_lmm_quadform_i8w<1>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;       // wide, no DMA
+    case 162: hipLaunchKernelGGL(k_lmm_quadform_i8w<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;    // wide, no epilogue
+    case 441: hipLaunchKernelGGL(k_lmm_quadform_i8w<407>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;    // wide, MFMAs only
     case 437: hipLaunchKernelGGL(k_lmm_quadform_i8<407>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // MFMAs only
     default: hipLaunchKernelGGL(k_lmm_quadform_i8<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;
     }
@@ -1114,7 +1119,7 @@ hipError_t shk_lmm_refine(hipStream_t st, int64_t V, int64_t Vpad, int nq, int E
                           uint64_t *T3, double *q3, LmmLinOut li, const double *q, LmmFinParams P, double *out, uint32_t *flags, LmmRefine R)
 {
     hipLaunchKernelGGL(k_gather_T_list, dim3(64, (unsigned)NB64p), dim3(256), 0, st, T, Vpad, T3, R);
-    hipError_t e = shk_lmm_quadform(st, 64, Glow, T3, Vpad, NR, E, E, q3, R.count);
+    hipError_t e = shk_lmm_quadform(st, 64, Glow, T3, Vpad, NR, E, E, q3, R.count, 128, nullptr);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lmm_refine_fix, dim3(64), dim3(256), 0, st, V, Vpad, nq, E, li, q, q3, P, out, flags, R);
     return hipGetLastError();

@@ -523,11 +523,13 @@ def test_complemented_rows_change_nothing_but_rounding(engine_mod, monkeypatch):
             assert _dev(a[f], b[f]) < 1e-9, (N, f, _dev(a[f], b[f]))
 
 
-@pytest.mark.parametrize("N,V,limbs", [(520, 700, 0), (1100, 1536, 5), (2049, 600, 4)])
+@pytest.mark.parametrize("N,V,limbs", [(520, 700, 0), (660, 513, 4), (680, 512, 4), (760, 100, 5), (1100, 1536, 5), (2049, 600, 4)])
 def test_one_wave_and_two_wave_contractions_agree_bit_for_bit(engine_mod, monkeypatch, N, V, limbs):
     """k_lmm_quadform_i8w (one wavefront per SIMD, the default where its conditions hold: here N >= 512) and k_lmm_quadform_i8 (SEERHIP_QF=0, read
     when the context is created; also the fallback for fewer than four row tiles) are the same exact integer contraction with the same fp64
-    recombination: every output double must be identical, whatever the shape (V not a multiple of the block, several launches' worth of tiles)."""
+    recombination: every output double must be identical, whatever the shape (V not a multiple of the block, several launches' worth of tiles).
+    The sample counts cover the one-wave kernel's treatment of the last 128-row tile (NR = 2 ceil(N / 256) row tiles): all padding and dropped
+    (520, 1100, 2049), 20 valid rows = one 32-row sub-tile (660), 40 = two (680), 120 = the full tile (760)."""
     Engine, pack = engine_mod
     U, S, covar, y, Kv = _random_lmm(N, 1, 77 + N, V)
     Kv[: V // 8] = (np.random.default_rng(3).random((V // 8, N)) < 0.9).astype(np.uint8)      # majority-carrier rows (stored complemented)

@@ -4,7 +4,7 @@
 # loop (everything outside ;;#ASMSTART / ;;#ASMEND) printed for inspection.
 cd "$(dirname "$0")/../pyseer_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -S --cuda-device-only -o /tmp/lmm_w.s lmm_kernels.hip 2>/dev/null
-K=${1:-_Z18k_lmm_quadform_i8wILi0ELi0ELi0EEvPKaPKmliiiPdPKi}
+K=${1:-_Z18k_lmm_quadform_i8wILi0ELi0ELi0EEvPKaPKmliiiPdPKii}
 awk "/^$K:/,/\\.end_amdhsa_kernel/" /tmp/lmm_w.s > /tmp/w0.s
 echo "lines $(wc -l < /tmp/w0.s)  mfma $(grep -c v_mfma /tmp/w0.s)  scratch $(grep -c scratch_ /tmp/w0.s)"
 grep -E "next_free_vgpr|accum_offset|private_segment_fixed|next_free_sgpr" /tmp/w0.s
