@@ -65,8 +65,8 @@ void    sh_destroy(sh_ctx *ctx);
 /* enqueue all later work on this hipStream_t (NULL = the device's default stream) */
 int     sh_set_stream(sh_ctx *ctx, void *hip_stream);
 int     sh_synchronize(sh_ctx *ctx);
-/* HIP-event timing of the dominant kernel(s) of each later *_batch_dev call, recorded on the context's stream: k_lmm_quadform_i8 (main
- * pass) for the LMM; every fit kernel of a fixed-effects batch (Newton, Firth rounds, final pass; the bit repack is outside).
+/* HIP-event timing of the dominant kernel(s) of each later *_batch_dev call, recorded on the context's stream: the contraction kernel
+ * (k_lmm_quadform_i8w, or k_lmm_quadform_i8 where the former's conditions do not hold; main pass) for the LMM; every fit kernel of a fixed-effects batch (Newton, Firth rounds, final pass; the bit repack is outside).
  * sh_get_timing synchronises on the recorded events and returns their sum. */
 int     sh_set_timing(sh_ctx *ctx, int on);
 int     sh_get_timing(sh_ctx *ctx, double *total_ms, int64_t *launches);
