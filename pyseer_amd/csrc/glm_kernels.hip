@@ -1326,29 +1326,35 @@ __global__ __launch_bounds__(64 * SCORE_SPLIT) void k_glm_score_split(const uint
 
 template <int Q>
 __global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
-                                                  int *__restrict__ next, int *__restrict__ next_cnt, int last_round)
+                                                  int *__restrict__ next, int *__restrict__ next_cnt, int last_round, int first_ll)
 {
     constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
     if ((int64_t)blockIdx.x * 64 >= *cnt) return;
     int64_t v;
     const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
     const double nobs = (double)P.N;
-    bool go_next = false, go_slow = false, go_fin = false;
+    bool go_next = false, go_slow = false, go_fin = false, go_direct = false;
     if (on) {
-        double A[NH], g[PC], beta[PC];
+        double A[NH], g[PC], beta[PC], bin[PC];
 #pragma unroll
         for (int a = 0; a < NH; ++a) A[a] = P.ch_fac[(int64_t)a * Vpad + v];
 #pragma unroll
-        for (int a = 0; a < PC; ++a) { g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; }
+        for (int a = 0; a < PC; ++a) { g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; beta[a] = bin[a] = P.ch_bs[(int64_t)a * Vpad + v]; }
         ldl_solve<PC>(A, g);
         double stp = 0.0; bool finite = true;
 #pragma unroll
         for (int a = 0; a < PC; ++a) { beta[a] += g[a]; stp = fmax(stp, fabs(g[a])); finite = finite && isfinite(beta[a]); }
         const bool sep = P.ch_md[v] <= 1e-8;
         if (finite && !sep && (double)P.ch_rho[v] * stp <= P.chord_tol && P.fin_rounds) {         // done: on to the finishing kernels
-            go_fin = true;
+            // first_ll: this round's pass was k_glm_ll, so ch_g / ch_ll / ch_md are the exact score, log-likelihood and callback value at the beta
+            // that came in.  With a small step that is all the finishing needs (k_glm_finish<Q, true>): the variant skips the final likelihood pass.
+            go_direct = first_ll && stp <= 1e-4;
+            go_fin = !go_direct;
 #pragma unroll
-            for (int a = 0; a < PC; ++a) P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
+            for (int a = 0; a < PC; ++a) {
+                if (go_direct) P.ch_b0[(int64_t)a * Vpad + v] = bin[a];              // the beta the pass was taken at
+                P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
+            }
         }
         else if (finite && !sep && (double)P.ch_rho[v] * stp <= P.chord_tol) {                     // done: beta to the final pass
             wk.state[v] = 1;
@@ -1369,6 +1375,7 @@ __global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, Glm
     list_push(go_next, next, next_cnt, (int)v);
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
     list_push(go_fin, P.ch_list[4], P.ch_cnt + 30, (int)v);
+    list_push(go_direct, P.ch_list[5], P.ch_cnt + 29, (int)v);
 }
 
 // ---- sums of per-run vectors over a variant's carriers, by nibble table (the device of k_glm_ols_tab) --------------------------
@@ -1897,7 +1904,11 @@ __global__ __launch_bounds__(64, 2) void k_glm_dpass_pk(const uint64_t *__restri
     for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
 }
 
-template <int Q>
+// DIRECT (GlmParams.ll_first): the score, log-likelihood and callback value on record were taken at ch_b0, one chord step in front of ch_bs (where
+// the information matrix was just evaluated): the result is the exact Newton step from ch_b0 with that matrix, beta = ch_b0 + H^-1 g (error
+// O(step^2), step <= 1e-4), its log-likelihood ll(ch_b0) + g . step / 2 (error O(N step^3)); the certificate is the distance of that beta from
+// the chord result (what the chord factor got wrong), <= 5e-7 as for the step of the plain form.
+template <int Q, bool DIRECT = false>
 __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmParams P, GlmWork wk, const int *__restrict__ list,
                                                    const int *__restrict__ cnt, double *__restrict__ out, uint32_t *__restrict__ flags,
                                                    int *__restrict__ firth_list, int *__restrict__ firth_count)
@@ -1914,7 +1925,7 @@ __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmP
         for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
         int status = 0;
         double bse1 = NAN;
-        const double llf = P.ch_ll[v];
+        double llf_adj = 0.0;
         bool emit = true;
         if (P.ch_md[v] <= 1e-8) status = 1;                                                       // callback after the last update
         else {
@@ -1937,18 +1948,32 @@ __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmP
                 for (int a = 0; a < PC; ++a) { e[a] = (a == 1) ? 1.0 : 0.0; g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; }
                 ldl_solve<PC>(H, e);
                 bse1 = sqrt(e[1] / nobs);
+                double gl = 0.0;                                    // g . step over the samples (DIRECT: the log-likelihood's second-order term)
                 ldl_solve<PC>(H, g);
-                double smax = 0.0; bool finite = true;
+                double smax = 0.0, stepmax = 0.0; bool finite = true;
+                if (DIRECT) {
+                    gl = 0.0;
 #pragma unroll
-                for (int a = 0; a < PC; ++a) { smax = fmax(smax, fabs(g[a])); finite = finite && isfinite(g[a]); }
+                    for (int a = 0; a < PC; ++a) {
+                        const double b0 = P.ch_b0[(int64_t)a * Vpad + v], bn = b0 + g[a];
+                        gl = fma(P.ch_g[(int64_t)a * Vpad + v], g[a], gl);
+                        smax = fmax(smax, fabs(bn - beta[a])); stepmax = fmax(stepmax, fabs(g[a])); finite = finite && isfinite(g[a]);
+                        g[a] = bn - beta[a];                        // what is added to beta (= the chord result) below
+                    }
+                    if (stepmax > 2e-4) smax = 1.0;                 // (the chord kernel let <= 1e-4 through; H^-1 g and the chord step differ by << that)
+                } else {
+#pragma unroll
+                    for (int a = 0; a < PC; ++a) { smax = fmax(smax, fabs(g[a])); finite = finite && isfinite(g[a]); }
+                }
                 if (!finite || smax > 5e-7) { emit = false; go_slow = true; if (P.dbg) atomicAdd(&P.dbg[4], 1); }
                 else {
 #pragma unroll
                     for (int a = 0; a < PC; ++a) beta[a] += g[a];
+                    if (DIRECT) llf_adj = 0.5 * gl;
                 }
             }
         }
-        if (emit) glm_emit<Q>(status, bse1, llf, beta, true, v, V, P, out, flags, firth_list, firth_count);
+        if (emit) glm_emit<Q>(status, bse1, P.ch_ll[v] + llf_adj, beta, true, v, V, P, out, flags, firth_list, firth_count);
     }
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
@@ -3229,16 +3254,23 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                                    P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
             }
             for (int r = 0; r < nc; ++r) {
-                if (r == 0) hipLaunchKernelGGL(k_glm_score<Q>, g256, b256, 0, st, T, Vpad, y, W, P, P.ch_list[2 + (r & 1)], cc + r);
+                const int first_ll = (r == 0 && P.ll_first && P.fin_rounds) ? 1 : 0;
+                if (first_ll) hipLaunchKernelGGL(k_glm_ll<Q>, g256, b256, 0, st, T, Vpad, y, P, P.ch_list[2 + (r & 1)], cc + r);
+                else if (r == 0) hipLaunchKernelGGL(k_glm_score<Q>, g256, b256, 0, st, T, Vpad, y, W, P, P.ch_list[2 + (r & 1)], cc + r);
                 else hipLaunchKernelGGL(k_glm_score_split<Q>, grid, dim3(64 * SCORE_SPLIT), 0, st, T, Vpad, P, P.ch_list[2 + (r & 1)], cc + r);
                 hipLaunchKernelGGL(k_glm_chord<Q>, grid, blk, 0, st, Vpad, P, wk, P.ch_list[2 + (r & 1)], cc + r, P.ch_list[2 + ((r + 1) & 1)], cc + r + 1,
-                                   r == nc - 1 ? 1 : 0);
+                                   r == nc - 1 ? 1 : 0, first_ll);
+            }
+            if (P.fin_rounds && P.ll_first) {                        // the variants the first chord round finished: no further likelihood pass
+                if (P.wfp) hipLaunchKernelGGL(k_glm_dpass_pk<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[5], P.ch_cnt + 29);
+                else hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[5], P.ch_cnt + 29);
+                hipLaunchKernelGGL((k_glm_finish<Q, true>), grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[5], P.ch_cnt + 29, out, flags, flist, fcount);
             }
             if (P.fin_rounds) {
                 hipLaunchKernelGGL(k_glm_ll<Q>, g256, b256, 0, st, T, Vpad, y, P, P.ch_list[4], P.ch_cnt + 30);
                 if (P.wfp) hipLaunchKernelGGL(k_glm_dpass_pk<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
                 else hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
-                hipLaunchKernelGGL(k_glm_finish<Q>, grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[4], P.ch_cnt + 30, out, flags, flist, fcount);
+                hipLaunchKernelGGL((k_glm_finish<Q, false>), grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[4], P.ch_cnt + 30, out, flags, flist, fcount);
             }
         } else hipLaunchKernelGGL((k_glm_fast<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
     }

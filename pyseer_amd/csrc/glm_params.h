@@ -44,10 +44,15 @@ struct GlmParams {
     // bd_tab: nibble tables of (w0, w0 z, r0) at the null model (k_glm_bitdot -> ch_bd [Q+2][Vpad]); null_h = (sum w0, sum w0 z_j),
     // null_g = the null model's score (sum r0, sum r0 z_j; ~1e-12), both in the standardised coordinates.
     int chord_on, chord_n32, chord_rounds, fin_rounds;
+    // ll_first (round 3): the FIRST chord round's pass is the exact fp64 likelihood pass (k_glm_ll: ll, separation callback, score) instead of
+    // the score pass, and a variant that leaves the chord rounds there is finished from that pass: ch_b0 = its beta before the chord step,
+    // ch_list[5] + ch_cnt[29] = those variants (k_glm_dpass at the chord result, k_glm_finish<DIRECT>).  One fp64 sample pass per variant less.
+    int ll_first;
+    double *ch_b0;
     double chord_enter, chord_tol;
     double *ch_bs, *ch_fac, *ch_g, *ch_md, *ch_bd, *ch_ll;
     float *ch_hf, *ch_rho;
-    int *ch_list[5], *ch_cnt;
+    int *ch_list[6], *ch_cnt;
     const double *bd_tab;
     const float *wfp, *yf, *w0f;  // packed-fp32 passes (pass32_pk): wfp = per pair of samples a record of Q + 2 float2 (standardised covariates, y, w0;
                                   // each (even sample, odd sample)); yf, w0f = y and w0 as float arrays (the odd last sample); null = unpacked passes
