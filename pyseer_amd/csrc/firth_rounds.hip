@@ -333,7 +333,8 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
 template <int Q>
 __global__ __launch_bounds__(512) void k_firth_step2(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, FirthWork fw,
                                                      const int *__restrict__ step_list, const int *__restrict__ step_count,
-                                                     int *__restrict__ next_eval, int *__restrict__ next_eval_count)
+                                                     int *__restrict__ next_eval, int *__restrict__ next_eval_count,
+                                                     int64_t V, double *__restrict__ out, uint32_t *__restrict__ flags)
 {
     constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2, RS = Q + 1, NL = PC * (PC - 1) / 2;
     const int cnt = *step_count;
@@ -569,7 +570,36 @@ __global__ __launch_bounds__(512) void k_firth_step2(const uint64_t *__restrict_
     double A[NH];
 #pragma unroll
     for (int a = 0; a < NH; ++a) A[a] = fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s];
+    double u0[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) u0[a] = nU[a];
     ldl_solve<PC>(A, nU);                                                      // var_covar_mat . U, model.py:463 (nU = -U)
+    // The fit's LAST likelihood pass, saved.  The reference stops once the PREVIOUS step is below 1e-4 (model.py:477-479), i.e. one iteration
+    // after it could have: the candidate formed here is then the result, a step of ~1e-8 away (quadratic convergence), and the pass over the
+    // samples that would follow only re-evaluates F and I11 there.  Both are known to more digits than the pass delivers: F(beta + d) =
+    // F(beta) - U.d / 2 (U = the penalised score = -grad F, d = V U; third-order terms ~ N |d|^3 < 1e-17), I11(beta + d) = I11(beta) (1 + O(|d|)),
+    // taken from the factor on record (I11 = D1 + L10^2 D0).  With the noise rules the step would be accepted (F does not increase but by rounding);
+    // the literal rule (firth_noise = 0) keeps the pass.
+    if (P.firth_last_taylor && P.firth_noise > 0.0 && fw.iter[s] > 0 && fw.st[(int64_t)fw_snp<PC>() * cap + s] < 1e-4) {
+        double stepmax = 0.0, ud = 0.0; bool fin = true;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) { stepmax = fmax(stepmax, fabs(nU[a])); fin = fin && isfinite(nU[a]); ud = fma(u0[a], nU[a], ud); }
+        if (fin && stepmax <= 1e-7) {
+            const double Fcand = fw.st[(int64_t)fw_fcur<PC>() * cap + s] - 0.5 * ud;
+            const double i11 = fma(A[sidx(1, 0)] * A[sidx(1, 0)], A[sidx(0, 0)], A[sidx(1, 1)]);
+            const double fitll = -Fcand;
+            const double lrstat = -2.0 * (P.null_firth - fitll);
+            double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
+            const double b1 = beta[1] - nU[1];
+            uint32_t fl = flags[v];
+            out[V + v] = pval; out[2 * V + v] = b1; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0] - nU[0];   // bse = sqrt(I11), model.py:491
+#pragma unroll
+            for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j] - nU[2 + j];
+            if (pval > P.lrtt || !isfinite(pval) || !isfinite(b1)) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
+            flags[v] = fl;
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = beta[a] - nU[a];
     next_eval[atomicAdd(next_eval_count, 1)] = s;
@@ -593,7 +623,7 @@ static hipError_t launch_firth2(hipStream_t st, int which, int64_t n, const uint
     else {
         // dynamic LDS: the reduction area of xw_sum, which also carries the factor from wavefront 0 to the others ((NL + PC + 2) x 64 floats)
         const size_t lds = S > 1 ? std::max(glm_split_lds(S), (size_t)(((Q + 2) * (Q + 1) / 2 + Q + 4) * 64 * sizeof(float))) : 0;
-        hipLaunchKernelGGL(k_firth_step2<Q>, grid, blks, lds, st, T, Vpad, P, fw, in_list, in_count, next_eval, next_eval_count);
+        hipLaunchKernelGGL(k_firth_step2<Q>, grid, blks, lds, st, T, Vpad, P, fw, in_list, in_count, next_eval, next_eval_count, V, out, flags);
     }
     return hipGetLastError();
 }
