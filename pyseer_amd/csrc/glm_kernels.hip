@@ -1345,7 +1345,10 @@ __global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, Glm
 #pragma unroll
         for (int a = 0; a < PC; ++a) { beta[a] += g[a]; stp = fmax(stp, fabs(g[a])); finite = finite && isfinite(beta[a]); }
         const bool sep = P.ch_md[v] <= 1e-8;
-        if (finite && !sep && (double)P.ch_rho[v] * stp <= P.chord_tol && P.fin_rounds) {         // done: on to the finishing kernels
+        // (a variant finished from the likelihood pass takes its beta from the exact Newton step there, not from this chord step: the chord result
+        // only says where the information matrix is evaluated, and bse tolerates 6e-7 of distance from the optimum as well as 2.5e-7)
+        const double rs = (double)P.ch_rho[v] * stp;
+        if (finite && !sep && (rs <= P.chord_tol || (first_ll && stp <= 1e-4 && rs <= 2.4 * P.chord_tol)) && P.fin_rounds) {   // done: on to the finishing kernels
             // first_ll: this round's pass was k_glm_ll, so ch_g / ch_ll / ch_md are the exact score, log-likelihood and callback value at the beta
             // that came in.  With a small step that is all the finishing needs (k_glm_finish<Q, true>): the variant skips the final likelihood pass.
             go_direct = first_ll && stp <= 1e-4;
