@@ -1041,9 +1041,13 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
 {
     // the wide kernel's conditions: one limb per block, at least four row tiles (its DMA cursor runs four stages past the stream), 32-bit offsets
     const bool wide_ok = lsplit == L && NR >= 4 && (uint64_t)NR * 2 * (uint64_t)Vpad * 8 < (1ull << 32) && (uint64_t)(L + 1) * NR * (NR + 1) * QF_TILE_BYTES < (1ull << 32);
-    const bool wide_var = variant == 4 || variant == 5 || variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 50 || variant == 441 || variant == 162 || variant == 35;
+    const bool wide_var = variant == 4 || variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 50 || variant == 441 || variant == 162 || variant == 35;
     if (wide_var && !wide_ok) variant = 0;
-    const bool wide = wide_var && wide_ok;                            // 128 x 128 wave tiles, one wavefront per SIMD
+    // the extra-limb pass (variant 64: a launch sized for the whole batch over a short list, `nlimit`) runs the same kernel under its own name
+    // (template argument DM = 3); SEERHIP_QF_REFINE=0 keeps k_lmm_quadform_i8<64>
+    static const bool refine_wide = [] { const char *e = getenv("SEERHIP_QF_REFINE"); return !(e && atoi(e) == 0); }();
+    if (variant == 64 && wide_ok && refine_wide) variant = 464;
+    const bool wide = (wide_var && wide_ok) || variant == 464;       // 128 x 128 wave tiles, one wavefront per SIMD
     // rows_last = valid rows (samples) of the last 128-row tile; the wide kernel contracts only the 32-row sub-tiles that hold any (4, 2, 1, or none:
     // NR = 2 NT may exceed ceil(N / 128) by one).  The int8 MACs actually issued per variant go back to the caller (sh_lmm_info, the bench's roofline).
     const int nit_last = !wide ? 4 : rows_last <= 0 ? 0 : rows_last <= 32 ? 1 : rows_last <= 64 ? 2 : 4;
@@ -1067,7 +1071,7 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8<407>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<0, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lmm_quadform_i8w<16, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1090,8 +1094,8 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
     case 158: hipLaunchKernelGGL(k_lmm_quadform_i8<128>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // no epilogue
     case 286: hipLaunchKernelGGL(k_lmm_quadform_i8<256>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // no zeroing
     case 414: hipLaunchKernelGGL(k_lmm_quadform_i8<384>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit); break;   // neither
+    case 464: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 3>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;   // extra-limb pass
     case 4: hipLaunchKernelGGL(k_lmm_quadform_i8w<0>, g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;        // wide wave tile
-    case 5: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break;    // wide, DMA burst
     case 6: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break; // wide, s_memtime profile
     case 7: hipLaunchKernelGGL((k_lmm_quadform_i8w<0, 0, 2>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break; // wide, s_memtime profile 2
     case 8: hipLaunchKernelGGL((k_lmm_quadform_i8w<16, 0, 1>), g, b, lds, st, G, T, Vpad, NR, L, lsplit, q, nlimit, nit_last); break; // profile, no barrier
