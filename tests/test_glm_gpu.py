@@ -82,6 +82,41 @@ def test_forced_firth_golden(path):
     close(r["pvalue"][ok], want_p, rtol=2e-6, atol=1e-300)
 
 
+@pytest.mark.parametrize("N,q", [(5000, 10), (1500, 6), (900, 0)])
+def test_firth_last_pass_saved_changes_nothing_at_the_bar(N, q, monkeypatch):
+    """Forced Firth (C4's mode): by default k_firth_step2 finishes a fit whose stop rule is already met from the beta before its last candidate
+    (F to second order, I11 from the factor on record) instead of taking the likelihood pass there; SEERHIP_FIRTH_LAST=0 takes the pass.  Same
+    flags, kbeta / intercept / betas identical (the candidate is formed by the same instructions), p-value to 1e-9, bse to 1e-7."""
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(31 + N)
+    V = 512
+    W = rng.standard_normal((N, q)); W /= np.maximum(np.abs(W).max(axis=0), 1e-300) if q else 1.0
+    eta = -0.3 + (1.1 * W[:, 0] - 0.6 * W[:, 1] if q >= 2 else 0.0)
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    af = np.concatenate([rng.uniform(0.03, 0.97, V - V // 6), rng.uniform(0.004, 0.03, V // 6)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K[: V // 8] = (rng.random((V // 8, N)) < (0.2 + 0.5 * y)[None, :]).astype(np.uint8)          # real effects
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    bits = pack_variants(K)
+    out = []
+    for last in ("1", "0"):
+        monkeypatch.setenv("SEERHIP_FIRTH_LAST", last)
+        e = Engine(N); e.set_af_filter(0.01, 0.99); e.glm_setup(y, W, False, nl, nf, force_firth=True); out.append(e.glm_batch(bits)); e.close()
+    monkeypatch.delenv("SEERHIP_FIRTH_LAST")
+    a, b = out
+    assert np.array_equal(a["flags"], b["flags"])
+    ok = np.isfinite(b["kbeta"])
+    assert ok.sum() > V // 2
+    for f in ("kbeta", "intercept"):
+        assert np.array_equal(a[f][ok], b[f][ok]), f
+    if q:
+        assert np.array_equal(a["betas"][ok], b["betas"][ok])
+    close(a["pvalue"][ok], b["pvalue"][ok], rtol=1e-9, atol=1e-300, what="pvalue")
+    close(a["bse"][ok], b["bse"][ok], rtol=1e-7, what="bse")
+
+
 @pytest.mark.parametrize("N,q,V,cont", [(1000, 10, 640, False), (517, 5, 300, False), (800, 7, 256, True), (5000, 10, 192, False)])
 def test_fixed_effects_vs_oracle_random(N, q, V, cont):
     from oracle import oracle as orc
@@ -570,7 +605,10 @@ def test_logistic_fit_paths_agree(N, q, monkeypatch):
               dict(SEERHIP_CHORD_N32="2"),                           # stragglers of the Newton rounds restarted in fp64 (workgroup kernel)
               dict(SEERHIP_CHORD_N32="2", SEERHIP_SLOW="wave"),      # ... by the lane-per-variant kernels
               dict(SEERHIP_BITDOT="0"),                              # first step by a pass, k_glm_final instead of the finishing kernels
-              dict(SEERHIP_FIN_ROUNDS="0"), dict(SEERHIP_PK="0"), dict(SEERHIP_WARM="0"), dict(SEERHIP_NEWTON="1")]
+              dict(SEERHIP_FIN_ROUNDS="0"), dict(SEERHIP_PK="0"), dict(SEERHIP_WARM="0"), dict(SEERHIP_NEWTON="1"),
+              dict(SEERHIP_LL_FIRST="0"),                            # score pass first, likelihood pass last (one more fp64 pass per variant)
+              dict(SEERHIP_LL_FIRST="0", SEERHIP_CHORD_ENTER="5e-2"),
+              dict(SEERHIP_FIRTH_LAST="0")]                          # the routed variants' Firth fits take their last likelihood pass
     for env in routes:
         r = run(**env)
         assert (r["flags"] == base["flags"]).all(), env
