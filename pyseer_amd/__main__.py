@@ -364,7 +364,7 @@ def main(argv=None):
 
     import time as _time
     cli_timing = os.environ.get("SEERHIP_CLI_TIMING") is not None
-    tm = {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter()}
+    tm = {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0}
 
     def sink_block(blk, r):
         nonlocal prefilter, tested, printed
@@ -478,7 +478,13 @@ def main(argv=None):
         if sink_err:
             raise sink_err[0]
 
-    for blk in blocks:
+    blocks = iter(blocks)
+    while True:
+        t_r = _time.perf_counter()
+        blk = next(blocks, None)                          # (waiting here = the reader is the slowest stage)
+        tm["reader"] += _time.perf_counter() - t_r
+        if blk is None:
+            break
         t_e = _time.perf_counter()
         if options.lmm:
             r = eng.lmm_batch(blk.bits) if blk.bits.shape[0] else None
@@ -489,7 +495,9 @@ def main(argv=None):
             if overlap:
                 if sink_err:
                     raise sink_err[0]
-                sink_q.put((blk, r))
+                t_q = _time.perf_counter()
+                sink_q.put((blk, r))                      # (waiting here = the sink is the slowest stage)
+                tm["queue"] += _time.perf_counter() - t_q
             else:
                 sink_block(blk, mask_like_fit_lmm(r) if (options.lmm and r is not None) else r)
             continue
@@ -569,9 +577,9 @@ def main(argv=None):
         loop = _time.perf_counter() - tm["t0"]
         nrows = prefilter + tested
         sys.stderr.write("[cli timing] %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; engine calls (H2D + GPU + D2H) %.2f s, sink (masking, "
-                         "counters, formatting, write) %.2f s of which write %.2f s; sink %s\n"
+                         "counters, formatting, write) %.2f s of which write %.2f s; sink %s; this thread waited %.2f s for the reader and %.2f s for the sink's queue\n"
                          % (tm["blocks"], nrows, loop, nrows / max(loop, 1e-9), tm["engine"], tm["sink"], tm["write"],
-                            "on a worker thread" if overlap else "serial"))
+                            "on a worker thread" if overlap else "serial", tm["reader"], tm["queue"]))
     if patterns is not None:
         patterns.close()
     if cache_out is not None:
