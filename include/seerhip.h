@@ -100,6 +100,15 @@ int sh_lmm_share(sh_ctx *dst, sh_ctx *src);
  * variant that passes the AF filter (the caller applies the NaN masking implied by flags, lmm.py:176-217). */
 int sh_lmm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
                  double *prep, double *pvalue, double *beta, double *bse, double *frac_h2, uint32_t *flags);
+/* Pipelined form of the host-pointer batches (the counterpart of the reference's pool.imap over blocks of variants, pyseer/__main__.py:541-568:
+ * block k+1 is submitted while block k's results are still being produced).  sh_lmm_batch_async / sh_glm_batch_async take the arguments of
+ * sh_lmm_batch / sh_glm_batch, stage all of `bits` (the caller may release it on return) and queue the batch, but return while its LAST
+ * chunk is still on the device: the result arrays of a call are complete when the NEXT sh_*_batch / sh_*_batch_async call on the context
+ * returns (it copies them back after queueing its own first chunk, so the device never idles between calls), or after sh_wait(ctx).
+ * The caller keeps the result arrays alive until then.  Results are bit-identical to the synchronous calls. */
+int sh_lmm_batch_async(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
+                       double *prep, double *pvalue, double *beta, double *bse, double *frac_h2, uint32_t *flags);
+int sh_wait(sh_ctx *ctx);
 /* device-resident variant: d_bits (V*row_bytes bytes), d_out (5*V doubles, SoA in the order above), d_flags (V). */
 int sh_lmm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
 /* introspection for tests/benchmarks: dominant-kernel work of the last batch */
@@ -134,6 +143,9 @@ int sh_glm_setup(sh_ctx *ctx, const double *y, const double *W, int q, int conti
 int sh_glm_batch(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
                  double *prep, double *pvalue, double *kbeta, double *bse, double *intercept,
                  double *betas, uint32_t *flags);
+/* pipelined form: see sh_lmm_batch_async */
+int sh_glm_batch_async(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V,
+                       double *prep, double *pvalue, double *kbeta, double *bse, double *intercept, double *betas, uint32_t *flags);
 /* d_out: (5+q)*V doubles SoA: prep,pvalue,kbeta,bse,intercept,betas[0..q) ; d_flags: V.
  * Device memory: the context keeps per-variant workspaces sized for the largest batch seen (logistic with 1..14 covariates:
  * (3(q+2) + 1.5 (q+2)(q+3)/2 + 6) x 8 bytes per variant, 0.9 GB for 2^20 variants at q = 10); sh_glm_batch cuts host batches into

@@ -225,6 +225,16 @@ def main(argv=None):
             return Engine(n, device=devs[0])
         from .parallel import ShardedEngine                          # one context and one host thread per GPU
         return ShardedEngine(n, devs)
+    import time as _time0
+    t_inputs = _time0.time()
+    since_start = float("nan")
+    try:                                                   # seconds since this process started (field 22 of /proc/self/stat against the uptime)
+        with open("/proc/self/stat") as fh:
+            st_ = fh.read()
+        with open("/proc/uptime") as fh:
+            since_start = float(fh.read().split()[0]) - int(st_[st_.rindex(")") + 2:].split()[19]) / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        pass
     if options.lmm:
         sys.stderr.write("Setting up LMM\n")
         # lineage_samples = p.index as the reference passes it (__main__.py:403, 455-456): a similarity matrix over another set of
@@ -241,6 +251,7 @@ def main(argv=None):
                       np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
                       options.filter_pvalue, options.lrt_pvalue)
 
+    t_setup = _time0.time()
     eng.set_dedup(not options.no_dedup)
     if options.lineage:
         eng.lineage_setup(np.asarray(lineage_clusters, dtype=float), cov.values if cov.shape[1] > 0 else None)
@@ -364,7 +375,7 @@ def main(argv=None):
 
     import time as _time
     cli_timing = os.environ.get("SEERHIP_CLI_TIMING") is not None
-    tm = {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0}
+    tm = {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0, "t0w": _time.time()}
 
     def sink_block(blk, r):
         nonlocal prefilter, tested, printed
@@ -432,8 +443,10 @@ def main(argv=None):
         printed += int(sel.shape[0])
         if sel.shape[0]:
             blob, off = (blk.names_blob, blk.name_off) if getattr(blk, "names_blob", None) is not None else names_blob(blk.names)
+            t_f = _time.perf_counter()
             text = formatter.format_view(blob, off, sel, cols, flags, betas, valid, lineage)
             t_w = _time.perf_counter()
+            tm["format"] += t_w - t_f
             if hasattr(sys.stdout, "buffer"):
                 sys.stdout.flush()
                 sys.stdout.buffer.write(text)
@@ -478,19 +491,8 @@ def main(argv=None):
         if sink_err:
             raise sink_err[0]
 
-    blocks = iter(blocks)
-    while True:
-        t_r = _time.perf_counter()
-        blk = next(blocks, None)                          # (waiting here = the reader is the slowest stage)
-        tm["reader"] += _time.perf_counter() - t_r
-        if blk is None:
-            break
-        t_e = _time.perf_counter()
-        if options.lmm:
-            r = eng.lmm_batch(blk.bits) if blk.bits.shape[0] else None
-        else:
-            r = eng.glm_batch(blk.bits) if blk.bits.shape[0] else None
-        tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
+    def after_engine(blk, r):
+        """Everything that follows a block's engine call: hand it to the sink (array-backed), or build the reference's row objects."""
         if not options.python_sink and not options.print_samples and 2 not in blk.status:
             if overlap:
                 if sink_err:
@@ -500,7 +502,7 @@ def main(argv=None):
                 tm["queue"] += _time.perf_counter() - t_q
             else:
                 sink_block(blk, mask_like_fit_lmm(r) if (options.lmm and r is not None) else r)
-            continue
+            return
         drain_sink()
         if options.lmm and r is not None:
             r = mask_like_fit_lmm(r)
@@ -569,6 +571,43 @@ def main(argv=None):
         for x in rows:
             emit(x)
 
+
+    # The engine calls themselves are pipelined (sh_*_batch_async, include/seerhip.h): a call returns while its last chunk is still on the
+    # device, and that chunk's results arrive while the NEXT call stages and queues its first chunk -- a block is therefore handed on one
+    # iteration late.  Synchronous calls left the device idle for a third of every call (first chunk's staging + upload at the head, the
+    # last chunk's kernels + download at the tail: 12.6 ms per 262 144-row block of which 8 ms were kernels).  SEERHIP_CLI_PIPELINE=0: off.
+    from .engine import Engine as _SingleEngine
+    pipe = isinstance(eng, _SingleEngine) and os.environ.get("SEERHIP_CLI_PIPELINE", "1") != "0"
+    held = None
+    blocks = iter(blocks)
+    while True:
+        t_r = _time.perf_counter()
+        blk = next(blocks, None)                          # (waiting here = the reader is the slowest stage)
+        tm["reader"] += _time.perf_counter() - t_r
+        if blk is None:
+            break
+        t_e = _time.perf_counter()
+        r = None
+        if blk.bits.shape[0]:
+            if pipe:
+                r = eng.lmm_batch(blk.bits, pipelined=True) if options.lmm else eng.glm_batch(blk.bits, pipelined=True)
+            else:
+                r = eng.lmm_batch(blk.bits) if options.lmm else eng.glm_batch(blk.bits)
+        elif pipe and held is not None:
+            eng.wait()
+        tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
+        if pipe:
+            if held is not None:
+                after_engine(*held)                       # complete since the call above returned
+            held = (blk, r)
+        else:
+            after_engine(blk, r)
+    if held is not None:
+        t_e = _time.perf_counter()
+        eng.wait()
+        tm["engine"] += _time.perf_counter() - t_e
+        after_engine(*held)
+
     drain_sink()
     if sink_thread is not None:
         sink_q.put(None)
@@ -577,9 +616,12 @@ def main(argv=None):
         loop = _time.perf_counter() - tm["t0"]
         nrows = prefilter + tested
         sys.stderr.write("[cli timing] %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; engine calls (H2D + GPU + D2H) %.2f s, sink (masking, "
-                         "counters, formatting, write) %.2f s of which write %.2f s; sink %s; this thread waited %.2f s for the reader and %.2f s for the sink's queue\n"
-                         % (tm["blocks"], nrows, loop, nrows / max(loop, 1e-9), tm["engine"], tm["sink"], tm["write"],
+                         "counters, formatting, write) %.2f s of which formatting %.2f s and write %.2f s; sink %s; this thread waited %.2f s for the reader and %.2f s for the sink's queue\n"
+                         % (tm["blocks"], nrows, loop, nrows / max(loop, 1e-9), tm["engine"], tm["sink"], tm["format"], tm["write"],
                             "on a worker thread" if overlap else "serial", tm["reader"], tm["queue"]))
+        sys.stderr.write("[cli timing] before the block loop: %.2f s from process start to the model set-up (interpreter, imports, phenotypes, "
+                         "structure), %.2f s model set-up (kinship cache / null fit, device context, engine set-up), %.2f s to the first block\n"
+                         % (since_start, t_setup - t_inputs, tm["t0w"] - t_setup))
     if patterns is not None:
         patterns.close()
     if cache_out is not None:

@@ -31,6 +31,8 @@ SIGNATURES = {
     "sh_lmm_setup": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_int,
                                C.c_double, C.c_double, C.c_int]),
     "sh_lmm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
+    "sh_lmm_batch_async": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
+    "sh_wait": (C.c_int, [C.c_void_p]),
     "sh_lmm_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "sh_lmm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), c_dp]),
     "sh_lmm_share": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -41,6 +43,7 @@ SIGNATURES = {
     "sh_glm_setup": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int]),
     "sh_glm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
+    "sh_glm_batch_async": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
     "sh_lineage_setup": (C.c_int, [C.c_void_p, c_dp, C.c_int, c_dp, C.c_int]),
     "sh_lineage_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "sh_sim_begin": (C.c_int, [C.c_void_p]),

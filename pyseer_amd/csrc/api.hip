@@ -99,6 +99,11 @@ struct sh_ctx {
     uint8_t *hb_bits[2] = {nullptr, nullptr}; double *hb_out[2] = {nullptr, nullptr}; uint32_t *hb_flags[2] = {nullptr, nullptr};
     int64_t hb_cap_bits = 0, hb_cap_out = 0, hb_cap_flags = 0;
     uint8_t *hp_bits[2] = {nullptr, nullptr}; int64_t hp_cap = 0;     // pinned host staging (pageable user rows are copied in by several threads)
+    // the chunk whose kernels are queued and whose results have not been copied back yet: within a call the previous chunk, across
+    // *_batch_async calls the last chunk of the previous call (its result pointers are the caller's, alive until sh_wait / the next call)
+    struct HostPending { bool valid = false; int b = 0, q = 0; int64_t s = 0, n = 0; double *outs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+                         double *betas = nullptr; uint32_t *flags = nullptr; } pend;
+    uint64_t hb_seq = 0;                                              // chunks queued so far: chunk k uses staging set k & 1
     // ---- staging for the host-pointer entry points
     int64_t cap_bits = 0, cap_out = 0, cap_flags = 0;
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
@@ -155,9 +160,30 @@ static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n)
 // Host-pointer batches, pipelined: the packed rows of chunk i+1 cross PCIe on a copy stream while chunk i runs its kernels
 // on the compute stream (two device staging sets; the results of chunk i-1 are copied back after chunk i has been queued).
 // outs[a] receives row a of the (nrow x V) SoA result; rows >= 5 of the GLM result are delivered row-major through `betas`.
+// With `async` the last chunk is left on the device (c->pend) and copied back by the next call -- after that call has queued its own
+// first chunk, so the device never waits for the host between calls -- or by sh_wait.
+static int drain_pending(sh_ctx *c)
+{
+    if (!c->pend.valid) return SH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const sh_ctx::HostPending p = c->pend;
+    c->pend.valid = false;
+    const int b = p.b;
+    const int64_t s = p.s, n = p.n;
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));      // chunk's results: copy stream, after its kernels (not behind the next chunk's)
+    for (int a = 0; a < 5; ++a)
+        HIPCHK(hipMemcpyAsync(p.outs[a] + s, c->hb_out[b] + (size_t)a * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
+    std::vector<double> tmp;
+    if (p.q > 0) { tmp.resize((size_t)p.q * n); HIPCHK(hipMemcpyAsync(tmp.data(), c->hb_out[b] + (size_t)5 * n, sizeof(double) * p.q * n, hipMemcpyDeviceToHost, c->copy_stream)); }
+    HIPCHK(hipMemcpyAsync(p.flags + s, c->hb_flags[b], sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    for (int j = 0; j < p.q; ++j) for (int64_t v = 0; v < n; ++v) p.betas[(size_t)(s + v) * p.q + j] = tmp[(size_t)j * n + v];
+    return SH_OK;
+}
+
 template <typename F>
 static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, int nrow, double *const *outs, double *betas,
-                      int q, uint32_t *flags, F inner_dev)
+                      int q, uint32_t *flags, bool async, F inner_dev)
 {
     HIPCHK(hipSetDevice(c->device));
     const int64_t CH = 1 << 18;
@@ -167,6 +193,7 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
         for (int b = 0; b < 2; ++b) { HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming)); }
     }
     if (cap * row_bytes > c->hb_cap_bits || cap * nrow > c->hb_cap_out || cap > c->hb_cap_flags) {     // each buffer against its own capacity
+        int rc = drain_pending(c); if (rc) return rc;                  // (the staging sets are about to be replaced)
         const int64_t nb = std::max(cap * row_bytes, c->hb_cap_bits), no = std::max(cap * nrow, c->hb_cap_out), nf = std::max(cap, c->hb_cap_flags);
         for (int b = 0; b < 2; ++b) {
             hipFree(c->hb_bits[b]); hipFree(c->hb_out[b]); hipFree(c->hb_flags[b]);
@@ -176,47 +203,40 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
         c->hb_cap_bits = nb; c->hb_cap_out = no; c->hb_cap_flags = nf;
     }
     if (cap * row_bytes > c->hp_cap) {
+        int rc = drain_pending(c); if (rc) return rc;
         for (int b = 0; b < 2; ++b) { if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]); c->hp_bits[b] = nullptr; HIPCHK(hipHostMalloc((void **)&c->hp_bits[b], cap * row_bytes, hipHostMallocDefault)); }
         c->hp_cap = cap * row_bytes;
     }
-    std::vector<double> tmp;
     // chunk boundaries: a shorter first chunk (2^17) so that the kernels start after 83 MB of upload instead of 166 MB; 2^17 and
     // 2^18 variants are whole numbers of block rounds for the LMM kernel (tiles x 5 limbs on 256 CUs)
     std::vector<int64_t> cut{0};
     for (int64_t step = 1 << 17; cut.back() < V; step = CH) cut.push_back(std::min(V, cut.back() + step));
     const int64_t nchunk = (int64_t)cut.size() - 1;
-    auto drain = [&](int64_t i) -> int {                 // chunk i's results: copy stream, after its kernels (not behind chunk i+1's)
-        const int b = (int)(i & 1);
-        const int64_t s = cut[i], n = cut[i + 1] - s;
-        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
-        for (int a = 0; a < 5; ++a)
-            HIPCHK(hipMemcpyAsync(outs[a] + s, c->hb_out[b] + (size_t)a * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->copy_stream));
-        if (q > 0) { tmp.resize((size_t)q * n); HIPCHK(hipMemcpyAsync(tmp.data(), c->hb_out[b] + (size_t)5 * n, sizeof(double) * q * n, hipMemcpyDeviceToHost, c->copy_stream)); }
-        HIPCHK(hipMemcpyAsync(flags + s, c->hb_flags[b], sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(hipStreamSynchronize(c->copy_stream));
-        for (int j = 0; j < q; ++j) for (int64_t v = 0; v < n; ++v) betas[(size_t)(s + v) * q + j] = tmp[(size_t)j * n + v];
-        return SH_OK;
-    };
     const bool dbg = std::getenv("SEERHIP_HOST_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t00 = now();
     for (int64_t i = 0; i < nchunk; ++i) {
-        const int b = (int)(i & 1);
+        const int b = (int)(c->hb_seq++ & 1);
         const int64_t s = cut[i], n = cut[i + 1] - s;
         const double t0 = now();
-        // staging set b (pinned host + device) is free: chunk i-2 was drained (copy stream synchronised) before this point
+        // staging set b (pinned host + device) is free: the chunk two before this one (of this call or the one before) was drained
+        // (copy stream synchronised) before this point
+        if (c->pend.valid && c->pend.b == b) { int rc = drain_pending(c); if (rc) return rc; }       // (cannot happen while the sets alternate)
         parallel_copy(c->hp_bits[b], bits + s * row_bytes, (size_t)(n * row_bytes));
         const double t1 = now();
         HIPCHK(hipMemcpyAsync(c->hb_bits[b], c->hp_bits[b], n * row_bytes, hipMemcpyHostToDevice, c->copy_stream));
         HIPCHK(hipEventRecord(c->ev_h2d[b], c->copy_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
-        int rc = inner_dev(c->hb_bits[b], n, c->hb_out[b], c->hb_flags[b]); if (rc) return rc;
+        int rc = inner_dev(c->hb_bits[b], n, c->hb_out[b], c->hb_flags[b]);
+        if (rc) { c->pend.valid = false; return rc; }
         HIPCHK(hipEventRecord(c->ev_done[b], c->stream));
         const double t2 = now();
-        if (i >= 1) { rc = drain(i - 1); if (rc) return rc; }
+        rc = drain_pending(c); if (rc) return rc;                      // the chunk before this one
+        c->pend.valid = true; c->pend.b = b; c->pend.q = q; c->pend.s = s; c->pend.n = n; c->pend.betas = betas; c->pend.flags = flags;
+        for (int a = 0; a < 5; ++a) c->pend.outs[a] = outs[a];
         if (dbg) fprintf(stderr, "[host_batch] chunk %lld n=%lld: stage %.2f ms, queue %.2f ms, drain(prev) %.2f ms, t=%.2f\n", (long long)i, (long long)n, t1 - t0, t2 - t1, now() - t2, now() - t00);
     }
-    return drain(nchunk - 1);
+    return async ? SH_OK : drain_pending(c);
 }
 
 static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
@@ -432,6 +452,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (!c || !U || !S || !y || !C) return fail(SH_EINVAL, "null argument");
     if (k < 1 || D < 1) return fail(SH_ESHAPE, "k and D must be >= 1");
     if (h2 < 0.0 || h2 >= 1.0 || std::isnan(h2)) return fail(SH_EH2, "h2 outside [0,1): reference returns no 'beta' (KeyError)");
+    { const int rc0 = drain_pending(c); if (rc0) return rc0; }        // a batch still in flight belongs to the model being replaced
     if (n_limbs == 0) {
         // Automatic limb count: the smallest L in {4, 5} whose TYPICAL a-posteriori bound (an AF-0.5 variant, section 3 of DESIGN.md) is at most a
         // quarter of lmm_tol, so that the extra-limb pass stays the exception; a variant whose own bound exceeds lmm_tol gets the extra limbs
@@ -811,15 +832,34 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
     return SH_OK;
 }
 
-int sh_lmm_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, double *prep, double *pvalue,
-                 double *beta, double *bse, double *frac_h2, uint32_t *flags)
+static int lmm_batch_host(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, double *prep, double *pvalue,
+                          double *beta, double *bse, double *frac_h2, uint32_t *flags, bool async)
 {
     if (!c || !c->lmm_ready) return fail(SH_EINVAL, "sh_lmm_setup has not run");
     if (!bits || !prep || !pvalue || !beta || !bse || !frac_h2 || !flags) return fail(SH_EINVAL, "null argument");
-    if (V <= 0) return SH_OK;
+    if (V <= 0) { HIPCHK(hipSetDevice(c->device)); return drain_pending(c); }      // (an empty batch still completes the one before it)
     double *outs[5] = {prep, pvalue, beta, bse, frac_h2};
-    return host_batch(c, bits, row_bytes, V, 5, outs, nullptr, 0, flags,
+    return host_batch(c, bits, row_bytes, V, 5, outs, nullptr, 0, flags, async,
                       [&](const void *b, int64_t n, void *o, void *f) { return sh_lmm_batch_dev(c, b, row_bytes, n, o, f); });
+}
+
+int sh_lmm_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, double *prep, double *pvalue,
+                 double *beta, double *bse, double *frac_h2, uint32_t *flags)
+{
+    return lmm_batch_host(c, bits, row_bytes, V, prep, pvalue, beta, bse, frac_h2, flags, false);
+}
+
+int sh_lmm_batch_async(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t V, double *prep, double *pvalue,
+                       double *beta, double *bse, double *frac_h2, uint32_t *flags)
+{
+    return lmm_batch_host(c, bits, row_bytes, V, prep, pvalue, beta, bse, frac_h2, flags, true);
+}
+
+int sh_wait(sh_ctx *c)
+{
+    if (!c) return fail(SH_EINVAL, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    return drain_pending(c);
 }
 
 // -------------------------------------------------------------------------------------------------------------

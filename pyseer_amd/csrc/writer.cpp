@@ -9,9 +9,12 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
+#include <algorithm>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -20,40 +23,89 @@
 static const char *const kNotes[9] = {"af-filter", "pre-filtering-failed", "bad-chisq", "high-bse", "perfectly-separable-data",
                                       "matrix-inversion-error", "firth-fail", "missing-data-error", "lrt-filtering-failed"};
 
-// '%.2E' without printf: d.ddE+xx, the correctly rounded 3-significant-digit decimal (round-half-even on the EXACT binary value, as glibc
-// does).  |x| is scaled to [100, 1000) with an 80-bit power of ten and rounded; whenever the scaled value is closer than 1e-6 to a rounding
-// boundary (x.5 ties, which are exactly representable for short decimals such as 1.125, and the 99.9999... / 999.5 edges) the answer is
-// left to snprintf, so the fast path never decides a case its arithmetic could get wrong (relative error of the scaling < 1e-17).
-// snprintf cost 1.2 us per 6-number row: the whole sink ran at 7 M rows/s, below the engine.  Checked against snprintf on 2e8 values
-// (tests/test_sink_cpu.py runs a smaller sweep).
-static long double g_pow10[700];
-static const bool g_pow10_init = [] { for (int k = -345; k < 355; ++k) g_pow10[k + 345] = powl(10.0L, (long double)k); return true; }();
+// '%.2E' without printf and without floating point: d.ddE+xx, the correctly rounded 3-significant-digit decimal (round-half-even on the EXACT
+// binary value, as glibc does).  |x| = m * 2^q (m the 53-bit significand) times 10^(2-e) ~ P * 2^s (P a 64-bit significand, relative error
+// < 2^-62) is one 64 x 64 -> 128-bit product Z; the three digits are Z >> t and the rounding decision is the fraction below them against one
+// half.  Z carries an absolute error below 2^56; whenever the fraction is closer than 2^58 to the half (which includes every exact tie of a
+// short decimal such as 1.125) or to either end, and for subnormals, the answer is left to snprintf, so the fast path never decides a case
+// its arithmetic could get wrong.  History: snprintf cost 1.2 us per 6-number row (the sink ran at 7 M rows/s, below the engine); an 80-bit
+// x87 version of this function 0.5 us; this one ~0.1 us.  tests/test_sink_cpu.py sweeps it against '%.2E'.
+struct Pow10 { uint64_t m; int e; };
+static Pow10 g_pow10[700];
+static double g_pow10d[700];                       // 10^k as a double: the branch-free first guess of the decimal exponent
+static uint32_t g_dig[1000];                       // "d.dd" of 100 .. 999
+static uint64_t g_exp[700]; static uint8_t g_explen[700];   // "E+05" / "E-123" (little-endian bytes) and its length, by e + 345
+static const bool g_pow10_init = [] {
+    for (int k = -345; k < 355; ++k) {
+        int ex; const long double fr = frexpl(powl(10.0L, (long double)k), &ex);        // 10^k = fr * 2^ex, fr in [0.5, 1)
+        g_pow10[k + 345].m = (uint64_t)ldexpl(fr, 64); g_pow10[k + 345].e = ex - 64;
+        g_pow10d[k + 345] = k < -323 ? 0.0 : (k > 308 ? INFINITY : (double)powl(10.0L, (long double)k));
+        char b[8] = {0}; const int n = snprintf(b, sizeof b, "E%c%02d", k < 0 ? '-' : '+', k < 0 ? -k : k);
+        uint64_t v = 0; memcpy(&v, b, 8); g_exp[k + 345] = v; g_explen[k + 345] = (uint8_t)n;
+    }
+    for (int d = 100; d < 1000; ++d) { const char b[4] = {(char)('0' + d / 100), '.', (char)('0' + (d / 10) % 10), (char)('0' + d % 10)}; memcpy(&g_dig[d], b, 4); }
+    return true; }();
 
-static inline void put_num(std::string &s, double x)
+static char *put_num_slow(char *w, double x) { return w + snprintf(w, 32, "%.2E", x); }
+
+// writes at most 16 bytes at w (12 of them text), returns the new end.  The common path has no data-dependent branch: sign, exponent
+// guess, rounding and the digit / exponent text are selects and table stores.
+static inline char *put_num(char *w, double x)
 {
-    if (!std::isfinite(x)) return;
-    char b[40];
-    if (x == 0.0) { s.append(std::signbit(x) ? "-0.00E+00" : "0.00E+00"); return; }
-    const double ax = std::fabs(x);
-    int e2; (void)std::frexp(ax, &e2);
-    int e = (int)std::floor((e2 - 1) * 0.30102999566398120);              // floor(log10) within one
-    long double sc = (long double)ax * g_pow10[(2 - e) + 345];
-    if (sc >= 1000.0L) { ++e; sc = (long double)ax * g_pow10[(2 - e) + 345]; }
-    else if (sc < 100.0L) { --e; sc = (long double)ax * g_pow10[(2 - e) + 345]; }
-    const long double fl = floorl(sc), fr = sc - fl;
-    const bool edge = sc < 100.000001L || sc > 999.499999L || (fr > 0.499999L && fr < 0.500001L) || ax < 1e-300 || e < -340 || e > 340;
-    if (edge) { const int n = snprintf(b, sizeof b, "%.2E", x); s.append(b, (size_t)n); return; }
-    int m = (int)fl + (fr > 0.5L ? 1 : 0);                                 // 100 .. 999 (1000 is an edge case above)
-    char *w = b;
-    if (x < 0) *w++ = '-';
-    *w++ = (char)('0' + m / 100); *w++ = '.'; *w++ = (char)('0' + (m / 10) % 10); *w++ = (char)('0' + m % 10);
-    *w++ = 'E';
-    int ea = e;
-    if (ea < 0) { *w++ = '-'; ea = -ea; } else *w++ = '+';
-    if (ea >= 100) { *w++ = (char)('0' + ea / 100); ea %= 100; }
-    *w++ = (char)('0' + ea / 10); *w++ = (char)('0' + ea % 10);
-    s.append(b, (size_t)(w - b));
+    uint64_t bits; memcpy(&bits, &x, 8);
+    const int be = (int)((bits >> 52) & 0x7ff);
+    if (__builtin_expect(be == 0x7ff, 0)) return w;                                    // nan / inf: empty field
+    const uint64_t frac52 = bits & ((1ull << 52) - 1);
+    if (__builtin_expect(be == 0, 0)) {
+        if (frac52 == 0) { if (bits >> 63) *w++ = '-'; memcpy(w, "0.00E+00", 8); return w + 8; }
+        return put_num_slow(w, x);                                                     // subnormal
+    }
+    const uint64_t m = frac52 | (1ull << 52);
+    const int q = be - 1075;                                                           // |x| = m * 2^q
+    double ax; { const uint64_t ab = bits & ~(1ull << 63); memcpy(&ax, &ab, 8); }
+    int e = ((be - 1023) * 78913) >> 18;                                               // floor((be - 1023) * log10 2): floor(log10 |x|) or one less
+    e += (ax >= g_pow10d[e + 1 + 345]) ? 1 : 0;
+    uint64_t D = 0; unsigned __int128 fr = 0; int t = 0;
+    for (int tries = 0; tries < 3; ++tries) {                                          // (a second turn only next to a power of ten)
+        const Pow10 &p = g_pow10[(2 - e) + 345];
+        const unsigned __int128 Z = (unsigned __int128)m * p.m;                        // |x| * 10^(2 - e) = Z * 2^(q + p.e)
+        t = -(q + p.e);
+        if (__builtin_expect(t < 100 || t > 116, 0)) return put_num_slow(w, x);     // (D in [100, 1000) implies 105 <= t <= 110)
+        const uint64_t hi = (uint64_t)(Z >> 64);
+        D = hi >> (t - 64);
+        fr = Z & ((((unsigned __int128)1) << t) - 1);
+        if (__builtin_expect(D >= 1000, 0)) { ++e; continue; }
+        if (__builtin_expect(D < 100, 0)) { --e; continue; }
+        break;
+    }
+    if (__builtin_expect(D < 100 || D >= 1000, 0)) return put_num_slow(w, x);
+    // the rounding decision on the top 64 bits of the fraction: the error of Z (< 2^56) is < 2^(56 + 64 - t) <= 2^20 units of that 64-bit
+    // fraction at t >= 100; a margin of 2^24 units is kept around one half and at both ends
+    const uint64_t f64 = (uint64_t)(fr >> (t - 64));                                   // fraction as a 64-bit fixed-point number in [0, 1)
+    const uint64_t half = 1ull << 63, margin = 1ull << 24;
+    if (__builtin_expect(f64 < margin || f64 > ~margin || (f64 > half - margin && f64 < half + margin), 0)) return put_num_slow(w, x);
+    int d = (int)D + (int)(f64 >> 63);
+    if (__builtin_expect(d == 1000, 0)) { d = 100; ++e; }
+    *w = '-'; w += bits >> 63;
+    memcpy(w, &g_dig[d], 4); w += 4;
+    memcpy(w, &g_exp[e + 345], 8);
+    return w + g_explen[e + 345];
 }
+
+// one thread's output: a malloc'ed buffer grown by doubling (no zero fill, no per-append capacity check: the row loop asks for a row's
+// upper bound once).  The buffers outlive the call (g_parts): a block's 10 - 20 MB of text would otherwise be page-faulted in afresh on
+// every call, under the process's one mmap lock with all threads at it.
+struct alignas(128) Part {                          // (a cache line pair of its own: the row loop updates n per row)
+    char *p = nullptr; size_t n = 0, cap = 0;
+    ~Part() { free(p); }
+    inline char *room(size_t need) {
+        if (n + need > cap) { cap = std::max(cap * 2, n + need + (1u << 16)); p = (char *)realloc(p, cap); if (!p) abort(); }
+        return p + n;
+    }
+};
+
+static Part g_parts[32];
+static std::mutex g_parts_mutex;
 
 // threads worth starting: the cgroup CPU quota when there is one (a GPU box shows 256 CPUs under a quota of 16; an OpenMP team of 256
 // spinning threads then only steals time from the threads that feed the GPU), at most 32
@@ -84,7 +136,15 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
     int nth = 1;
     nth = format_threads();
     if (nsel < 4096) nth = 1;
-    std::vector<std::string> parts((size_t)nth);
+    size_t lab_max = 2;                                                    // "NA"
+    std::vector<size_t> lab_len((size_t)std::max(n_labels, 0));
+    for (int l = 0; l < n_labels; ++l) { lab_len[(size_t)l] = strlen(lineage_labels[l]); lab_max = std::max(lab_max, lab_len[(size_t)l]); }
+    const size_t fixed = (size_t)(ncol + std::max(q, 0)) * 13 + lab_max + 1 + 160 + 2 + 8;  // all but the name: numbers <= 12 + tab (put_num stores 8 bytes at its tail), notes <= 149
+    std::lock_guard<std::mutex> lock(g_parts_mutex);
+    Part *const parts = g_parts;
+    std::vector<int64_t> start((size_t)nth + 1, 0);
+    int64_t total = 0;
+    bool fits = false;
 #pragma omp parallel num_threads(nth)
     {
         int t = 0;
@@ -92,31 +152,42 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
         t = omp_get_thread_num();
 #endif
         const int64_t lo = nsel * t / nth, hi = nsel * (t + 1) / nth;
-        std::string &s = parts[(size_t)t];
-        s.reserve((size_t)(hi - lo) * 96);
+        Part &s = parts[(size_t)t];
+        s.n = 0;
+        s.room((size_t)(hi - lo) * 96 + fixed);
         for (int64_t r = lo; r < hi; ++r) {
             const int64_t v = sel[r];
-            s.append(names + name_off[v], (size_t)(name_off[v + 1] - name_off[v]));
-            for (int c = 0; c < ncol; ++c) { s.push_back('\t'); put_num(s, cols[c][v]); }
+            const size_t nl = (size_t)(name_off[v + 1] - name_off[v]);
+            char *w = s.room(nl + fixed);
+            memcpy(w, names + name_off[v], nl); w += nl;
+            for (int c = 0; c < ncol; ++c) { *w++ = '\t'; w = put_num(w, cols[c][v]); }
             if (q > 0 && betas_valid[v])
-                for (int j = 0; j < q; ++j) { s.push_back('\t'); put_num(s, betas[(size_t)v * q + j]); }
+                for (int j = 0; j < q; ++j) { *w++ = '\t'; w = put_num(w, betas[(size_t)v * q + j]); }
             if (lineage) {
-                s.push_back('\t');
+                *w++ = '\t';
                 const int32_t l = lineage[v];
-                if (l >= 0 && l < n_labels) s.append(lineage_labels[l]); else s.append("NA");
+                if (l >= 0 && l < n_labels) { memcpy(w, lineage_labels[l], lab_len[(size_t)l]); w += lab_len[(size_t)l]; }
+                else { *w++ = 'N'; *w++ = 'A'; }
             }
-            s.push_back('\t');
-            const uint32_t f = flags[v];
-            bool first = true;
-            for (int b = 0; b < 9; ++b)
-                if ((f >> b) & 1u) { if (!first) s.push_back(','); s.append(kNotes[b]); first = false; }
-            s.push_back('\n');
+            *w++ = '\t';
+            const uint32_t f = flags[v] & 0x1ffu;
+            if (f) {
+                bool first = true;
+                for (int b = 0; b < 9; ++b)
+                    if ((f >> b) & 1u) { if (!first) *w++ = ','; const size_t k = strlen(kNotes[b]); memcpy(w, kNotes[b], k); w += k; first = false; }
+            }
+            *w++ = '\n';
+            s.n = (size_t)(w - s.p);
         }
+#pragma omp barrier
+#pragma omp single
+        {
+            for (int i = 0; i < nth; ++i) start[(size_t)i + 1] = start[(size_t)i] + (int64_t)parts[(size_t)i].n;
+            total = start[(size_t)nth];
+            fits = out && total <= cap;
+        }                                                                  // (implicit barrier)
+        if (fits) memcpy(out + start[(size_t)t], s.p, s.n);               // every thread places its own part
     }
-    int64_t total = 0;
-    for (auto &p : parts) total += (int64_t)p.size();
-    if (!out || total > cap) return -(total + 1);       // caller retries with at least `total` bytes
-    char *w = out;
-    for (auto &p : parts) { memcpy(w, p.data(), p.size()); w += p.size(); }
+    if (!fits) return -(total + 1);                     // caller retries with at least `total` bytes
     return total;
 }

@@ -28,6 +28,7 @@ class Engine(object):
         self.device = int(device)
         self.q = None
         self._keep = []
+        self._inflight = (None,)           # result arrays of pipelined batches the library still writes into
 
     def close(self):
         if getattr(self, "_h", None):
@@ -121,15 +122,29 @@ class Engine(object):
         """Relative bound on x^T K^-1 x above which a variant is contracted again with the extra limbs (include/seerhip.h)."""
         _abi.check(self._lib.sh_set_lmm_tol(self._h, float(tol)))
 
-    def lmm_batch(self, bits):
-        """bits: (V, row_bytes) uint8 host array -> dict of host arrays (raw statistics + flags)."""
+    def lmm_batch(self, bits, pipelined=False):
+        """bits: (V, row_bytes) uint8 host array -> dict of host arrays (raw statistics + flags).
+        pipelined=True (sh_lmm_batch_async): the call returns while the batch's last chunk is still on the device; the arrays of the
+        returned dict are complete once the NEXT lmm_batch call on this engine has returned, or after wait()."""
         bits = self._bits(bits)
         V = bits.shape[0]
         o = np.empty((5, V)); fl = np.empty(V, dtype=np.uint32)           # every element is written by the call
-        if V:
-            _abi.check(self._lib.sh_lmm_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
-                                              _dp(o[2]), _dp(o[3]), _dp(o[4]), fl.ctypes.data_as(_abi.c_u32p)))
+        fn = self._lib.sh_lmm_batch_async if pipelined else self._lib.sh_lmm_batch
+        if V == 0 and pipelined:
+            self.wait()                                                  # an empty block still completes the one before it
+        elif V:
+            if pipelined:
+                self._inflight = (self._inflight[-1], (o, fl))           # the library writes into them after this call has returned
+            _abi.check(fn(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
+                          _dp(o[2]), _dp(o[3]), _dp(o[4]), fl.ctypes.data_as(_abi.c_u32p)))
+            if not pipelined:
+                self._inflight = (None,)                                 # (a synchronous call completes the batch before it too)
         return dict(prep=o[0], pvalue=o[1], beta=o[2], bse=o[3], frac_h2=o[4], flags=fl)
+
+    def wait(self):
+        """Complete the results of the last pipelined batch (sh_wait)."""
+        _abi.check(self._lib.sh_wait(self._h))
+        self._inflight = (None,)
 
     def lmm_batch_dev(self, bits_t, out_t=None, flags_t=None):
         """bits_t: torch uint8 CUDA tensor (V, row_bytes); returns (out (5,V) float64, flags (V,) int32) CUDA tensors."""
@@ -155,15 +170,23 @@ class Engine(object):
         _abi.check(self._lib.sh_glm_setup(self._h, _dp(y), _dp(Wp), self.q, int(bool(continuous)), float(null_llf), nf,
                                           float(pret), float(lrtt), int(bool(force_firth))))
 
-    def glm_batch(self, bits):
+    def glm_batch(self, bits, pipelined=False):
+        """pipelined=True: as lmm_batch (sh_glm_batch_async)."""
         bits = self._bits(bits)
         V = bits.shape[0]; q = self.q
         o = np.empty((5, V)); betas = np.empty((V, max(q, 1))); fl = np.empty(V, dtype=np.uint32)   # all written by the call
         if q == 0:
             betas[:] = np.nan
-        if V:
-            _abi.check(self._lib.sh_glm_batch(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
-                                              _dp(o[2]), _dp(o[3]), _dp(o[4]), _dp(betas), fl.ctypes.data_as(_abi.c_u32p)))
+        fn = self._lib.sh_glm_batch_async if pipelined else self._lib.sh_glm_batch
+        if V == 0 and pipelined:
+            self.wait()
+        elif V:
+            if pipelined:
+                self._inflight = (self._inflight[-1], (o, betas, fl))
+            _abi.check(fn(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], V, _dp(o[0]), _dp(o[1]),
+                          _dp(o[2]), _dp(o[3]), _dp(o[4]), _dp(betas), fl.ctypes.data_as(_abi.c_u32p)))
+            if not pipelined:
+                self._inflight = (None,)
         return dict(prep=o[0], pvalue=o[1], kbeta=o[2], bse=o[3], intercept=o[4], betas=betas[:, :q], flags=fl)
 
     # ---- lineage effect ------------------------------------------------------------------------

@@ -311,6 +311,50 @@ def test_host_batches_longer_than_one_pipeline_chunk(engine_mod):
     e.close()
 
 
+def test_pipelined_host_batches_equal_the_synchronous_ones(engine_mod):
+    """sh_lmm_batch_async / sh_glm_batch_async (include/seerhip.h): a call returns with its last chunk still on the device; its arrays are
+    complete after the next call on the context (pipelined or not) or after sh_wait.  Blocks of several chunk counts in a row, an empty
+    block in between, a synchronous call and a new set-up behind a pending batch: every result bit-identical to the synchronous call's."""
+    Engine, pack = engine_mod
+    N, D = 130, 1
+    U, S, covar, y, _ = _random_lmm(N, D, 5, 8)
+    rng = np.random.default_rng(12)
+    rb = (N + 63) // 64 * 8
+    sizes = [700, (1 << 17) + 5, 0, (1 << 18) + (1 << 17) + 77, 3, 1 << 17]
+    blocks = []
+    for V in sizes:
+        b = rng.integers(0, 256, (V, rb), dtype=np.uint8)
+        b[:, N // 8] &= (1 << (N % 8)) - 1
+        b[:, N // 8 + 1:] = 0
+        blocks.append(b)
+    e = Engine(N)
+    e.lmm_setup(U, S, y, covar, 0.3)
+    want = [e.lmm_batch(b) for b in blocks]
+    got = [e.lmm_batch(b, pipelined=True) for b in blocks]
+    e.wait()
+    for w, g, V in zip(want, got, sizes):
+        for f in ("prep", "pvalue", "beta", "bse", "frac_h2", "flags"):
+            assert g[f].shape[0] == V and np.array_equal(w[f], g[f], equal_nan=True), (f, V)
+    # completion by the next call alone (no wait): the first block's arrays after the second call has returned
+    g0 = e.lmm_batch(blocks[1], pipelined=True)
+    g1 = e.lmm_batch(blocks[0])                                   # a synchronous call completes the pending batch as well
+    for f in ("prep", "pvalue", "beta", "bse", "frac_h2", "flags"):
+        assert np.array_equal(want[1][f], g0[f], equal_nan=True) and np.array_equal(want[0][f], g1[f], equal_nan=True), f
+    # a new model behind a pending batch: the pending results are delivered first
+    g3 = e.lmm_batch(blocks[3], pipelined=True)
+    W = rng.standard_normal((N, 2))
+    e.glm_setup(y, W, False, -80.0, -75.0)
+    for f in ("prep", "pvalue", "beta", "bse", "frac_h2", "flags"):
+        assert np.array_equal(want[3][f], g3[f], equal_nan=True), f
+    wantg = [e.glm_batch(b) for b in blocks]
+    gotg = [e.glm_batch(b, pipelined=True) for b in blocks]
+    e.wait()
+    for w, g in zip(wantg, gotg):
+        for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas", "flags"):
+            assert np.array_equal(w[f], g[f], equal_nan=True), f
+    e.close()
+
+
 def test_fit_lmm_block_drop_in_reads_like_the_reference_test(engine_mod):
     """tests/lmm_test.py:395-420 (TestFitLmmBlock) with pyseer_amd.lmm.fit_lmm_block in place of pyseer.lmm.fit_lmm_block."""
     from pyseer_amd.lmm import fit_lmm_block, LmmState

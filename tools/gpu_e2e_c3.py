@@ -38,10 +38,14 @@ open(d + "/kmers.txt", "w").write("AAAA | sample_00000:1\n")    # the CLI wants 
 print("inputs: %d k-mers x %d samples, cache %.2f GB, written in %.1f s" % (V, N, os.path.getsize(d + "/kmers.seerpack") / 1e9, time.time() - t0))
 del U
 torch.cuda.empty_cache()
-env = dict(os.environ); env["PYTHONPATH"] = ROOT; env["SEERHIP_CLI_TIMING"] = "1"
+env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_CLI_TIMING"] = "1"
 res = {"n_samples": N, "k_mers": V, "block_size": BLK, "cache_GB": os.path.getsize(d + "/kmers.seerpack") / 1e9}
-for name, extra in (("overlapped", []), ("serial", ["--serial-sink"])):
+runs = [("overlapped", [], {}), ("serial", ["--serial-sink"], {})]
+for t in [x for x in os.environ.get("E2E_SINK_THREADS", "").split(",") if x]:   # extra overlapped runs with the sink's OpenMP team capped (a probe, not part of the record)
+    runs.append(("overlapped_omp%s" % t, [], {"OMP_NUM_THREADS": t}))
+for name, extra, more_env in runs:
     out = d + "/out_%s.tsv" % name
+    env = dict(env0); env.update(more_env)
     t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv", "--lmm",
                         "--load-lmm", d + "/lmm.npz", "--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + extra,
