@@ -58,6 +58,10 @@ typedef struct sh_ctx sh_ctx;
 int         sh_abi_version(void);
 const char *sh_last_error(void);
 int         sh_device_count(void);
+/* Start the HIP runtime on `device` and load this library's code object (a no-op launch): about 0.8 s of driver work on first use, which
+ * a caller can run on a side thread while it reads its inputs (the reference has no counterpart: its workers start with the interpreter).
+ * Optional: every other entry point initialises what it needs. */
+int         sh_warmup(int device);
 
 /* one context per device; n_samples = len(p) of the reference */
 sh_ctx *sh_create(int device, int n_samples);

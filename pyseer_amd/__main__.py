@@ -16,6 +16,40 @@ import os
 import sys
 import warnings
 
+
+def _torch_reachable(argv):
+    """torch is used by the command line for one thing: the eigendecomposition of a similarity matrix on the GPU (--lmm without
+    --load-lmm / --cpu-eigh; lmm.spectral_decomposition).  Judged on the raw arguments (argparse accepts unique prefixes), because the
+    device warm-up starts before the options are parsed; main() sets the same flag from the parsed options."""
+    return any(a.startswith("--lm") for a in argv) and not any(a.startswith("--load-l") or a.startswith("--cpu-e") for a in argv)
+
+
+def _warm_device():
+    """sh_warmup on a side thread: the HIP runtime's start (0.8 s at N = 5000's first context) runs while the interpreter imports
+    numpy / pandas and the inputs are read.  Errors are left to the engine, which reports a missing library or device itself."""
+    try:
+        dev = 0
+        for i, a in enumerate(sys.argv[:-1]):
+            if a == "--gpu":
+                dev = int(sys.argv[i + 1])
+        import ctypes
+        from . import _abi
+        _abi.TORCH_FIRST = _torch_reachable(sys.argv)
+        # ctypes.CDLL() holds the GIL through dlopen (the HIP runtime and its dependencies: 0.4 s); dlopen called as a foreign function
+        # does not, and makes the CDLL() that follows a look-up
+        libc = ctypes.CDLL(None)
+        libc.dlopen.restype = ctypes.c_void_p
+        libc.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        libc.dlopen(_abi.LIB_PATH.encode(), os.RTLD_NOW | os.RTLD_GLOBAL)
+        _abi.load().sh_warmup(dev)
+    except Exception:
+        pass
+
+
+if __name__ == "__main__" and "--help" not in sys.argv and "-h" not in sys.argv:
+    import threading
+    threading.Thread(target=_warm_device, daemon=True).start()
+
 import numpy as np
 import pandas as pd
 
@@ -114,6 +148,9 @@ from .model import host_pre_filtering as _host_prefilter
 
 def main(argv=None):
     options = get_options(argv)
+    if __name__ == "__main__":                             # as a program (a caller of main() keeps the library's default: torch first)
+        from . import _abi as _abi_mod
+        _abi_mod.TORCH_FIRST = bool(options.lmm and not options.load_lmm and not options.cpu_eigh)
     if options.vcf or options.burden:
         _die('VCF / burden input needs pysam and is not supported by pyseer_amd\n')
     if options.wg:
@@ -620,8 +657,9 @@ def main(argv=None):
                          % (tm["blocks"], nrows, loop, nrows / max(loop, 1e-9), tm["engine"], tm["sink"], tm["format"], tm["write"],
                             "on a worker thread" if overlap else "serial", tm["reader"], tm["queue"]))
         sys.stderr.write("[cli timing] before the block loop: %.2f s from process start to the model set-up (interpreter, imports, phenotypes, "
-                         "structure), %.2f s model set-up (kinship cache / null fit, device context, engine set-up), %.2f s to the first block\n"
-                         % (since_start, t_setup - t_inputs, tm["t0w"] - t_setup))
+                         "structure), %.2f s model set-up (kinship cache / null fit, device context, engine set-up), %.2f s to the first block; "
+                         "%.2f s from process start to the end of the loop\n"
+                         % (since_start, t_setup - t_inputs, tm["t0w"] - t_setup, since_start + _time.time() - t_inputs))
     if patterns is not None:
         patterns.close()
     if cache_out is not None:

@@ -10,6 +10,8 @@ LIB_PATH = os.environ.get("SEERHIP_LIB") or os.path.join(_HERE, "libseerhip.so")
 
 SH_OK, SH_EINVAL, SH_ENODEV, SH_ENOMEM, SH_EH2, SH_ESHAPE, SH_EHIP = 0, -1, -2, -3, -4, -5, -6
 
+TORCH_FIRST = True
+
 c_dp = C.POINTER(C.c_double)
 c_u8p = C.POINTER(C.c_uint8)
 c_u32p = C.POINTER(C.c_uint32)
@@ -19,6 +21,7 @@ SIGNATURES = {
     "sh_abi_version": (C.c_int, []),
     "sh_last_error": (C.c_char_p, []),
     "sh_device_count": (C.c_int, []),
+    "sh_warmup": (C.c_int, [C.c_int]),
     "sh_create": (C.c_void_p, [C.c_int, C.c_int]),
     "sh_destroy": (None, [C.c_void_p]),
     "sh_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -81,7 +84,10 @@ def load():
         # torch first: libseerhip shares torch's HIP runtime (one libamdhip64 per process), which is what lets the engine
         # run on torch's streams and on torch-allocated HBM.  Loading our library before torch makes torch's later
         # runtime initialisation fail ("no ROCm-capable device").
-        import torch  # noqa: F401
+        # TORCH_FIRST = False (the command line sets it when its options cannot reach torch: anything but a kinship decomposition on the
+        # GPU): skips the 0.6 s import; importing torch afterwards in the same process is then an error the HIP runtime reports itself.
+        if TORCH_FIRST:
+            import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError("libseerhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
                               "There is no CPU fallback." % LIB_PATH)

@@ -343,6 +343,19 @@ int sh_device_count(void)
     return n;
 }
 
+__global__ void k_noop() {}
+
+int sh_warmup(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(SH_ENODEV, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return SH_OK;
+}
+
 sh_ctx *sh_create(int device, int n_samples)
 {
     int n = 0;
