@@ -445,7 +445,7 @@ def main(argv=None):
                 flags[on] = r["flags"][j]
             if not options.lmm and r["betas"].shape[1]:
                 if ident:
-                    betas = np.where(on[:, None], r["betas"], np.nan)
+                    betas = r["betas"]                    # (rows that are not `on` have valid = 0: the formatter never reads their slopes)
                     valid = (on & (np.isfinite(r["kbeta"]) | np.isfinite(r["pvalue"]))).astype(np.uint8)
                 else:
                     betas = np.full((nb, r["betas"].shape[1]), np.nan)
