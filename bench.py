@@ -321,6 +321,30 @@ def lmm_variant_line(U, S, y, C, h2, dev, local, bits, steps, limbs=0, tol=None)
     return res
 
 
+def lmm_host_pointer_line(U, S, y, C, h2, dev, local, bits_t, steps):
+    """The LMM step through the HOST-pointer entry point (sh_lmm_batch_async: pageable numpy rows in, numpy results out, PCIe both ways,
+    calls pipelined as the command line issues them).  Reported beside the line, never as its `value` (inputs resident in HBM)."""
+    import torch
+    from pyseer_amd.engine import Engine
+    N = U.shape[0]
+    eng = Engine(N, device=local)
+    eng.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=1.0, lrt_pvalue=1.0)
+    host = bits_t.cpu().numpy()
+    Vs = host.shape[0]
+    want = eng.lmm_batch(host)                                        # warm-up (staging buffers), and the synchronous call's result
+    t0 = time.perf_counter(); eng.lmm_batch(host); dt_sync = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    got = [eng.lmm_batch(host, pipelined=True) for _ in range(steps)]
+    eng.wait()
+    dt = time.perf_counter() - t0
+    same = all(np.array_equal(want[k], g[k], equal_nan=True) for g in got for k in want)
+    eng.close()
+    return {"value": Vs * steps / dt, "unit": "variants/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "synchronous_call_ms": dt_sync * 1e3,
+            "bytes_per_variant_over_pcie": {"in": int(host.shape[1]), "out": 44}, "identical_to_synchronous_call": bool(same),
+            "what": "sh_lmm_batch_async on host memory (pageable numpy rows -> pinned staging -> HBM, results back to numpy), %d back-to-back "
+                    "calls of %d variants + sh_wait; PCIe-inclusive, not the line's value" % (steps, Vs)}
+
+
 def rel_dev(got, want, floor=1e-300):
     got = np.asarray(got, dtype=float); want = np.asarray(want, dtype=float)
     ok = np.isfinite(want) & np.isfinite(got)
@@ -539,6 +563,7 @@ def main():
                     "C2": fixed_effects_line("C2", dev, local, steps=3, cpu=False, parity=False),
                     "C3_five_limbs": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=5),
                     "C3_all_refined_56bit": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=0, tol=1e-300),
+                    "C3_host_pointers_pcie_inclusive": lmm_host_pointer_line(U, S, y, C, h2, dev, local, bits[0], 4),
                 }
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_lmm(U, S, y, C, h2, N)

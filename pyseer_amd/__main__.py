@@ -47,8 +47,11 @@ def _warm_device():
 
 
 if __name__ == "__main__" and "--help" not in sys.argv and "-h" not in sys.argv:
+    import atexit
     import threading
-    threading.Thread(target=_warm_device, daemon=True).start()
+    _warm_thread = threading.Thread(target=_warm_device, daemon=True)
+    _warm_thread.start()
+    atexit.register(_warm_thread.join, 10.0)               # an early exit (bad options) must not tear the process down under a running dlopen
 
 import numpy as np
 import pandas as pd

@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import pandas as pd
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -109,3 +110,21 @@ def test_cmdscale_matches_the_references_own_vectors():
     Y, e = cmdscale(D.values if hasattr(D, "values") else D)
     assert np.abs(np.abs(Y0) - np.abs(Y[:, :10])).max() < 1e-10
     assert np.abs(e0 - e[:10]).max() < 1e-10
+
+
+def test_placeholder_sequence_and_torch_reachability_rule():
+    """input._Repeat stands for a block's per-row placeholder lists (index, slice, iteration, len); __main__._torch_reachable decides from the raw
+    arguments whether the command line can reach torch (only the kinship decomposition on the GPU does), prefixes as argparse accepts them."""
+    import importlib
+    from pyseer_amd.input import _Repeat
+    r = _Repeat(b'', 5)
+    assert len(r) == 5 and r[0] == b'' and r[-1] == b'' and r[np.int64(3)] == b'' and list(r) == [b''] * 5 and r[1:4] == [b''] * 3
+    with pytest.raises(IndexError):
+        r[5]
+    assert [a for a, _ in zip(r, range(9))] == [b''] * 5
+    m = importlib.import_module("pyseer_amd.__main__")
+    reach = m._torch_reachable
+    assert reach(["prog", "--lmm", "--similarity", "k.tsv"])
+    assert not reach(["prog", "--lmm", "--load-lmm", "c.npz"]) and not reach(["prog", "--lmm", "--load-l", "c.npz"])
+    assert not reach(["prog", "--lmm", "--similarity", "k.tsv", "--cpu-eigh"])
+    assert not reach(["prog", "--kmers", "k.gz", "--no-distances"])
