@@ -615,19 +615,24 @@ def main(argv=None):
     # The engine calls themselves are pipelined (sh_*_batch_async, include/seerhip.h): a call returns while its last chunk is still on the
     # device, and that chunk's results arrive while the NEXT call stages and queues its first chunk -- a block is therefore handed on one
     # iteration late.  Synchronous calls left the device idle for a third of every call (first chunk's staging + upload at the head, the
-    # last chunk's kernels + download at the tail: 12.6 ms per 262 144-row block of which 8 ms were kernels).  SEERHIP_CLI_PIPELINE=0: off.
+    # last chunk's kernels + download at the tail: 12.6 ms per 262 144-row block of which 8 ms were kernels).  The loop also reads one block
+    # ahead and announces its rows to the engine (sh_prefetch_rows).  SEERHIP_CLI_PIPELINE=0: off.
     from .engine import Engine as _SingleEngine
     pipe = isinstance(eng, _SingleEngine) and os.environ.get("SEERHIP_CLI_PIPELINE", "1") != "0"
     held = None
     blocks = iter(blocks)
-    while True:
+    t_r = _time.perf_counter()
+    ahead = next(blocks, None)
+    tm["reader"] += _time.perf_counter() - t_r
+    while ahead is not None:
+        blk = ahead
         t_r = _time.perf_counter()
-        blk = next(blocks, None)                          # (waiting here = the reader is the slowest stage)
+        ahead = next(blocks, None)                        # (waiting here = the reader is the slowest stage)
         tm["reader"] += _time.perf_counter() - t_r
-        if blk is None:
-            break
         t_e = _time.perf_counter()
         r = None
+        if pipe and ahead is not None and ahead.bits.shape[0] and ahead.bits.dtype == np.uint8 and ahead.bits.flags.c_contiguous:
+            eng.prefetch(ahead.bits)                      # block k+1's first chunk goes up while block k is on the device (sh_prefetch_rows)
         if blk.bits.shape[0]:
             if pipe:
                 r = eng.lmm_batch(blk.bits, pipelined=True) if options.lmm else eng.glm_batch(blk.bits, pipelined=True)

@@ -36,6 +36,7 @@ SIGNATURES = {
     "sh_lmm_batch": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
     "sh_lmm_batch_async": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_u32p]),
     "sh_wait": (C.c_int, [C.c_void_p]),
+    "sh_prefetch_rows": (C.c_int, [C.c_void_p, c_u8p, C.c_int64, C.c_int64]),
     "sh_lmm_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "sh_lmm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), c_dp]),
     "sh_lmm_share": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -29,6 +29,7 @@ class Engine(object):
         self.q = None
         self._keep = []
         self._inflight = (None,)           # result arrays of pipelined batches the library still writes into
+        self._announced = (None,)          # rows announced with prefetch(): alive until the batch that consumes them has been called
 
     def close(self):
         if getattr(self, "_h", None):
@@ -140,6 +141,14 @@ class Engine(object):
             if not pipelined:
                 self._inflight = (None,)                                 # (a synchronous call completes the batch before it too)
         return dict(prep=o[0], pvalue=o[1], beta=o[2], bse=o[3], frac_h2=o[4], flags=fl)
+
+    def prefetch(self, bits):
+        """Announce the rows of the batch after the next one (sh_prefetch_rows): call before batch k with block k+1's rows; the library uploads
+        their first chunk while batch k runs.  The SAME array object must then be passed to the batch call (it is kept alive here)."""
+        bits = self._bits(bits)
+        self._announced = (self._announced[-1], bits)       # the one before stays alive until its batch has certainly been called
+        if bits.shape[0]:
+            _abi.check(self._lib.sh_prefetch_rows(self._h, bits.ctypes.data_as(_abi.c_u8p), bits.shape[1], bits.shape[0]))
 
     def wait(self):
         """Complete the results of the last pipelined batch (sh_wait)."""

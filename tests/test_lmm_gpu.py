@@ -352,6 +352,33 @@ def test_pipelined_host_batches_equal_the_synchronous_ones(engine_mod):
     for w, g in zip(wantg, gotg):
         for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas", "flags"):
             assert np.array_equal(w[f], g[f], equal_nan=True), f
+    # rows announced one batch ahead (sh_prefetch_rows: their first chunk is uploaded by the batch before); an announcement that the next
+    # batch does not honour (other rows; the announced array overwritten in place after its upload) must change nothing
+    nz = [b for b in blocks if b.shape[0]]
+    gotp = []
+    for i, b in enumerate(nz):
+        if i + 1 < len(nz):
+            e.prefetch(nz[i + 1])
+        gotp.append(e.glm_batch(b, pipelined=True))
+    e.wait()
+    for w, g in zip([w for w, b in zip(wantg, blocks) if b.shape[0]], gotp):
+        for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas", "flags"):
+            assert np.array_equal(w[f], g[f], equal_nan=True), ("announced", f)
+    e.prefetch(nz[1])
+    a = e.glm_batch(nz[0], pipelined=True)
+    c = e.glm_batch(nz[3], pipelined=True)                         # not the announced rows
+    e.wait()
+    scratch = nz[1].copy()
+    e.prefetch(scratch)
+    e.glm_batch(nz[0], pipelined=True)
+    scratch[:] = nz[4][:1].repeat(scratch.shape[0], axis=0) if nz[4].shape[0] < scratch.shape[0] else nz[4][:scratch.shape[0]]
+    d = e.glm_batch(scratch, pipelined=True)                      # same pointer, other rows than were uploaded
+    e.wait()
+    wd = e.glm_batch(scratch)
+    wn = [w for w, b in zip(wantg, blocks) if b.shape[0]]
+    for f in ("prep", "pvalue", "kbeta", "bse", "intercept", "betas", "flags"):
+        assert np.array_equal(wn[0][f], a[f], equal_nan=True) and np.array_equal(wn[3][f], c[f], equal_nan=True), ("other rows", f)
+        assert np.array_equal(wd[f], d[f], equal_nan=True), ("overwritten", f)
     e.close()
 
 

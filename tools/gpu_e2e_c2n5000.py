@@ -24,7 +24,10 @@ with open(d + "/cov.tsv", "w") as f:
 V = None
 env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_CLI_TIMING"] = "1"
 res = {"n_samples": N, "block_size": BLK, "covariates": 10, "cache_GB": os.path.getsize(src + "/kmers.seerpack") / 1e9}
-for name, extra in (("overlapped", []), ("serial", ["--serial-sink"])):
+runs = [("overlapped", []), ("serial", ["--serial-sink"])]
+if os.environ.get("E2E_EXTRA"):                              # e.g. "--gpus 0,0": a probe, not part of the record
+    runs.append(("overlapped_extra", os.environ["E2E_EXTRA"].split()))
+for name, extra in runs:
     out = d + "/out_%s.tsv" % name
     t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", src + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv", "--no-distances",
