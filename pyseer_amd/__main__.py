@@ -37,10 +37,11 @@ def _warm_device():
         _abi.TORCH_FIRST = _torch_reachable(sys.argv)
         # ctypes.CDLL() holds the GIL through dlopen (the HIP runtime and its dependencies: 0.4 s); dlopen called as a foreign function
         # does not, and makes the CDLL() that follows a look-up
-        libc = ctypes.CDLL(None)
-        libc.dlopen.restype = ctypes.c_void_p
-        libc.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
-        libc.dlopen(_abi.LIB_PATH.encode(), os.RTLD_NOW | os.RTLD_GLOBAL)
+        if not _abi.TORCH_FIRST:                           # (with torch in play its libraries must be loaded first: _abi.load does that)
+            libc = ctypes.CDLL(None)
+            libc.dlopen.restype = ctypes.c_void_p
+            libc.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
+            libc.dlopen(_abi.LIB_PATH.encode(), os.RTLD_NOW)
         _abi.load().sh_warmup(dev)
     except Exception:
         pass
