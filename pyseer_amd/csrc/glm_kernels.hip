@@ -1181,6 +1181,69 @@ __global__ __launch_bounds__(64) void k_glm_solve32(int64_t Vpad, GlmParams P, G
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
 
+// The first Newton step (from the null model, carrier sums instead of a pass: see k_glm_solve32<Q, true>) as a bordered solve.  With the
+// variant's column ordered LAST the leading (Q+1) x (Q+1) block of the matrix is the null model's and the same for every variant: its factor
+// and the constant halves of the solve come from the host (GlmParams.b1), and a variant costs two triangular solves with that factor and
+// one division -- ~160 fp64 FMAs instead of a 12 x 12 factorisation (~450 and 12 divisions, 156 registers of matrix per lane).  Same
+// system, same scaling and ridge; the pivot test applies to the variant's own pivot (its residual against intercept AND covariates).  A
+// first step that is already <= chord_enter (a few % of the variants) takes one more Newton round instead of entering the chord rounds
+// here: those need the factor in the general kernel's order.
+template <int Q>
+__global__ __launch_bounds__(64) void k_glm_first_step(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                       int *__restrict__ next, int *__restrict__ next_cnt)
+{
+    constexpr int M = Q + 1, NL = M * (M + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const double nobs = (double)P.N;
+    const double *__restrict__ L = P.b1, *__restrict__ iD = P.b1 + NL, *__restrict__ yc = iD + M, *__restrict__ xc0 = yc + M;
+    bool go_next = false, go_slow = false;
+    if (on) {
+        double w[M], u[M];
+        const double bd0 = P.ch_bd[v];
+        w[0] = bd0 / nobs;                                             // column of the variant: with the intercept, with covariate j
+#pragma unroll
+        for (int j = 0; j < Q; ++j) w[1 + j] = P.ch_bd[(int64_t)(1 + j) * Vpad + v] / nobs;
+        const double alpha = bd0 / nobs - 1e-10, gk = P.ch_bd[(int64_t)(Q + 1) * Vpad + v] / nobs;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {                                  // w = L^-1 a
+#pragma unroll
+            for (int k = 0; k < i; ++k) w[i] = fma(-L[sidx(i, k)], w[k], w[i]);
+        }
+        double d = alpha, yk = gk;
+#pragma unroll
+        for (int i = 0; i < M; ++i) { u[i] = w[i] * iD[i]; d = fma(-w[i], u[i], d); yk = fma(-u[i], yc[i], yk); }   // l = w / D;  d = alpha - w.l;  y_k = g_k - l.y_c
+        if (d == 0.0 || fabs(d) <= 1e-4 * fabs(alpha) || !isfinite(d)) go_slow = true;
+        else {
+            const double xk = yk / d;
+#pragma unroll
+            for (int i = M - 1; i >= 0; --i) {                         // u = L^-T l
+#pragma unroll
+                for (int k = i + 1; k < M; ++k) u[i] = fma(-L[sidx(k, i)], u[k], u[i]);
+            }
+            double stp = fabs(xk); bool finite = true;
+            {
+                const double b = P.ch_bs[(int64_t)1 * Vpad + v] + xk;
+                finite = finite && isfinite(b);
+                P.ch_bs[(int64_t)1 * Vpad + v] = b;
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) {                              // x_c = x_c0 - x_k u;  row 0 = intercept, rows 2.. = covariates
+                const double x = fma(-xk, u[i], xc0[i]);
+                const int a = i == 0 ? 0 : i + 1;
+                const double b = P.ch_bs[(int64_t)a * Vpad + v] + x;
+                stp = fmax(stp, fabs(x)); finite = finite && isfinite(b);
+                P.ch_bs[(int64_t)a * Vpad + v] = b;
+            }
+            if (!finite) go_slow = true; else go_next = true;
+            (void)stp;
+        }
+    }
+    list_push(go_next, next, next_cnt, (int)v);
+    list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
+}
+
 #ifndef GLM_SCORE_BLOCKS
 #define GLM_SCORE_BLOCKS 1
 #endif
@@ -3240,8 +3303,9 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
             int r0 = 0;
             if (P.bd_tab) {                                          // carrier sums: the first Newton step needs no pass, the finishing rounds use them too
                 hipLaunchKernelGGL(k_glm_bitdot<Q>, g256, b256, 0, st, T, Vpad, P);
-                hipLaunchKernelGGL((k_glm_solve32<Q, true>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1,
-                                   P.ch_list[2], cc, n32 == 1 ? 1 : 0);
+                if (P.b1 && n32 > 1) hipLaunchKernelGGL(k_glm_first_step<Q>, grid, blk, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1);
+                else hipLaunchKernelGGL((k_glm_solve32<Q, true>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1,
+                                        P.ch_list[2], cc, n32 == 1 ? 1 : 0);
                 r0 = 1;
             }
             for (int r = r0; r < n32; ++r) {

@@ -64,6 +64,11 @@ struct GlmParams {
     const float *rec_pf;          // per PAIR of samples Q float2 = (even, odd) standardised covariates: k_firth_step2 (staged through LDS)
     const double *rec_o;          // the same with the covariates as given, y in {0, 1} only: the Firth rounds (info_pass_bin); null = info_pass
     double null_h[16], null_g[16];
+    // the first Newton step as a BORDERED solve (k_glm_first_step): with the variant's column ordered last, the leading (Q+1) x (Q+1) block of
+    // X^T W0 X / n -- intercept and covariates at the null model -- is the same for every variant; its unit-lower factor, the reciprocal
+    // pivots and the constant halves of the solve are computed once on the host.  Layout: L [m(m+1)/2, sidx], 1/D [m], y_c = L^-1 g_c [m],
+    // x_c0 = L^-T (y_c / D) [m], m = Q + 1.  nullptr: the general kernel (k_glm_solve32<Q, true>).
+    const double *b1;
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
 #define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */
