@@ -608,7 +608,9 @@ def test_logistic_fit_paths_agree(N, q, monkeypatch):
               dict(SEERHIP_FIN_ROUNDS="0"), dict(SEERHIP_PK="0"), dict(SEERHIP_WARM="0"), dict(SEERHIP_NEWTON="1"),
               dict(SEERHIP_LL_FIRST="0"),                            # score pass first, likelihood pass last (one more fp64 pass per variant)
               dict(SEERHIP_LL_FIRST="0", SEERHIP_CHORD_ENTER="5e-2"),
-              dict(SEERHIP_FIRTH_LAST="0")]                          # the routed variants' Firth fits take their last likelihood pass
+              dict(SEERHIP_FIRTH_LAST="0"),                          # the routed variants' Firth fits take their last likelihood pass
+              dict(SEERHIP_FIRST_BORDERED="0"),                      # the first Newton step through the general 12 x 12 kernel (product: bordered solve)
+              dict(SEERHIP_FIRST_BORDERED="0", SEERHIP_CHORD_ENTER="5e-2")]
     for env in routes:
         r = run(**env)
         assert (r["flags"] == base["flags"]).all(), env
