@@ -188,6 +188,26 @@ __device__ __forceinline__ void list_push(bool p, int *__restrict__ list, int *_
     if (p) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
+// workgroup-aggregated append: ONE atomic per workgroup.  Every thread of the workgroup must call it (uniform control flow; blockDim.x a
+// multiple of 64, at most 1024); lds = 17 ints of shared memory, free again when the call returns.  With one wavefront per workgroup a
+// 2^20-variant round issues 16 384 same-address atomics per list, and those serialise in the L2: they, not the arithmetic, set the time of
+// the per-variant kernels at N = 1000.
+__device__ __forceinline__ void list_push_block(bool p, int *__restrict__ list, int *__restrict__ count, int v, int *lds)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long m = __ballot(p);
+    if (lane == 0) lds[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < nw; ++i) { const int c = lds[i]; lds[i] = tot; tot += c; }
+        lds[16] = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (p) list[lds[16] + lds[w] + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    __syncthreads();
+}
+
 struct FirthWork {
     double *st;                 // [FW_ND(PC)][cap]
     int *iter, *halv, *var;     // [cap] accepted steps (-1 = initial evaluation pending), halvings of the current step, variant index

@@ -1120,14 +1120,15 @@ __global__ __launch_bounds__(64, PK ? 2 : 3) void k_glm_pass32(const uint64_t *_
 }
 
 template <int Q, bool FIRST>
-__global__ __launch_bounds__(64) void k_glm_solve32(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
-                                                    int *__restrict__ next, int *__restrict__ next_cnt, int *__restrict__ chord, int *__restrict__ chord_cnt,
-                                                    int last_round)
+__global__ __launch_bounds__(256) void k_glm_solve32(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                     int *__restrict__ next, int *__restrict__ next_cnt, int *__restrict__ chord, int *__restrict__ chord_cnt,
+                                                     int last_round)
 {
     constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
-    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    __shared__ int push_lds[17];
+    if ((int64_t)blockIdx.x * 256 >= *cnt) return;                    // (workgroups of four wavefronts: one list atomic per 256 variants, list_push_block)
     int64_t v;
-    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
     const double nobs = (double)P.N;
     bool go_next = false, go_chord = false, go_slow = false;
     if (on) {
@@ -1176,8 +1177,8 @@ __global__ __launch_bounds__(64) void k_glm_solve32(int64_t Vpad, GlmParams P, G
             else go_next = true;
         }
     }
-    list_push(go_next, next, next_cnt, (int)v);
-    list_push(go_chord, chord, chord_cnt, (int)v);
+    list_push_block(go_next, next, next_cnt, (int)v, push_lds);
+    list_push_block(go_chord, chord, chord_cnt, (int)v, push_lds);
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
 
@@ -1189,13 +1190,14 @@ __global__ __launch_bounds__(64) void k_glm_solve32(int64_t Vpad, GlmParams P, G
 // first step that is already <= chord_enter (a few % of the variants) takes one more Newton round instead of entering the chord rounds
 // here: those need the factor in the general kernel's order.
 template <int Q>
-__global__ __launch_bounds__(64) void k_glm_first_step(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
-                                                       int *__restrict__ next, int *__restrict__ next_cnt)
+__global__ __launch_bounds__(256) void k_glm_first_step(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                        int *__restrict__ next, int *__restrict__ next_cnt)
 {
     constexpr int M = Q + 1, NL = M * (M + 1) / 2;
-    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    __shared__ int push_lds[17];
+    if ((int64_t)blockIdx.x * 256 >= *cnt) return;
     int64_t v;
-    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
     const double nobs = (double)P.N;
     const double *__restrict__ L = P.b1, *__restrict__ iD = P.b1 + NL, *__restrict__ yc = iD + M, *__restrict__ xc0 = yc + M;
     bool go_next = false, go_slow = false;
@@ -1240,8 +1242,8 @@ __global__ __launch_bounds__(64) void k_glm_first_step(int64_t Vpad, GlmParams P
             (void)stp;
         }
     }
-    list_push(go_next, next, next_cnt, (int)v);
-    list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
+    list_push_block(go_next, next, next_cnt, (int)v, push_lds);        // (nearly every lane: one atomic per 256 variants)
+    list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);           // (rare: a wavefront without one issues nothing)
 }
 
 #ifndef GLM_SCORE_BLOCKS
@@ -1388,13 +1390,14 @@ __global__ __launch_bounds__(64 * SCORE_SPLIT) void k_glm_score_split(const uint
 }
 
 template <int Q>
-__global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
-                                                  int *__restrict__ next, int *__restrict__ next_cnt, int last_round, int first_ll)
+__global__ __launch_bounds__(256) void k_glm_chord(int64_t Vpad, GlmParams P, GlmWork wk, const int *__restrict__ list, const int *__restrict__ cnt,
+                                                   int *__restrict__ next, int *__restrict__ next_cnt, int last_round, int first_ll)
 {
     constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
-    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    __shared__ int push_lds[17];
+    if ((int64_t)blockIdx.x * 256 >= *cnt) return;
     int64_t v;
-    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 256 + threadIdx.x, v);
     const double nobs = (double)P.N;
     bool go_next = false, go_slow = false, go_fin = false, go_direct = false;
     if (on) {
@@ -1438,10 +1441,10 @@ __global__ __launch_bounds__(64) void k_glm_chord(int64_t Vpad, GlmParams P, Glm
             for (int a = 0; a < PC; ++a) P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
         }
     }
-    list_push(go_next, next, next_cnt, (int)v);
+    list_push_block(go_next, next, next_cnt, (int)v, push_lds);
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
-    list_push(go_fin, P.ch_list[4], P.ch_cnt + 30, (int)v);
-    list_push(go_direct, P.ch_list[5], P.ch_cnt + 29, (int)v);
+    list_push_block(go_fin, P.ch_list[4], P.ch_cnt + 30, (int)v, push_lds);
+    list_push_block(go_direct, P.ch_list[5], P.ch_cnt + 29, (int)v, push_lds);
 }
 
 // ---- sums of per-run vectors over a variant's carriers, by nibble table (the device of k_glm_ols_tab) --------------------------
@@ -3303,8 +3306,8 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
             int r0 = 0;
             if (P.bd_tab) {                                          // carrier sums: the first Newton step needs no pass, the finishing rounds use them too
                 hipLaunchKernelGGL(k_glm_bitdot<Q>, g256, b256, 0, st, T, Vpad, P);
-                if (P.b1 && n32 > 1) hipLaunchKernelGGL(k_glm_first_step<Q>, grid, blk, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1);
-                else hipLaunchKernelGGL((k_glm_solve32<Q, true>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1,
+                if (P.b1 && n32 > 1) hipLaunchKernelGGL(k_glm_first_step<Q>, g256, b256, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1);
+                else hipLaunchKernelGGL((k_glm_solve32<Q, true>), g256, b256, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1,
                                         P.ch_list[2], cc, n32 == 1 ? 1 : 0);
                 r0 = 1;
             }
@@ -3317,7 +3320,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                 }
                 else if (P.wfp) hipLaunchKernelGGL((k_glm_pass32<Q, true>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
                 else hipLaunchKernelGGL((k_glm_pass32<Q, false>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
-                hipLaunchKernelGGL((k_glm_solve32<Q, false>), grid, blk, 0, st, Vpad, P, wk, P.ch_list[r & 1], P.ch_cnt + r, P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1,
+                hipLaunchKernelGGL((k_glm_solve32<Q, false>), g256, b256, 0, st, Vpad, P, wk, P.ch_list[r & 1], P.ch_cnt + r, P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1,
                                    P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
             }
             for (int r = 0; r < nc; ++r) {
@@ -3325,7 +3328,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                 if (first_ll) hipLaunchKernelGGL(k_glm_ll<Q>, g256, b256, 0, st, T, Vpad, y, P, P.ch_list[2 + (r & 1)], cc + r);
                 else if (r == 0) hipLaunchKernelGGL(k_glm_score<Q>, g256, b256, 0, st, T, Vpad, y, W, P, P.ch_list[2 + (r & 1)], cc + r);
                 else hipLaunchKernelGGL(k_glm_score_split<Q>, grid, dim3(64 * SCORE_SPLIT), 0, st, T, Vpad, P, P.ch_list[2 + (r & 1)], cc + r);
-                hipLaunchKernelGGL(k_glm_chord<Q>, grid, blk, 0, st, Vpad, P, wk, P.ch_list[2 + (r & 1)], cc + r, P.ch_list[2 + ((r + 1) & 1)], cc + r + 1,
+                hipLaunchKernelGGL(k_glm_chord<Q>, g256, b256, 0, st, Vpad, P, wk, P.ch_list[2 + (r & 1)], cc + r, P.ch_list[2 + ((r + 1) & 1)], cc + r + 1,
                                    r == nc - 1 ? 1 : 0, first_ll);
             }
             if (P.fin_rounds && P.ll_first) {                        // the variants the first chord round finished: no further likelihood pass
