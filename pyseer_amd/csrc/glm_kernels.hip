@@ -475,7 +475,7 @@ struct GlmWork { double *bw; int *state; int *slow_list; int *slow_count; int *t
 
 // ---- kernel 1: a1 prefilter + routing + phase A (fast Newton) ---------------------------------------------------------------
 template <int Q, bool CHORD>
-__global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
+__global__ __launch_bounds__(CHORD ? 256 : 64, CHORD ? 1 : GLM_FAST_WAVES) void k_glm_fast(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
                                                  const double *__restrict__ y, const double *__restrict__ W,
                                                  const float *__restrict__ Wf,
                                                  const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
@@ -484,7 +484,8 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
                                                  int *__restrict__ firth_list, int *__restrict__ firth_count)
 {
     constexpr int PC = Q + 2;
-    const int64_t v = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t v = (int64_t)blockIdx.x * (CHORD ? 256 : 64) + threadIdx.x;   // (the classifier of the rounds: four wavefronts per workgroup, list_push_block)
+    __shared__ int push_lds[CHORD ? 17 : 1];
     const bool live = v < V;
     const int64_t vr = live ? v : 0;           // dead lanes shadow variant 0 and never write
     const int N = P.N, NB64 = P.NB64;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(64, GLM_FAST_WAVES) void k_glm_fast(const uint64_t 
 #pragma unroll
             for (int a = 0; a < PC; ++a) P.ch_bs[(int64_t)a * Vpad + v] = beta[a];
         }
-        list_push(chord_go, P.ch_list[0], P.ch_cnt, (int)v);
+        list_push_block(chord_go, P.ch_list[0], P.ch_cnt, (int)v, push_lds);
         active = false;
     }
     // Newton's iteration is affine invariant, so this phase runs on covariates standardised per column (Wf and the products table
@@ -3301,8 +3302,8 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
             // counters: ch_cnt[0 .. n32] Newton lists, ch_cnt[n32 + 1 ..] chord lists (zeroed by the caller); lists ping-pong
             const int n32 = P.chord_n32, nc = P.chord_rounds;
             int *cc = P.ch_cnt + n32 + 1;
-            hipLaunchKernelGGL((k_glm_fast<Q, true>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
             const dim3 g256((unsigned)(Vpad / 256)), b256(256);
+            hipLaunchKernelGGL((k_glm_fast<Q, true>), g256, b256, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
             int r0 = 0;
             if (P.bd_tab) {                                          // carrier sums: the first Newton step needs no pass, the finishing rounds use them too
                 hipLaunchKernelGGL(k_glm_bitdot<Q>, g256, b256, 0, st, T, Vpad, P);
