@@ -39,3 +39,7 @@ for i in bad[:12]:
 worst = np.argsort(-np.abs(np.where(firth | ~np.isfinite(want["bse"]), 0, (r["bse"] - want["bse"]) / want["bse"])))[:5]
 for i in worst:
     print("  worst bse row %d: af %.4f kbeta %.6g bse %.9g/%.9g rel %.2e" % (i, K[i].mean(), want["kbeta"][i], r["bse"][i], want["bse"][i], (r["bse"][i] - want["bse"][i]) / want["bse"][i]))
+worst = np.argsort(-np.abs(np.where(firth | ~np.isfinite(want["pvalue"]) | (want["pvalue"] == 0), 0, (r["pvalue"] - want["pvalue"]) / np.maximum(want["pvalue"], 1e-300))))[:5]
+for i in worst:
+    print("  worst p row %d: af %.4f kbeta %.9g/%.9g p %.9g/%.9g rel %.2e" % (i, K[i].mean(), r["kbeta"][i], want["kbeta"][i], r["pvalue"][i], want["pvalue"][i],
+          (r["pvalue"][i] - want["pvalue"][i]) / want["pvalue"][i]))
