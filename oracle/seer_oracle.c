@@ -320,15 +320,39 @@ static void logit_hess_score(const double *X, const double *y, int n, int pc, co
     }
 }
 
+/* numpy's float64 add.reduce over one contiguous run (numpy/core/src/umath/loops_utils.h.src, pairwise_sum): plain loop below 8
+ * elements, eight interleaved partial sums up to 128, recursive halves (first half rounded down to a multiple of 8) above.  The
+ * reference's log-likelihood is np.sum of N logs (SM:discrete/discrete_model.py Logit.loglike); fit_firth's step-halving test
+ * (model.py:467) compares two such sums that differ by less than their rounding noise near convergence, so the ORDER of the sum
+ * decides how often the comparison is a coin flip: with a running sum this restatement reported a spurious `firth-fail` on 26 of
+ * 24 332 forced-Firth rows at N = 5000, the reference itself on none of them (tests/golden/n5000_firth.npz). */
+static double np_pairwise_sum(const double *a, int n)
+{
+    if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8]; int i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 static double logit_loglike(const double *X, const double *y, int n, int pc, const double *beta)
 {
-    double ll = 0;
+    double stack_t[1024], *t = n <= 1024 ? stack_t : (double *)malloc(sizeof(double) * n);
+    stack_t[0] = 0;
     for (int i = 0; i < n; i++) {
         const double *x = X + (size_t)i * pc;
         double eta = 0; for (int a = 0; a < pc; a++) eta += x[a] * beta[a];
         double q = 2 * y[i] - 1;
-        ll += log(logit_cdf(q * eta));          /* SM Logit.loglike: sum(log(cdf(q*Xb))) */
+        t[i] = log(logit_cdf(q * eta));         /* SM Logit.loglike: sum(log(cdf(q*Xb))) */
     }
+    double ll = np_pairwise_sum(t, n);
+    if (t != stack_t) free(t);
     return ll;
 }
 

@@ -25,3 +25,19 @@ def firth_rows_close(got, variants, field, rows, rtol=1e-6):
             near |= (np.isnan(g) & np.isnan(w)) | (np.abs(g - w) <= rtol * np.abs(w) + FA)
     ok = same | (sens & near)
     return ok, int((~same & sens & near).sum())
+
+
+def golden_firth_rows_close(got, golden, variants, field, rows, rtol=1e-6):
+    """The same rule against numbers the REFERENCE produced: `golden` over all rows, `variants` the oracle's answers under the tie detector's
+    settings (only used to tell whether the row's halving test sits on rounding noise), `rows` the Firth-routed rows to hold.  A row passes at
+    rtol with no slack, or -- only if the detector fires on it -- at rtol + FA.  Returns (ok mask over rows, rows that needed the detector)."""
+    g = np.asarray(got, dtype=float)[rows]; w = np.asarray(golden, dtype=float)[rows]
+    base = np.asarray(variants[0][field], dtype=float)[rows]
+    with np.errstate(invalid="ignore"):
+        same = (np.isnan(g) & np.isnan(w)) | (np.abs(g - w) <= rtol * np.abs(w) + TINY)
+        sens = np.zeros(g.shape, dtype=bool)
+        for v in variants[1:]:
+            x = np.asarray(v[field], dtype=float)[rows]
+            sens |= ~((np.isnan(x) & np.isnan(base)) | (np.abs(x - base) <= 1e-9 * np.abs(base) + 1e-13))
+        near = (np.isnan(g) & np.isnan(w)) | (np.abs(g - w) <= rtol * np.abs(w) + FA)
+    return same | (sens & near), int((~same & sens & near).sum())
