@@ -39,6 +39,108 @@ PROFILE_DIRS = ("r03", "r02", "r01")      # committed rocprofv3 summaries, newes
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# clock and board power over the timed region (round-3 review, item 8): boxes of the pool differ by 10 % on the same binary, and the
+# kernel runs into the chip's clock management, so the line says at what clock its fraction was measured
+# ---------------------------------------------------------------------------------------------------------------
+class ClockSampler(object):
+    """Samples the amdgpu hwmon files of one device from a side thread every `period` seconds: freq1_input (sclk, Hz) and power1_average /
+    power1_input (microwatts).  Reading sysfs does not touch the GPU's queues.  Everything is best effort: a box without the files gives
+    nulls, never an error."""
+
+    def __init__(self, torch_index=0, period=0.004):
+        import glob
+        self.period = period
+        self.f_clk = self.f_pow = None
+        self.clk, self.pow = [], []
+        self._stop = False
+        self._thread = None
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            if hw:
+                cards.append((os.path.realpath(dev), hw[0]))
+        if not cards:
+            return
+        pick = cards[min(torch_index, len(cards) - 1)]
+        try:                                               # match torch's device by PCI address where torch exposes it
+            import torch
+            pr = torch.cuda.get_device_properties(torch_index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            for c in cards:
+                if want in c[0]:
+                    pick = c
+        except Exception:
+            pass
+        self.source = pick[1]
+        f = os.path.join(pick[1], "freq1_input")
+        self.f_clk = f if os.path.exists(f) else None
+        for nm in ("power1_average", "power1_input"):
+            f = os.path.join(pick[1], nm)
+            if os.path.exists(f):
+                self.f_pow = f
+                break
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            if self.f_clk:
+                v = self._read(self.f_clk)
+                if v is not None:
+                    self.clk.append(v)
+            if self.f_pow:
+                v = self._read(self.f_pow)
+                if v is not None:
+                    self.pow.append(v)
+            time.sleep(self.period)
+
+    def start(self):
+        import threading
+        self.clk, self.pow, self._stop = [], [], False
+        if self.f_clk or self.f_pow:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        out = {"sclk_mhz_mean": None, "sclk_mhz_min": None, "power_w_mean": None, "power_w_max": None, "clock_samples": len(self.clk),
+               "clock_source": ("sysfs hwmon freq1_input / %s, sampled every %.0f ms over the timed region" %
+                                (os.path.basename(self.f_pow) if self.f_pow else "-", self.period * 1e3)) if (self.f_clk or self.f_pow) else None}
+        if self.clk:
+            out["sclk_mhz_mean"] = float(np.mean(self.clk)) / 1e6; out["sclk_mhz_min"] = float(np.min(self.clk)) / 1e6
+        if self.pow:
+            out["power_w_mean"] = float(np.mean(self.pow)) / 1e6; out["power_w_max"] = float(np.max(self.pow)) / 1e6
+        return out
+
+
+NOMINAL_SCLK_MHZ = 2400.0          # the clock the guide's peaks are quoted at (MI355X_MICROARCH.md)
+
+
+def with_clock(roof, clocks):
+    """roofline dict + the sampled clock / power, and the same fraction against the peak AT THE CLOCK THE CHIP GRANTED (frac itself stays
+    against the nominal-clock peak): two boxes that differ only in their power management then show the same frac_at_measured_clock."""
+    out = dict(roof, **clocks)
+    if clocks.get("sclk_mhz_mean"):
+        out["frac_at_measured_clock"] = roof["frac"] * NOMINAL_SCLK_MHZ / clocks["sclk_mhz_mean"]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # synthetic workloads (SURVEY.md section 8d); tests/test_bench_inputs_gpu.py runs the oracle on exactly these
 # ---------------------------------------------------------------------------------------------------------------
 def synth_lmm_inputs(N, seed, device):
@@ -268,16 +370,18 @@ def fixed_effects_line(cfg, dev, local, steps=5, warmup=1, Vs=None, cpu=True, pa
         eng.glm_batch_dev(bits[i % nb], out, fl)
     torch.cuda.synchronize()
     eng.set_timing(True)
+    sampler = ClockSampler(local).start()
     t0 = time.perf_counter()
     for i in range(steps):
         eng.glm_batch_dev(bits[(warmup + i) % nb], out, fl)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    clocks = sampler.stop()
     kms, klaunch = eng.get_timing()
     kern_s = kms / max(klaunch, 1) * 1e-3
     metric, dtype = glm_metric(cfg, N)
     res = {"metric": metric, "value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-           "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), "roofline": glm_roofline(cfg, q, Vs, kern_s, klaunch, rb)}
+           "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), "roofline": with_clock(glm_roofline(cfg, q, Vs, kern_s, klaunch, rb), clocks)}
     if env:
         res["env"] = dict(env)
     if parity:
@@ -485,6 +589,7 @@ def main():
     if world > 1:
         dist.barrier()
     eng.set_timing(True)
+    sampler = ClockSampler(local).start() if rank == 0 else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -493,6 +598,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt_local = time.perf_counter() - t0
+    clocks = sampler.stop() if sampler is not None else {}
     dt = dt_local
     kms, klaunch = eng.get_timing()
     if not lmm and os.environ.get("SEERHIP_GLM_DEBUG"):
@@ -536,14 +642,14 @@ def main():
                 "config": {"workload": "C3: LMM (FaST-LMM per-variant test), %d synthetic k-mers x %d samples per step per GPU, "
                                        "D=1, k=%d, h2=%.4f, inputs resident in HBM" % (Vs, N, U.shape[1], h2),
                            "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"},
-                "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                "roofline": with_clock({"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                              "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                              "traffic_source": traffic_src,
                              "kernel": "k_lmm_quadform_i8w", "kernel_ms": kern_s * 1e3, "launches": klaunch,
                              "ops": "int8 multiply-adds x2 actually issued per variant (sh_lmm_info) x variants per launch",
                              "int8_macs_per_variant": info["int8_macs_per_variant"],
                              "fp64_equiv_tflops": FP64_FLOP_PER_TEST * Vs / kern_s / 1e12,
-                             "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9},
+                             "hbm_algorithmic_GBps": ALGO_BYTES_PER_TEST * Vs / kern_s / 1e9}, clocks),
                 "error_bound": {k: info[k] for k in ("quant_err_norm", "quant_err_norm_power_iteration", "quant_err_norm_squarings", "bound_rel_typical",
                                                      "refined_last_batch") if k in info},
             })
@@ -571,7 +677,7 @@ def main():
             force = cfg == "C4"
             metric, dtype = glm_metric(cfg, N)
             res.update({"metric": metric, "dtype": dtype, "config": glm_workload(cfg, Vs, N, q),
-                        "roofline": glm_roofline(cfg, q, Vs, kern_s, klaunch, rb)})
+                        "roofline": with_clock(glm_roofline(cfg, q, Vs, kern_s, klaunch, rb), clocks)})
             if not args.no_parity:
                 n, devs = parity_glm(y, W, nl, nf, force, last, out, fl, N)
                 res["parity_checked"] = n; res["parity_max_rel_dev"] = devs

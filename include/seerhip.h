@@ -116,8 +116,9 @@ int sh_wait(sh_ctx *ctx);
 /* Announce the rows of the batch AFTER the next one: called before batch k with the `bits` of batch k+1 (same row_bytes), it lets batch k's
  * copy thread upload the first chunk of batch k+1 while batch k's last chunk runs, so that batch k+1 starts on the device at once (the
  * fixed-effects launch code blocks on its read-backs: without the announcement every call exposes its first upload, 2.8 of 12 ms per 262 144
- * rows).  `bits` must stay valid until batch k+1 has been called with exactly this pointer; a batch called with other rows ignores the
- * announcement.  Optional; results do not depend on it. */
+ * rows).  `bits` must stay valid AND UNCHANGED until batch k+1 has been called with exactly this pointer (the rows may be uploaded at any
+ * time in between; the call only probes two 4 KiB windows of them before it trusts the early upload); a batch called with other rows
+ * ignores the announcement, and so does anything after sh_*_setup or sh_set_stream.  Optional; results do not depend on it. */
 int sh_prefetch_rows(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int64_t V);
 /* device-resident variant: d_bits (V*row_bytes bytes), d_out (5*V doubles, SoA in the order above), d_flags (V). */
 int sh_lmm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);

@@ -37,6 +37,7 @@ def lib():
         L.orc_firth_likelihood.restype = C.c_double
         L.orc_set_firth_tie.restype = None; L.orc_set_firth_tie.argtypes = [C.c_double]
         L.orc_set_firth_accept_below.restype = None; L.orc_set_firth_accept_below.argtypes = [C.c_double]
+        L.orc_set_firth_conv_scale.restype = None; L.orc_set_firth_conv_scale.argtypes = [C.c_double]
         L.orc_lmm_create.restype = C.c_void_p
         L.orc_lmm_nll.restype = C.c_double
         L.orc_lmm_nll.argtypes = [C.c_void_p, C.c_double]
@@ -112,19 +113,27 @@ def set_firth_accept_below(eps=0.0):
     lib().orc_set_firth_accept_below(C.c_double(eps))
 
 
-FIRTH_NOISE_VARIANTS = [(0.0, 0.0), (2e-13, 0.0), (-2e-13, 0.0), (0.0, 1e-10), (2e-13, 1e-10), (-2e-13, 1e-10)]
+def set_firth_conv_scale(s=1.0):
+    """Test-only: fit_firth's convergence_limit times s (1 = the reference).  Recognises fits whose stop rule (model.py:477) is decided within
+    1e-8 of the limit while the iteration still moves beta by ~1e-4 per step (linear convergence, ratio near -1)."""
+    lib().orc_set_firth_conv_scale(C.c_double(s))
+
+
+FIRTH_NOISE_VARIANTS = [(0.0, 0.0, 1.0), (2e-13, 0.0, 1.0), (-2e-13, 0.0, 1.0), (0.0, 1e-10, 1.0), (2e-13, 1e-10, 1.0), (-2e-13, 1e-10, 1.0),
+                        (0.0, 0.0, 1.0 + 1e-4), (0.0, 0.0, 1.0 - 1e-4)]
 
 
 def firth_noise_variants(fn):
-    """[fn() under each (tie, accept_below) setting]: the answers the reference can legitimately give for a Firth fit whose
-    step-halving comparisons sit on last-bit ties. The first entry is the reference's behaviour exactly."""
+    """[fn() under each (tie, accept_below, conv_scale) setting]: the answers the reference can legitimately give for a Firth fit whose
+    step-halving comparisons sit on last-bit ties, or whose stop rule is met within 1e-8 of the limit. The first entry is the reference's
+    behaviour exactly."""
     out = []
-    for tie, eps in FIRTH_NOISE_VARIANTS:
-        set_firth_tie(tie); set_firth_accept_below(eps)
+    for tie, eps, cs in FIRTH_NOISE_VARIANTS:
+        set_firth_tie(tie); set_firth_accept_below(eps); set_firth_conv_scale(cs)
         try:
             out.append(fn())
         finally:
-            set_firth_tie(0.0); set_firth_accept_below(0.0)
+            set_firth_tie(0.0); set_firth_accept_below(0.0); set_firth_conv_scale(1.0)
     return out
 
 

@@ -24,17 +24,33 @@ def _torch_reachable(argv):
     return any(a.startswith("--lm") for a in argv) and not any(a.startswith("--load-l") or a.startswith("--cpu-e") for a in argv)
 
 
+def _first_device(argv):
+    """The device the run will use first, from the raw arguments: `--gpu N`, `--gpu=N`, `--gpus a,b,...` / `--gpus=a,b` (first listed) or
+    `--gpus N` (a count: device 0).  Anything unreadable warms device 0 -- a context on a device the run does not use is the cost."""
+    dev = 0
+    for i, a in enumerate(argv):
+        key, _, val = a.partition("=")
+        if key not in ("--gpu", "--gpus"):
+            continue
+        if not val and i + 1 < len(argv):
+            val = argv[i + 1]
+        try:
+            if key == "--gpu":
+                dev = int(val)
+            else:
+                dev = int(val.split(",")[0]) if "," in val else 0
+        except ValueError:
+            pass
+    return dev
+
+
 def _warm_device():
     """sh_warmup on a side thread: the HIP runtime's start (0.8 s at N = 5000's first context) runs while the interpreter imports
     numpy / pandas and the inputs are read.  Errors are left to the engine, which reports a missing library or device itself."""
     try:
-        dev = 0
-        for i, a in enumerate(sys.argv[:-1]):
-            if a == "--gpu":
-                dev = int(sys.argv[i + 1])
+        dev = _first_device(sys.argv)
         import ctypes
         from . import _abi
-        _abi.TORCH_FIRST = _torch_reachable(sys.argv)
         # ctypes.CDLL() holds the GIL through dlopen (the HIP runtime and its dependencies: 0.4 s); dlopen called as a foreign function
         # does not, and makes the CDLL() that follows a look-up
         if not _abi.TORCH_FIRST:                           # (with torch in play its libraries must be loaded first: _abi.load does that)
@@ -50,6 +66,10 @@ def _warm_device():
 if __name__ == "__main__" and "--help" not in sys.argv and "-h" not in sys.argv:
     import atexit
     import threading
+    from . import _abi as _abi0
+    # written once, on this thread, before the warm-up thread exists and before anyone loads the library; main() reads it back and, should
+    # the parsed options disagree with this reading of the raw arguments, decomposes on the CPU rather than import torch after libseerhip
+    _abi0.TORCH_FIRST = _torch_reachable(sys.argv)
     _warm_thread = threading.Thread(target=_warm_device, daemon=True)
     _warm_thread.start()
     atexit.register(_warm_thread.join, 10.0)               # an early exit (bad options) must not tear the process down under a running dlopen
@@ -116,8 +136,9 @@ def get_options(argv=None):
     ot.add_argument('--cpu', type=int, default=1, help='Accepted for compatibility; the tests run on the GPU')
     ot.add_argument('--block_size', type=int, default=3000, help='Number of variants parsed and sent to the GPU at a time')
     ot.add_argument('--gpu', type=int, default=0, help='GPU index [Default: 0]')
-    ot.add_argument('--gpus', default=None, help='Comma-separated GPU indices, or a count N (= 0..N-1): every block of variants is '
-                    'split into contiguous shards, one per GPU, results keep the input order [Default: the single --gpu]')
+    ot.add_argument('--gpus', default=None, help='Comma-separated GPU indices, or a count N (= 0..N-1): the variant stream is sharded across them. '
+                    'From a packed cache every GPU tests its own contiguous range of the rows through its own pipeline; other input is one stream '
+                    'whose blocks go to the GPUs in turn. Output keeps the input order [Default: the single --gpu]')
     ot.add_argument('--save-packed', default=None,
                     help='Also write the parsed k-mer file as packed bit rows (for --load-packed in later runs over the same samples)')
     ot.add_argument('--packed-cache', action='store_true', default=False,
@@ -154,7 +175,11 @@ def main(argv=None):
     options = get_options(argv)
     if __name__ == "__main__":                             # as a program (a caller of main() keeps the library's default: torch first)
         from . import _abi as _abi_mod
-        _abi_mod.TORCH_FIRST = bool(options.lmm and not options.load_lmm and not options.cpu_eigh)
+        if bool(options.lmm and not options.load_lmm and not options.cpu_eigh) and not _abi_mod.TORCH_FIRST:
+            # (the raw-argument reading missed that this run decomposes a kinship matrix: libseerhip may already be loaded without torch's
+            # HIP runtime underneath it, and importing torch now would break the device for both)
+            sys.stderr.write("pyseer_amd: kinship decomposition on the CPU (numpy) for this run\n")
+            options.cpu_eigh = True
     if options.vcf or options.burden:
         _die('VCF / burden input needs pysam and is not supported by pyseer_amd\n')
     if options.wg:
@@ -258,14 +283,13 @@ def main(argv=None):
 
     from .engine import Engine
 
-    def make_engine(n):
+    def make_engines(n):
+        """One context per listed device; the same device may be listed twice (two contexts on one GPU: the test of
+        the multi-device job path on a one-GPU box)."""
         if options.gpus is None:
-            return Engine(n, device=options.gpu)
+            return [Engine(n, device=options.gpu)]
         devs = [int(x) for x in options.gpus.split(",")] if "," in options.gpus else list(range(int(options.gpus)))
-        if len(devs) == 1:
-            return Engine(n, device=devs[0])
-        from .parallel import ShardedEngine                          # one context and one host thread per GPU
-        return ShardedEngine(n, devs)
+        return [Engine(n, device=d) for d in devs]
     import time as _time0
     t_inputs = _time0.time()
     since_start = float("nan")
@@ -284,23 +308,32 @@ def main(argv=None):
                                     lineage_samples=(p.index if options.lineage else None),
                                     use_gpu=not options.cpu_eigh, device=options.gpu)
         sys.stderr.write("h^2 = " + '{0:.2f}'.format(h2) + "\n")
-        eng = make_engine(len(p))
-        eng.lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)
+        engs = make_engines(len(p))
+        # the first context builds the per-run state (M = U~ diag(1/Sd) U~^T, limbs, tables); the others receive it device to device
+        # (sh_lmm_share: 94 MB at N = 5000) instead of each re-deriving it from the host copy of U
+        engs[0].lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)
+        for e_ in engs[1:]:
+            e_.lmm_share_from(engs[0])
     else:
-        eng = make_engine(len(p))
-        eng.glm_setup(p.values, covariate_block(len(p), m, cov), options.continuous,
-                      np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
-                      options.filter_pvalue, options.lrt_pvalue)
+        engs = make_engines(len(p))
+        for e_ in engs:
+            e_.glm_setup(p.values, covariate_block(len(p), m, cov), options.continuous,
+                         np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
+                         options.filter_pvalue, options.lrt_pvalue)
 
     t_setup = _time0.time()
-    eng.set_dedup(not options.no_dedup)
-    if options.lineage:
-        eng.lineage_setup(np.asarray(lineage_clusters, dtype=float), cov.values if cov.shape[1] > 0 else None)
+    for e_ in engs:
+        e_.set_dedup(not options.no_dedup)
+        if options.lineage:
+            e_.lineage_setup(np.asarray(lineage_clusters, dtype=float), cov.values if cov.shape[1] > 0 else None)
     if not options.lineage:
         lineage_dict = None
 
     all_strains = set(p.index)
     kmer_files = list(options.kmers) if options.kmers else []
+    if options.load_packed and options.save_packed and os.path.realpath(options.load_packed) == os.path.realpath(options.save_packed):
+        # (the cache is memory-mapped while it is read: rewriting it under the mapping would end the run with SIGBUS)
+        _die('--save-packed and --load-packed name the same file\n')
     if len(kmer_files) > 1 and (options.python_reader or options.load_packed or options.save_packed or options.packed_cache):
         _die('Several --kmers files need the native reader and cannot be combined with a packed cache\n')
     var_type, var_file = ("kmers", kmer_files[0]) if kmer_files else ("Rtab", options.pres)
@@ -308,7 +341,8 @@ def main(argv=None):
     if native or options.load_packed:
         # blocks of the native reader / the packed cache hand every parsed row to the engine (input.py _block_from_raw): the AF window is applied
         # on the device as well, so filtered rows are neither copied out on the host nor contracted on the GPU
-        eng.set_af_filter(options.min_af, options.max_af)
+        for e_ in engs:
+            e_.set_af_filter(options.min_af, options.max_af)
     if native and not options.uncompressed and not options.load_packed:
         for vf in (kmer_files or [var_file]):
             with open(vf, "rb") as fh:                     # the reference's gzip.open raises on plain text (input.py:271-276)
@@ -336,26 +370,8 @@ def main(argv=None):
     print('\t'.join(header))
 
     model = 'lmm' if options.lmm else 'seer'
-    prefilter = tested = printed = 0
     pv = p.values.astype(float)
     nan = np.nan
-    out = sys.stdout
-
-    def emit(x):
-        nonlocal prefilter, tested, printed
-        if x.prefilter:
-            prefilter += 1
-            if options.print_filtered:
-                printed += 1
-                out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
-            return
-        tested += 1
-        if patterns is not None:
-            patterns.write(x.pattern)
-        if x.filter and not options.print_filtered:
-            return
-        printed += 1
-        out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
 
     cache_out, cache_stamp = None, None
     if options.packed_cache and native and not options.load_packed and not options.save_packed:
@@ -410,270 +426,371 @@ def main(argv=None):
     # is kept for --print-samples, for variants carrying missing calls, and as the cross-check (--python-sink)
     from .sink import RowFormatter, names_blob
     from .packing import pack_variants
-    formatter = RowFormatter(lineage_dict if options.lineage else None)
     NOTE_AF, NOTE_FIRTH_FAIL = 1, 1 << 6
     q_out = 0
 
     import time as _time
     cli_timing = os.environ.get("SEERHIP_CLI_TIMING") is not None
-    tm = {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0, "t0w": _time.time()}
 
-    def sink_block(blk, r):
-        nonlocal prefilter, tested, printed
-        t_in = _time.perf_counter()
-        nb = len(blk)
-        status = np.asarray(blk.status)
-        on = status == 0
-        row_of = np.asarray(blk.row_of, dtype=np.int64)
-        # blocks of the native reader / the packed cache: one engine row per variant, in place (row_of = 0, 1, 2, ...): whole-array selects
-        # instead of gathers through an index
-        ident = r is not None and isinstance(blk.row_of, np.ndarray) and nb == r["flags"].shape[0]
-        j = None if ident else row_of[on]
-        flags = np.zeros(nb, dtype=np.uint32)
-        flags[status == 1] = NOTE_AF | FLAG_PREFILTER
-        keys = ("prep", "pvalue", "beta", "bse", "frac_h2") if options.lmm else ("prep", "pvalue", "kbeta", "bse", "intercept")
-        cols = [np.asarray(blk.afs, dtype=np.float64)]
-        for kname in keys:
-            if ident:
-                c = np.where(on, r[kname], np.nan)
-            else:
-                c = np.full(nb, np.nan)
-                if r is not None:
-                    c[on] = r[kname][j]
-            cols.append(c)
-        betas = valid = None
-        if r is not None:
-            if ident:
-                flags = np.where(on, r["flags"], flags)
-            else:
-                flags[on] = r["flags"][j]
-            if not options.lmm and r["betas"].shape[1]:
+    def new_tm():
+        return {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0,
+                "t0w": _time.time(), "rows": 0}
+
+    def run_stream(engs, blocks, write_text, write_patterns, tm):
+        """One stream of blocks, in order: reader (its own thread inside `blocks`) -> engine calls, block k on engs[k % len(engs)], each engine
+        pipelined -> one ordered sink writing through write_text / write_patterns.  Returns (pre-filtered, tested, printed).  The job runs one
+        such stream per device when the input can be cut into ranges (a packed cache), else one stream over all devices."""
+        prefilter = tested = printed = 0
+        eng = engs[0]
+        formatter = RowFormatter(lineage_dict if options.lineage else None)     # (its text buffer is valid until its next call: one per stream)
+
+        class out(object):                                   # the tuple path writes text; the streams carry bytes
+            @staticmethod
+            def write(s):
+                write_text(s.encode())
+
+        class _Pat(object):
+            @staticmethod
+            def write(b):
+                write_patterns(b)
+        patterns = _Pat if write_patterns is not None else None
+
+        def emit(x):
+            nonlocal prefilter, tested, printed
+            if x.prefilter:
+                prefilter += 1
+                if options.print_filtered:
+                    printed += 1
+                    out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
+                return
+            tested += 1
+            if patterns is not None:
+                patterns.write(x.pattern)
+            if x.filter and not options.print_filtered:
+                return
+            printed += 1
+            out.write(format_output(x, lineage_dict, model, options.print_samples) + "\n")
+
+        def sink_block(blk, r):
+            nonlocal prefilter, tested, printed
+            t_in = _time.perf_counter()
+            nb = len(blk)
+            status = np.asarray(blk.status)
+            on = status == 0
+            row_of = np.asarray(blk.row_of, dtype=np.int64)
+            # blocks of the native reader / the packed cache: one engine row per variant, in place (row_of = 0, 1, 2, ...): whole-array selects
+            # instead of gathers through an index
+            ident = r is not None and isinstance(blk.row_of, np.ndarray) and nb == r["flags"].shape[0]
+            j = None if ident else row_of[on]
+            flags = np.zeros(nb, dtype=np.uint32)
+            flags[status == 1] = NOTE_AF | FLAG_PREFILTER
+            keys = ("prep", "pvalue", "beta", "bse", "frac_h2") if options.lmm else ("prep", "pvalue", "kbeta", "bse", "intercept")
+            cols = [np.asarray(blk.afs, dtype=np.float64)]
+            for kname in keys:
                 if ident:
-                    betas = r["betas"]                    # (rows that are not `on` have valid = 0: the formatter never reads their slopes)
-                    valid = (on & (np.isfinite(r["kbeta"]) | np.isfinite(r["pvalue"]))).astype(np.uint8)
+                    c = np.where(on, r[kname], np.nan)
                 else:
-                    betas = np.full((nb, r["betas"].shape[1]), np.nan)
-                    betas[on] = r["betas"][j]
-                    valid = np.zeros(nb, dtype=np.uint8)
-                    valid[on] = np.isfinite(r["kbeta"][j]) | np.isfinite(r["pvalue"][j])
-        pf = (flags & FLAG_PREFILTER) != 0
-        ft = (flags & FLAG_FILTER) != 0
-        lineage = None
-        if options.lineage:
-            lineage = np.full(nb, -1, dtype=np.int32)
-            if options.lmm and not options.lmm_lineage_per_variant:
-                kl = blk.last_k                      # pyseer/lmm.py:209-213: the stale `k` of fit_lmm's first loop
-                ml = -1
-                if kl is not None and not np.isnan(np.asarray(kl, dtype=float)).any():
-                    ml = int(eng.lineage_batch(pack_variants(np.asarray(kl).reshape(1, -1)))[0])
-                lineage[~pf & ~ft] = ml
-            else:
-                need = on & ~pf & (~ft if options.lmm else ((flags & NOTE_FIRTH_FAIL) == 0))
-                if need.any():
-                    lineage[need] = eng.lineage_batch(blk.bits[row_of[need]])
-        order = np.arange(nb)
-        if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
-            order = np.concatenate([order[pf], order[~pf]])
-        npf = int(pf.sum())
-        prefilter += npf
-        tested += nb - npf
-        if patterns is not None:
-            patterns.write(b''.join(blk.patterns[i] for i in order if not pf[i]))
-        show = np.ones(nb, dtype=bool) if options.print_filtered else (~pf & ~ft)
-        sel = order[show[order]]
-        printed += int(sel.shape[0])
-        if sel.shape[0]:
-            blob, off = (blk.names_blob, blk.name_off) if getattr(blk, "names_blob", None) is not None else names_blob(blk.names)
-            t_f = _time.perf_counter()
-            text = formatter.format_view(blob, off, sel, cols, flags, betas, valid, lineage)
-            t_w = _time.perf_counter()
-            tm["format"] += t_w - t_f
-            if hasattr(sys.stdout, "buffer"):
-                sys.stdout.flush()
-                sys.stdout.buffer.write(text)
-            else:
-                sys.stdout.write(bytes(text).decode())
-            tm["write"] += _time.perf_counter() - t_w
-        tm["sink"] += _time.perf_counter() - t_in
+                    c = np.full(nb, np.nan)
+                    if r is not None:
+                        c[on] = r[kname][j]
+                cols.append(c)
+            betas = valid = None
+            if r is not None:
+                if ident:
+                    flags = np.where(on, r["flags"], flags)
+                else:
+                    flags[on] = r["flags"][j]
+                if not options.lmm and r["betas"].shape[1]:
+                    if ident:
+                        betas = r["betas"]                    # (rows that are not `on` have valid = 0: the formatter never reads their slopes)
+                        valid = (on & (np.isfinite(r["kbeta"]) | np.isfinite(r["pvalue"]))).astype(np.uint8)
+                    else:
+                        betas = np.full((nb, r["betas"].shape[1]), np.nan)
+                        betas[on] = r["betas"][j]
+                        valid = np.zeros(nb, dtype=np.uint8)
+                        valid[on] = np.isfinite(r["kbeta"][j]) | np.isfinite(r["pvalue"][j])
+            pf = (flags & FLAG_PREFILTER) != 0
+            ft = (flags & FLAG_FILTER) != 0
+            lineage = None
+            if options.lineage:
+                lineage = np.full(nb, -1, dtype=np.int32)
+                if options.lmm and not options.lmm_lineage_per_variant:
+                    kl = blk.last_k                      # pyseer/lmm.py:209-213: the stale `k` of fit_lmm's first loop
+                    ml = -1
+                    if kl is not None and not np.isnan(np.asarray(kl, dtype=float)).any():
+                        ml = int(eng.lineage_batch(pack_variants(np.asarray(kl).reshape(1, -1)))[0])
+                    lineage[~pf & ~ft] = ml
+                else:
+                    need = on & ~pf & (~ft if options.lmm else ((flags & NOTE_FIRTH_FAIL) == 0))
+                    if need.any():
+                        lineage[need] = eng.lineage_batch(blk.bits[row_of[need]])
+            order = np.arange(nb)
+            if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
+                order = np.concatenate([order[pf], order[~pf]])
+            npf = int(pf.sum())
+            prefilter += npf
+            tested += nb - npf
+            if patterns is not None:
+                patterns.write(b''.join(blk.patterns[i] for i in order if not pf[i]))
+            show = np.ones(nb, dtype=bool) if options.print_filtered else (~pf & ~ft)
+            sel = order[show[order]]
+            printed += int(sel.shape[0])
+            if sel.shape[0]:
+                blob, off = (blk.names_blob, blk.name_off) if getattr(blk, "names_blob", None) is not None else names_blob(blk.names)
+                t_f = _time.perf_counter()
+                text = formatter.format_view(blob, off, sel, cols, flags, betas, valid, lineage)
+                t_w = _time.perf_counter()
+                tm["format"] += t_w - t_f
+                write_text(text)
+                tm["write"] += _time.perf_counter() - t_w
+            tm["sink"] += _time.perf_counter() - t_in
 
-    # Three stages run at once (round 3): the block reader (its own thread, `prefetched`), the engine call of block k on this thread (a ctypes
-    # call: the GIL is released while the rows go to the GPU and the statistics come back), and the sink of block k-1 on a worker thread
-    # (NaN masking, counters, native formatter, the write to stdout -- the reference does all of this per variant between two fits,
-    # pyseer/__main__.py:805-827).  One worker and a FIFO of depth 2: the output order is the input order.  The tuple path below (missing
-    # calls, --print-samples, --python-sink) and the lineage fits (a second engine call on the same context) stay on this thread, after the
-    # worker has drained.
-    import queue
-    import threading
-    sink_q = queue.Queue(maxsize=2)
-    sink_err = []
-    overlap = not options.lineage and not options.python_sink and not options.print_samples and not options.serial_sink
+        # Three stages run at once (round 3): the block reader (its own thread, `prefetched`), the engine call of block k on this thread (a ctypes
+        # call: the GIL is released while the rows go to the GPU and the statistics come back), and the sink of block k-1 on a worker thread
+        # (NaN masking, counters, native formatter, the write to stdout -- the reference does all of this per variant between two fits,
+        # pyseer/__main__.py:805-827).  One worker and a FIFO of depth 2: the output order is the input order.  The tuple path below (missing
+        # calls, --print-samples, --python-sink) and the lineage fits (a second engine call on the same context) stay on this thread, after the
+        # worker has drained.
+        import queue
+        import threading
+        sink_q = queue.Queue(maxsize=2)
+        sink_err = []
+        overlap = not options.lineage and not options.python_sink and not options.print_samples and not options.serial_sink
 
-    def sink_worker():
-        while True:
-            item = sink_q.get()
-            try:
-                if item is None:
-                    return
-                if not sink_err:
-                    blk_, r_ = item
-                    sink_block(blk_, mask_like_fit_lmm(r_) if (options.lmm and r_ is not None) else r_)
-            except BaseException as ex:          # re-raised on the main thread
-                sink_err.append(ex)
-            finally:
-                sink_q.task_done()
-    sink_thread = None
-    if overlap:
-        sink_thread = threading.Thread(target=sink_worker, daemon=True)
-        sink_thread.start()
+        def sink_worker():
+            while True:
+                item = sink_q.get()
+                try:
+                    if item is None:
+                        return
+                    if not sink_err:
+                        blk_, r_ = item
+                        sink_block(blk_, mask_like_fit_lmm(r_) if (options.lmm and r_ is not None) else r_)
+                except BaseException as ex:          # re-raised on the main thread
+                    sink_err.append(ex)
+                finally:
+                    sink_q.task_done()
+        sink_thread = None
+        if overlap:
+            sink_thread = threading.Thread(target=sink_worker, daemon=True)
+            sink_thread.start()
 
-    def drain_sink():
-        if sink_thread is not None:
-            sink_q.join()
-        if sink_err:
-            raise sink_err[0]
+        def drain_sink():
+            if sink_thread is not None:
+                sink_q.join()
+            if sink_err:
+                raise sink_err[0]
 
-    def after_engine(blk, r):
-        """Everything that follows a block's engine call: hand it to the sink (array-backed), or build the reference's row objects."""
-        if not options.python_sink and not options.print_samples and 2 not in blk.status:
-            if overlap:
-                if sink_err:
-                    raise sink_err[0]
-                t_q = _time.perf_counter()
-                sink_q.put((blk, r))                      # (waiting here = the sink is the slowest stage)
-                tm["queue"] += _time.perf_counter() - t_q
-            else:
-                sink_block(blk, mask_like_fit_lmm(r) if (options.lmm and r is not None) else r)
-            return
-        drain_sink()
-        if options.lmm and r is not None:
-            r = mask_like_fit_lmm(r)
-        rows = []
-        for i, name in enumerate(blk.names):
-            st, af, ks, nks = blk.status[i], blk.afs[i], blk.kstrains[i], blk.nkstrains[i]
-            if st == 1:                                   # AF / missing filtered (model.py:255-260, lmm.py:160-167)
+        def after_engine(blk, r):
+            """Everything that follows a block's engine call: hand it to the sink (array-backed), or build the reference's row objects."""
+            if not options.python_sink and not options.print_samples and 2 not in blk.status:
+                if overlap:
+                    if sink_err:
+                        raise sink_err[0]
+                    t_q = _time.perf_counter()
+                    sink_q.put((blk, r))                      # (waiting here = the sink is the slowest stage)
+                    tm["queue"] += _time.perf_counter() - t_q
+                else:
+                    sink_block(blk, mask_like_fit_lmm(r) if (options.lmm and r is not None) else r)
+                return
+            drain_sink()
+            if options.lmm and r is not None:
+                r = mask_like_fit_lmm(r)
+            rows = []
+            for i, name in enumerate(blk.names):
+                st, af, ks, nks = blk.status[i], blk.afs[i], blk.kstrains[i], blk.nkstrains[i]
+                if st == 1:                                   # AF / missing filtered (model.py:255-260, lmm.py:160-167)
+                    if options.lmm:
+                        rows.append(LMM(name, None, af, nan, nan, nan, nan, nan, None, ks, nks, {'af-filter'}, True, False))
+                    else:
+                        rows.append(Seer(name, blk.patterns[i], af, nan, nan, nan, nan, nan, np.array([]), None, ks, nks,
+                                         {'af-filter'}, True, False))
+                    continue
+                if st == 2:                                   # missing calls inside k: the reference's error path
+                    prep, bad = _host_prefilter(pv, blk.ks[i], options.continuous)
+                    notes = {'bad-chisq'} if bad else set()
+                    thr = options.filter_pvalue
+                    failed = (prep >= thr) if options.lmm else (prep > thr)
+                    if failed or not np.isfinite(prep):
+                        notes.add('pre-filtering-failed')
+                        x = (LMM(name, blk.patterns[i], af, prep, nan, nan, nan, nan, None, ks, nks, notes, True, False)
+                             if options.lmm else
+                             Seer(name, blk.patterns[i], af, prep, nan, nan, nan, nan, np.array([]), None, ks, nks, notes, True, False))
+                    elif options.lmm:                         # NaN propagates through fit_lmm_block -> lrt-filtering-failed
+                        notes.add('lrt-filtering-failed')
+                        x = LMM(name, blk.patterns[i], af, prep, nan, nan, nan, nan, None, ks, nks, notes, False, True)
+                    else:                                     # statsmodels MissingDataError, model.py:371-377
+                        notes.add('missing-data-error')
+                        x = Seer(name, blk.patterns[i], af, prep, nan, nan, nan, nan, np.array([]), None, ks, nks, notes, False, True)
+                    rows.append(x)
+                    continue
+                j = blk.row_of[i]
+                fl = int(r["flags"][j])
+                notes = notes_from_flags(fl)
+                pf, ft = bool(fl & FLAG_PREFILTER), bool(fl & FLAG_FILTER)
                 if options.lmm:
-                    rows.append(LMM(name, None, af, nan, nan, nan, nan, nan, None, ks, nks, {'af-filter'}, True, False))
+                    rows.append(LMM(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["beta"][j], r["bse"][j],
+                                    r["frac_h2"][j], None, ks, nks, notes, pf, ft))
                 else:
-                    rows.append(Seer(name, blk.patterns[i], af, nan, nan, nan, nan, nan, np.array([]), None, ks, nks,
-                                     {'af-filter'}, True, False))
-                continue
-            if st == 2:                                   # missing calls inside k: the reference's error path
-                prep, bad = _host_prefilter(pv, blk.ks[i], options.continuous)
-                notes = {'bad-chisq'} if bad else set()
-                thr = options.filter_pvalue
-                failed = (prep >= thr) if options.lmm else (prep > thr)
-                if failed or not np.isfinite(prep):
-                    notes.add('pre-filtering-failed')
-                    x = (LMM(name, blk.patterns[i], af, prep, nan, nan, nan, nan, None, ks, nks, notes, True, False)
-                         if options.lmm else
-                         Seer(name, blk.patterns[i], af, prep, nan, nan, nan, nan, np.array([]), None, ks, nks, notes, True, False))
-                elif options.lmm:                         # NaN propagates through fit_lmm_block -> lrt-filtering-failed
-                    notes.add('lrt-filtering-failed')
-                    x = LMM(name, blk.patterns[i], af, prep, nan, nan, nan, nan, None, ks, nks, notes, False, True)
-                else:                                     # statsmodels MissingDataError, model.py:371-377
-                    notes.add('missing-data-error')
-                    x = Seer(name, blk.patterns[i], af, prep, nan, nan, nan, nan, np.array([]), None, ks, nks, notes, False, True)
-                rows.append(x)
-                continue
-            j = blk.row_of[i]
-            fl = int(r["flags"][j])
-            notes = notes_from_flags(fl)
-            pf, ft = bool(fl & FLAG_PREFILTER), bool(fl & FLAG_FILTER)
-            if options.lmm:
-                rows.append(LMM(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["beta"][j], r["bse"][j],
-                                r["frac_h2"][j], None, ks, nks, notes, pf, ft))
-            else:
-                tested_ok = np.isfinite(r["kbeta"][j]) or np.isfinite(r["pvalue"][j])
-                betas = r["betas"][j] if (tested_ok and r["betas"].shape[1]) else np.array([])
-                rows.append(Seer(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["kbeta"][j], r["bse"][j],
-                                 r["intercept"][j], betas, None, ks, nks, notes, pf, ft))
-        if options.lineage:
-            # fit_lineage_effect: fixed effects -> every variant that reached the fit (model.py:379-382; firth-fail and
-            # missing-data return earlier); LMM -> only variants that pass the LRT filter (lmm.py:209-213)
-            need = [i for i, x in enumerate(rows) if blk.status[i] == 0 and not x.prefilter and
-                    ((not x.filter) if options.lmm else ('firth-fail' not in x.notes))]
-            if options.lmm and not options.lmm_lineage_per_variant:
-                # Reference behaviour (pyseer/lmm.py:209-213): inside fit_lmm's second loop `k` still holds the LAST variant
-                # unpacked by the first loop, so every passing variant of a block reports the lineage of that last variant.
-                kl = blk.last_k
-                ml = -1
-                if kl is not None and not np.isnan(np.asarray(kl, dtype=float)).any():
-                    from .packing import pack_variants
-                    ml = int(eng.lineage_batch(pack_variants(np.asarray(kl).reshape(1, -1)))[0])
-                for i, x in enumerate(rows):
-                    if not x.prefilter and not x.filter:
-                        rows[i] = x._replace(max_lineage=(None if ml < 0 else ml))
-            elif need:
-                ml = eng.lineage_batch(blk.bits[[blk.row_of[i] for i in need]])
-                for i, v in zip(need, ml):
-                    rows[i] = rows[i]._replace(max_lineage=(None if v < 0 else int(v)))
-        if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
-            rows = [x for x in rows if x.prefilter] + [x for x in rows if not x.prefilter]
-        for x in rows:
-            emit(x)
+                    tested_ok = np.isfinite(r["kbeta"][j]) or np.isfinite(r["pvalue"][j])
+                    betas = r["betas"][j] if (tested_ok and r["betas"].shape[1]) else np.array([])
+                    rows.append(Seer(name, blk.patterns[i], af, r["prep"][j], r["pvalue"][j], r["kbeta"][j], r["bse"][j],
+                                     r["intercept"][j], betas, None, ks, nks, notes, pf, ft))
+            if options.lineage:
+                # fit_lineage_effect: fixed effects -> every variant that reached the fit (model.py:379-382; firth-fail and
+                # missing-data return earlier); LMM -> only variants that pass the LRT filter (lmm.py:209-213)
+                need = [i for i, x in enumerate(rows) if blk.status[i] == 0 and not x.prefilter and
+                        ((not x.filter) if options.lmm else ('firth-fail' not in x.notes))]
+                if options.lmm and not options.lmm_lineage_per_variant:
+                    # Reference behaviour (pyseer/lmm.py:209-213): inside fit_lmm's second loop `k` still holds the LAST variant
+                    # unpacked by the first loop, so every passing variant of a block reports the lineage of that last variant.
+                    kl = blk.last_k
+                    ml = -1
+                    if kl is not None and not np.isnan(np.asarray(kl, dtype=float)).any():
+                        from .packing import pack_variants
+                        ml = int(eng.lineage_batch(pack_variants(np.asarray(kl).reshape(1, -1)))[0])
+                    for i, x in enumerate(rows):
+                        if not x.prefilter and not x.filter:
+                            rows[i] = x._replace(max_lineage=(None if ml < 0 else ml))
+                elif need:
+                    ml = eng.lineage_batch(blk.bits[[blk.row_of[i] for i in need]])
+                    for i, v in zip(need, ml):
+                        rows[i] = rows[i]._replace(max_lineage=(None if v < 0 else int(v)))
+            if options.lmm:                                   # fit_lmm's return order: filtered first, then tested
+                rows = [x for x in rows if x.prefilter] + [x for x in rows if not x.prefilter]
+            for x in rows:
+                emit(x)
 
-
-    # The engine calls themselves are pipelined (sh_*_batch_async, include/seerhip.h): a call returns while its last chunk is still on the
-    # device, and that chunk's results arrive while the NEXT call stages and queues its first chunk -- a block is therefore handed on one
-    # iteration late.  Synchronous calls left the device idle for a third of every call (first chunk's staging + upload at the head, the
-    # last chunk's kernels + download at the tail: 12.6 ms per 262 144-row block of which 8 ms were kernels).  The loop also reads one block
-    # ahead and announces its rows to the engine (sh_prefetch_rows).  SEERHIP_CLI_PIPELINE=0: off.
-    from .engine import Engine as _SingleEngine
-    pipe = isinstance(eng, _SingleEngine) and os.environ.get("SEERHIP_CLI_PIPELINE", "1") != "0"
-    held = None
-    blocks = iter(blocks)
-    t_r = _time.perf_counter()
-    ahead = next(blocks, None)
-    tm["reader"] += _time.perf_counter() - t_r
-    while ahead is not None:
-        blk = ahead
+        # The engine calls themselves are pipelined (sh_*_batch_async, include/seerhip.h): a call returns while its last chunk is still on the
+        # device, and that chunk's results arrive while the NEXT call on the same context stages and queues its first chunk -- a block is
+        # therefore handed on len(engs) iterations late.  Synchronous calls left the device idle for a third of every call (first chunk's
+        # staging + upload at the head, the last chunk's kernels + download at the tail: 12.6 ms per 262 144-row block of which 8 ms were
+        # kernels).  With one context the loop also announces the rows of the block it has read ahead (sh_prefetch_rows).
+        # SEERHIP_CLI_PIPELINE=0: synchronous calls.
+        import collections
+        pipe = os.environ.get("SEERHIP_CLI_PIPELINE", "1") != "0"
+        G = len(engs)
+        pend = collections.deque()                        # (block, results, engine) handed to the engine, not yet to the sink
+        blocks = iter(blocks)
         t_r = _time.perf_counter()
-        ahead = next(blocks, None)                        # (waiting here = the reader is the slowest stage)
+        ahead = next(blocks, None)
         tm["reader"] += _time.perf_counter() - t_r
-        t_e = _time.perf_counter()
-        r = None
-        if pipe and ahead is not None and ahead.bits.shape[0] and ahead.bits.dtype == np.uint8 and ahead.bits.flags.c_contiguous:
-            eng.prefetch(ahead.bits)                      # block k+1's first chunk goes up while block k is on the device (sh_prefetch_rows)
-        if blk.bits.shape[0]:
+        k = 0
+        while ahead is not None:
+            blk = ahead
+            t_r = _time.perf_counter()
+            ahead = next(blocks, None)                    # (waiting here = the reader is the slowest stage)
+            tm["reader"] += _time.perf_counter() - t_r
+            t_e = _time.perf_counter()
+            e = engs[k % G]
+            r = None
+            if pipe and G == 1 and ahead is not None and ahead.bits.shape[0] and ahead.bits.dtype == np.uint8 and ahead.bits.flags.c_contiguous:
+                e.prefetch(ahead.bits)                    # block k+1's first chunk goes up while block k is on the device (sh_prefetch_rows)
+            if blk.bits.shape[0]:
+                if pipe:
+                    r = e.lmm_batch(blk.bits, pipelined=True) if options.lmm else e.glm_batch(blk.bits, pipelined=True)
+                else:
+                    r = e.lmm_batch(blk.bits) if options.lmm else e.glm_batch(blk.bits)
+            elif pipe:
+                e.wait()                                  # no call for an empty block: complete this context's previous one here
+            tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
+            pend.append((blk, r, e))
+            # block j is complete once its context has returned from its next call (or wait): the oldest of more than G pending ones is
+            while len(pend) > (G if pipe else 0):
+                b_, r_, e_ = pend.popleft()
+                eng = e_                                  # (the lineage fits of the sink go to the context that holds the block's rows)
+                after_engine(b_, r_)
+            k += 1
+        while pend:
+            b_, r_, e_ = pend.popleft()
+            t_e = _time.perf_counter()
             if pipe:
-                r = eng.lmm_batch(blk.bits, pipelined=True) if options.lmm else eng.glm_batch(blk.bits, pipelined=True)
-            else:
-                r = eng.lmm_batch(blk.bits) if options.lmm else eng.glm_batch(blk.bits)
-        elif pipe and held is not None:
-            eng.wait()
-        tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
-        if pipe:
-            if held is not None:
-                after_engine(*held)                       # complete since the call above returned
-            held = (blk, r)
-        else:
-            after_engine(blk, r)
-    if held is not None:
-        t_e = _time.perf_counter()
-        eng.wait()
-        tm["engine"] += _time.perf_counter() - t_e
-        after_engine(*held)
+                e_.wait()
+            tm["engine"] += _time.perf_counter() - t_e
+            eng = e_
+            after_engine(b_, r_)
 
-    drain_sink()
-    if sink_thread is not None:
-        sink_q.put(None)
-        sink_thread.join()
+        drain_sink()
+        if sink_thread is not None:
+            sink_q.put(None)
+            sink_thread.join()
+        tm["rows"] = prefilter + tested; tm["loop"] = _time.perf_counter() - tm["t0"]; tm["overlap"] = overlap
+        return prefilter, tested, printed
+
+    if hasattr(sys.stdout, "buffer"):
+        def write_stdout(b):
+            sys.stdout.flush()
+            sys.stdout.buffer.write(b)
+    else:
+        def write_stdout(b):
+            sys.stdout.write(bytes(b).decode())
+
+    # ---- the job: one stream over all contexts, or one stream PER context ------------------------------------------------------------------
+    # The reference's --cpu N hands blocks of the variant stream to N workers and takes them back in order (__main__.py:541-568, 777-780).
+    # Here every device gets its own pipelined stream when the input can be cut into ranges up front (the packed cache: range i of the
+    # rows to context i, each with its own reader thread, engine pipeline, sink thread and output part; the parts are joined in order and the
+    # four counters summed at the end -- nothing crosses between devices while the job runs).  Input that is only readable front to back
+    # (text, gzip) stays one stream whose blocks go to the contexts in turn.
+    tms = [new_tm()]
+    if len(engs) > 1 and options.load_packed:
+        import shutil
+        import tempfile
+        import threading as _th
+        G = len(engs)
+        tms = [new_tm() for _ in range(G)]
+        outs = [None] + [tempfile.TemporaryFile() for _ in range(1, G)]
+        pouts = [None] + [tempfile.TemporaryFile() if patterns is not None else None for _ in range(1, G)]
+        counts = [None] * G
+        errs = [None] * G
+
+        def stream_worker(i):
+            try:
+                blocks_i = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
+                                                     want_patterns=bool(options.output_patterns), want_samples=options.print_samples, part=(i, G))
+                wp = None if patterns is None else (patterns.write if i == 0 else pouts[i].write)
+                counts[i] = run_stream([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, wp, tms[i])
+            except BaseException as ex:                    # re-raised below, on the main thread
+                errs[i] = ex
+        workers = [_th.Thread(target=stream_worker, args=(i,)) for i in range(G)]
+        for w_ in workers:
+            w_.start()
+        for w_ in workers:
+            w_.join()
+        for ex in errs:
+            if ex is not None:
+                raise ex
+        sys.stdout.flush()
+        for i in range(1, G):                              # the parts, in the order of the input
+            outs[i].seek(0)
+            if hasattr(sys.stdout, "buffer"):
+                shutil.copyfileobj(outs[i], sys.stdout.buffer, 1 << 22)
+            else:
+                sys.stdout.write(outs[i].read().decode())
+            outs[i].close()
+            if patterns is not None:
+                pouts[i].seek(0)
+                shutil.copyfileobj(pouts[i], patterns, 1 << 22)
+                pouts[i].close()
+        prefilter, tested, printed = (sum(c[j] for c in counts) for j in range(3))
+    else:
+        prefilter, tested, printed = run_stream(engs, blocks, write_stdout, None if patterns is None else patterns.write, tms[0])
+
     if cli_timing:
-        loop = _time.perf_counter() - tm["t0"]
-        nrows = prefilter + tested
-        sys.stderr.write("[cli timing] %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; engine calls (H2D + GPU + D2H) %.2f s, sink (masking, "
-                         "counters, formatting, write) %.2f s of which formatting %.2f s and write %.2f s; sink %s; this thread waited %.2f s for the reader and %.2f s for the sink's queue\n"
-                         % (tm["blocks"], nrows, loop, nrows / max(loop, 1e-9), tm["engine"], tm["sink"], tm["format"], tm["write"],
-                            "on a worker thread" if overlap else "serial", tm["reader"], tm["queue"]))
+        for i, tm in enumerate(tms):
+            sys.stderr.write("[cli timing] stream %d of %d: %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; engine calls (H2D + GPU + D2H) %.2f s, sink (masking, "
+                             "counters, formatting, write) %.2f s of which formatting %.2f s and write %.2f s; sink %s; this thread waited %.2f s for the reader and %.2f s for the sink's queue\n"
+                             % (i, len(tms), tm["blocks"], tm["rows"], tm["loop"], tm["rows"] / max(tm["loop"], 1e-9), tm["engine"], tm["sink"], tm["format"], tm["write"],
+                                "on a worker thread" if tm["overlap"] else "serial", tm["reader"], tm["queue"]))
         sys.stderr.write("[cli timing] before the block loop: %.2f s from process start to the model set-up (interpreter, imports, phenotypes, "
                          "structure), %.2f s model set-up (kinship cache / null fit, device context, engine set-up), %.2f s to the first block; "
                          "%.2f s from process start to the end of the loop\n"
-                         % (since_start, t_setup - t_inputs, tm["t0w"] - t_setup, since_start + _time.time() - t_inputs))
+                         % (since_start, t_setup - t_inputs, tms[0]["t0w"] - t_setup, since_start + _time.time() - t_inputs))
     if patterns is not None:
         patterns.close()
     if cache_out is not None:
         cache_out.close()
-    eng.close()
+    for e_ in engs:
+        e_.close()
     sys.stderr.write('%d loaded variants\n' % (prefilter + tested))
     sys.stderr.write('%d pre-filtered variants\n' % prefilter)
     sys.stderr.write('%d tested variants\n' % tested)

@@ -177,6 +177,10 @@ __global__ void k_betas_rows(const double *__restrict__ src, double *__restrict_
     dst[i] = src[(size_t)j * n + v];
 }
 
+// An announcement (sh_prefetch_rows) and a first chunk uploaded ahead belong to the call sequence they were made in: a set-up, a change of
+// stream or a reallocation of the staging buffers forgets them (the next batch then uploads its own first chunk).
+static void forget_announced(sh_ctx *c) { c->next_bits = nullptr; c->pre_bits = nullptr; c->pre_set = -1; }
+
 static int drain_pending(sh_ctx *c)
 {
     if (!c->pend.valid) return SH_OK;
@@ -216,11 +220,13 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
             HIPCHK(hipMalloc((void **)&c->hb_bits[b], nb)); HIPCHK(dmalloc(&c->hb_out[b], no)); HIPCHK(dmalloc(&c->hb_flags[b], nf));
         }
         c->hb_cap_bits = nb; c->hb_cap_out = no; c->hb_cap_flags = nf;
+        c->pre_bits = nullptr; c->pre_set = -1;                        // a first chunk uploaded ahead lived in the buffers just freed
     }
     if (cap * row_bytes > c->hp_cap) {
         int rc = drain_pending(c); if (rc) return rc;
         for (int b = 0; b < 2; ++b) { if (c->hp_bits[b]) hipHostFree(c->hp_bits[b]); c->hp_bits[b] = nullptr; HIPCHK(hipHostMalloc((void **)&c->hp_bits[b], cap * row_bytes, hipHostMallocDefault)); }
         c->hp_cap = cap * row_bytes;
+        c->pre_bits = nullptr; c->pre_set = -1;
     }
     // chunk boundaries: a shorter first chunk (2^17) so that the kernels start after 83 MB of upload instead of 166 MB; 2^17 and
     // 2^18 variants are whole numbers of block rounds for the LMM kernel (tiles x 5 limbs on 256 CUs)
@@ -459,7 +465,7 @@ void sh_destroy(sh_ctx *c)
     delete c;
 }
 
-int sh_set_stream(sh_ctx *c, void *s) { if (!c) return fail(SH_EINVAL, "null ctx"); c->stream = (hipStream_t)s; return SH_OK; }
+int sh_set_stream(sh_ctx *c, void *s) { if (!c) return fail(SH_EINVAL, "null ctx"); forget_announced(c); c->stream = (hipStream_t)s; return SH_OK; }
 
 int sh_synchronize(sh_ctx *c)
 {
@@ -524,6 +530,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     if (k < 1 || D < 1) return fail(SH_ESHAPE, "k and D must be >= 1");
     if (h2 < 0.0 || h2 >= 1.0 || std::isnan(h2)) return fail(SH_EH2, "h2 outside [0,1): reference returns no 'beta' (KeyError)");
     { const int rc0 = drain_pending(c); if (rc0) return rc0; }        // a batch still in flight belongs to the model being replaced
+    forget_announced(c);
     if (n_limbs == 0) {
         // Automatic limb count: the smallest L in {4, 5} whose TYPICAL a-posteriori bound (an AF-0.5 variant, section 3 of DESIGN.md) is at most a
         // quarter of lmm_tol, so that the extra-limb pass stays the exception; a variant whose own bound exceeds lmm_tol gets the extra limbs

@@ -30,6 +30,14 @@ static const char *const kNotes[9] = {"af-filter", "pre-filtering-failed", "bad-
 // short decimal such as 1.125) or to either end, and for subnormals, the answer is left to snprintf, so the fast path never decides a case
 // its arithmetic could get wrong.  History: snprintf cost 1.2 us per 6-number row (the sink ran at 7 M rows/s, below the engine); an 80-bit
 // x87 version of this function 0.5 us; this one ~0.1 us.  tests/test_sink_cpu.py sweeps it against '%.2E'.
+#include <cfloat>
+// the table below takes the 64-bit significand of 10^k from long double arithmetic: exact to 2^-63 only where long double is the 80-bit x87
+// format (LDBL_MANT_DIG = 64).  Anywhere else the margin argument of put_num does not hold and every number goes through snprintf.
+#if LDBL_MANT_DIG >= 64
+static constexpr bool kFastNum = true;
+#else
+static constexpr bool kFastNum = false;
+#endif
 struct Pow10 { uint64_t m; int e; };
 static Pow10 g_pow10[700];
 static double g_pow10d[700];                       // 10^k as a double: the branch-free first guess of the decimal exponent
@@ -55,6 +63,7 @@ static inline char *put_num(char *w, double x)
     uint64_t bits; memcpy(&bits, &x, 8);
     const int be = (int)((bits >> 52) & 0x7ff);
     if (__builtin_expect(be == 0x7ff, 0)) return w;                                    // nan / inf: empty field
+    if (!kFastNum) return put_num_slow(w, x);
     const uint64_t frac52 = bits & ((1ull << 52) - 1);
     if (__builtin_expect(be == 0, 0)) {
         if (frac52 == 0) { if (bits >> 63) *w++ = '-'; memcpy(w, "0.00E+00", 8); return w + 8; }
@@ -134,7 +143,9 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
     if (!names || !name_off || !sel || !cols || !flags || nsel < 0 || ncol < 1) return -1;
     if (q > 0 && (!betas || !betas_valid)) return -1;
     int nth = 1;
+#ifdef _OPENMP
     nth = format_threads();
+#endif
     if (nsel < 4096) nth = 1;
     size_t lab_max = 2;                                                    // "NA"
     std::vector<size_t> lab_len((size_t)std::max(n_labels, 0));
@@ -145,14 +156,17 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
     std::vector<int64_t> start((size_t)nth + 1, 0);
     int64_t total = 0;
     bool fits = false;
+    // The rows are cut into `nth` parts, part i into parts[i].  The runtime may deliver a smaller team than asked for (OMP_THREAD_LIMIT,
+    // OMP_DYNAMIC, a nested region): every member then takes the parts i = t, t + team, ... so that no part keeps the text of an earlier call.
 #pragma omp parallel num_threads(nth)
     {
-        int t = 0;
+        int t = 0, team = 1;
 #ifdef _OPENMP
-        t = omp_get_thread_num();
+        t = omp_get_thread_num(); team = omp_get_num_threads();
 #endif
-        const int64_t lo = nsel * t / nth, hi = nsel * (t + 1) / nth;
-        Part &s = parts[(size_t)t];
+      for (int part = t; part < nth; part += team) {
+        const int64_t lo = nsel * part / nth, hi = nsel * (part + 1) / nth;
+        Part &s = parts[(size_t)part];
         s.n = 0;
         s.room((size_t)(hi - lo) * 96 + fixed);
         for (int64_t r = lo; r < hi; ++r) {
@@ -179,6 +193,7 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
             *w++ = '\n';
             s.n = (size_t)(w - s.p);
         }
+      }
 #pragma omp barrier
 #pragma omp single
         {
@@ -186,7 +201,8 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
             total = start[(size_t)nth];
             fits = out && total <= cap;
         }                                                                  // (implicit barrier)
-        if (fits) memcpy(out + start[(size_t)t], s.p, s.n);               // every thread places its own part
+        if (fits)
+            for (int part = t; part < nth; part += team) memcpy(out + start[(size_t)part], parts[(size_t)part].p, parts[(size_t)part].n);
     }
     if (!fits) return -(total + 1);                     // caller retries with at least `total` bytes
     return total;

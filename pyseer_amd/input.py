@@ -627,9 +627,12 @@ def packed_cache_complete(path):
         return False
 
 
-def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False):
+def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, part=None):
     """PackedBlock stream from a packed cache written by --save-packed; the samples (and their order) must be the run's own.
-    Stored blocks are re-cut to about `block_size` variants (stored blocks are never split, only merged)."""
+    Stored blocks are re-cut to about `block_size` variants (stored blocks are never split, only merged).
+    part = (i, n): only range i of n contiguous ranges of the cache's rows (the multi-GPU job: one range per device,
+    pyseer_amd/__main__.py).  Ranges are made of whole blocks of the single stream, so the n parts yield exactly its blocks; they are
+    as equal as block_size allows (a cache of B blocks over n devices: ceil(B/n) against floor(B/n) blocks)."""
     samples = [str(x) for x in p.index]
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
@@ -669,11 +672,46 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
             at = pos
             pos += nbytes
             return at
+        lo_blk, hi_blk = 0, None
+        if part is not None:
+            # index pass: the 16-byte header of every stored block (a few hundred bytes of the mapping are touched).  The single stream merges
+            # stored blocks until it holds block_size rows (merged() below); a part owns whole such groups -- the groups whose first row falls
+            # into its share of the rows -- so every part hands the engine exactly the blocks the single stream would, and output that depends
+            # on where blocks end (fit_lmm's filtered-first order, its stale-k lineage: pyseer/lmm.py:160-217) does not change
+            start = pos
+            nvs = []
+            while True:
+                at = need(16)
+                nv, nb = (int(x) for x in np.frombuffer(mm, dtype="<u8", count=2, offset=at))
+                if nv == 0:
+                    break
+                need(8 * (nv + 1) + 4 * nv + nb + nv * rb)
+                nvs.append(nv)
+            pos = start
+            total = sum(nvs)
+            i_, n_ = part
+            owner, first_row, rows, row0 = [], 0, 0, 0
+            for j, nv in enumerate(nvs):
+                if rows == 0:
+                    first_row = row0
+                owner.append(min(n_ - 1, (first_row * n_) // max(total, 1)))
+                rows += nv; row0 += nv
+                if rows >= block_size:
+                    rows = 0
+            mine = [j for j, o in enumerate(owner) if o == i_]
+            lo_blk, hi_blk = (mine[0], mine[-1] + 1) if mine else (0, 0)
+        j = -1
         while True:
             at = need(16)
             nv, nb = (int(x) for x in np.frombuffer(mm, dtype="<u8", count=2, offset=at))
             if nv == 0:
                 return
+            j += 1
+            if hi_blk is not None and not (lo_blk <= j < hi_blk):                          # a stored block of another part: skipped unread
+                if j >= hi_blk:
+                    return
+                need(8 * (nv + 1) + 4 * nv + nb + nv * rb)
+                continue
             off = np.frombuffer(mm, dtype="<i8", count=nv + 1, offset=need(8 * (nv + 1)))
             counts = np.frombuffer(mm, dtype="<i4", count=nv, offset=need(4 * nv))
             at = need(nb)

@@ -40,4 +40,11 @@ def golden_firth_rows_close(got, golden, variants, field, rows, rtol=1e-6):
             x = np.asarray(v[field], dtype=float)[rows]
             sens |= ~((np.isnan(x) & np.isnan(base)) | (np.abs(x - base) <= 1e-9 * np.abs(base) + 1e-13))
         near = (np.isnan(g) & np.isnan(w)) | (np.abs(g - w) <= rtol * np.abs(w) + FA)
-    return same | (sens & near), int((~same & sens & near).sum())
+        # a stop rule met within 1e-8 of the limit on a slowly (linearly) converging fit moves the answer by a whole step (~1e-4): such a row
+        # must then EQUAL, at rtol, the oracle's answer under one of the detector's settings (oracle.set_firth_conv_scale)
+        alt = np.zeros(g.shape, dtype=bool)
+        for v in variants[1:]:
+            x = np.asarray(v[field], dtype=float)[rows]
+            alt |= np.abs(g - x) <= rtol * np.abs(x) + TINY
+    ok = same | (sens & (near | alt))
+    return ok, int((~same & ok).sum())

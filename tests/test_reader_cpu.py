@@ -4,6 +4,7 @@ import gzip
 import os
 
 import numpy as np
+import pytest
 import pandas as pd
 
 from pyseer_amd.input import (NativeKmerReader, iter_packed_blocks, iter_packed_blocks_native, open_variant_file,
@@ -359,3 +360,42 @@ def test_packed_cache_is_written_atomically_and_truncation_is_reported(tmp_path)
         raise AssertionError("truncation went unnoticed")
     except IOError as ex:
         assert "truncated" in str(ex)
+
+
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
+def test_packed_cache_ranges_partition_the_rows(tmp_path, n_parts):
+    """part = (i, n) of iter_packed_blocks_cached (the multi-GPU job: one contiguous range of the cache's rows per device): the ranges are
+    disjoint, in order, made of whole blocks of the single stream, and together they are that stream -- names, counts and bits."""
+    import pandas as pd
+    from pyseer_amd.input import PackedCacheWriter, iter_packed_blocks_cached, row_bytes_for
+    from pyseer_amd.packing import pack_variants
+    n = 37
+    samples = ["s%02d" % i for i in range(n)]
+    p = pd.Series(np.arange(n, dtype=float), index=samples)
+    rb = row_bytes_for(n)
+    rng = np.random.default_rng(12)
+    path = str(tmp_path / "c.seerpack")
+    w = PackedCacheWriter(path, samples)
+    names_all, bits_all = [], []
+    for nv in (5, 1, 40, 17, 3, 64):                         # stored blocks of uneven length
+        dense = (rng.random((nv, n)) < 0.4).astype(np.uint8)
+        bits = pack_variants(dense)
+        assert bits.shape[1] == rb
+        counts = dense.sum(axis=1).astype(np.int32)
+        names = [("k%d_%d" % (len(names_all) + j, j) * (1 + j % 3)).encode() for j in range(nv)]
+        off = np.concatenate([[0], np.cumsum([len(x) for x in names])]).astype(np.int64)
+        w.write_block(b"".join(names), off, counts, bits)
+        names_all += names; bits_all.append(bits)
+    w.close()
+    bits_all = np.concatenate(bits_all, axis=0)
+    single = [np.array(b.bits) for b in iter_packed_blocks_cached(p, path, 0.0, 1.0, 16)]
+    got_names, got_blocks = [], []
+    for i in range(n_parts):
+        for blk in iter_packed_blocks_cached(p, path, 0.0, 1.0, 16, part=(i, n_parts)):
+            nv = blk.bits.shape[0]
+            got_blocks.append(np.array(blk.bits))
+            got_names += [bytes(blk.names_blob[int(blk.name_off[j]):int(blk.name_off[j + 1])]) for j in range(nv)]
+            assert int(blk.name_off[0]) == 0 and len(blk.afs) == nv
+    # the parts hand over exactly the blocks of the single stream, in order
+    assert len(got_blocks) == len(single) and all(np.array_equal(a, b) for a, b in zip(got_blocks, single))
+    assert got_names == names_all and np.array_equal(np.concatenate(got_blocks, axis=0), bits_all)

@@ -89,3 +89,34 @@ def test_native_number_format_equals_printf_on_a_sweep():
     want = ["%.2E" % v for v in x]
     bad = [(v, g, w) for v, g, w in zip(x, got, want) if g != w]
     assert not bad, bad[:5]
+
+
+def test_a_smaller_openmp_team_than_asked_for_loses_nothing():
+    """the formatter cuts the rows into as many parts as it ASKS threads for; a runtime that grants fewer (OMP_THREAD_LIMIT, nested
+    regions) must still fill every part, and a part must never keep the text of an earlier call.  Two calls of different length under
+    OMP_THREAD_LIMIT=2 in a child process against the same calls here."""
+    import subprocess
+    code = r'''
+import sys, numpy as np, hashlib
+sys.path.insert(0, %r)
+from pyseer_amd.sink import RowFormatter, names_blob
+rng = np.random.default_rng(5)
+f = RowFormatter()
+for n in (30000, 9000):
+    names = ["k%%d" %% i for i in range(n)]
+    cols = [rng.normal(size=n) for _ in range(6)]
+    flags = rng.integers(0, 512, n).astype(np.uint32)
+    blob, off = names_blob(names)
+    t = f.format(blob, off, np.arange(n), cols, flags)
+    print(len(t), hashlib.md5(t).hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for lim in (None, "2", "1"):
+        env = dict(os.environ)
+        env.pop("OMP_THREAD_LIMIT", None)
+        if lim:
+            env["OMP_THREAD_LIMIT"] = lim
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0].splitlines()) == 2

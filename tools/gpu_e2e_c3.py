@@ -41,6 +41,8 @@ torch.cuda.empty_cache()
 env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_CLI_TIMING"] = "1"
 res = {"n_samples": N, "k_mers": V, "block_size": BLK, "cache_GB": os.path.getsize(d + "/kmers.seerpack") / 1e9}
 runs = [("overlapped", [], {}), ("serial", ["--serial-sink"], {})]
+if os.environ.get("E2E_GPUS"):            # e.g. "0,0": two contexts on one device = the multi-device job path (one pipelined stream per context over its
+    runs.append(("gpus_" + os.environ["E2E_GPUS"].replace(",", "_"), ["--gpus", os.environ["E2E_GPUS"]], {}))      # own range of the cache) on a one-GPU box
 for t in [x for x in os.environ.get("E2E_SINK_THREADS", "").split(",") if x]:   # extra overlapped runs with the sink's OpenMP team capped (a probe, not part of the record)
     runs.append(("overlapped_omp%s" % t, [], {"OMP_NUM_THREADS": t}))
 for name, extra, more_env in runs:
@@ -54,10 +56,10 @@ for name, extra, more_env in runs:
     err = r.stderr.decode()
     tl = [l for l in err.splitlines() if l.startswith("[cli timing]")]
     print("%s: rc %d, %.1f s wall, %.3g rows/s end to end (start-up included), output %.2f GB" % (name, r.returncode, dt, V / dt, os.path.getsize(out) / 1e9))
-    for l in tl[-3:]:
+    for l in tl[-9:]:
         print("   ", l)
     print("   ", err.strip().splitlines()[-4:])
-    res[name] = {"rc": r.returncode, "wall_s": dt, "rows_per_s_wall": V / dt, "output_GB": os.path.getsize(out) / 1e9, "timing": tl[-3:]}
+    res[name] = {"rc": r.returncode, "wall_s": dt, "rows_per_s_wall": V / dt, "output_GB": os.path.getsize(out) / 1e9, "timing": tl[-9:]}
 import hashlib
 def digest(p):
     h = hashlib.md5()
@@ -67,5 +69,10 @@ def digest(p):
     return h.hexdigest()
 res["outputs_identical"] = digest(d + "/out_overlapped.tsv") == digest(d + "/out_serial.tsv")
 print("overlapped and serial outputs identical:", res["outputs_identical"])
-o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "r03"); os.makedirs(o, exist_ok=True)
+for name, extra, _ in runs[2:]:
+    if name.startswith("gpus_"):
+        res[name]["identical_to_single_engine"] = digest(d + "/out_%s.tsv" % name) == digest(d + "/out_overlapped.tsv")
+        res[name]["rows_per_s_vs_single_engine"] = res[name]["rows_per_s_wall"] / res["overlapped"]["rows_per_s_wall"]
+        print(name, "identical to the single-engine output:", res[name]["identical_to_single_engine"], " wall ratio %.3f" % res[name]["rows_per_s_vs_single_engine"])
+o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "r04"); os.makedirs(o, exist_ok=True)
 json.dump(res, open(o + "/e2e_c3.json", "w"), indent=1)
