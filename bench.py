@@ -530,11 +530,10 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # how many ranks the collective library really connected (the driver's "did RCCL see N ranks" check): an all-reduce of ones
-    ranks_seen = 1
+    from pyseer_amd import parallel as par
+    cdev = dev if args.backend == "nccl" else "cpu"              # where the collectives' tensors live
+    ranks_seen = par.ranks_connected(cdev)
     if world > 1:
-        one = torch.ones(1, dtype=torch.int32, device=dev)
-        dist.all_reduce(one)
-        ranks_seen = int(one.item())
         assert ranks_seen == world == dist.get_world_size(), (ranks_seen, world)
 
     from pyseer_amd.engine import Engine, row_bytes_for
@@ -549,22 +548,13 @@ def main():
 
     if lmm:
         # per-run constants: rank 0 decomposes the kinship once and broadcasts (U, S, h2, y) at set-up time; the data path has no collective
+        consts = None
         if rank == 0:
             U, S, h2, C, y, _ = synth_lmm_inputs(N, 1003, dev)
+            consts = {"U": U, "S": S, "y": y, "h2": np.array([h2]), "C": C}
         if world > 1:
-            shp = torch.tensor([U.shape[0], U.shape[1]] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
-            dist.broadcast(shp, 0)
-            n_, k_ = int(shp[0]), int(shp[1])
-            tU = torch.from_numpy(np.ascontiguousarray(U)).to(dev) if rank == 0 else torch.empty((n_, k_), dtype=torch.float64, device=dev)
-            tS = torch.from_numpy(np.ascontiguousarray(S)).to(dev) if rank == 0 else torch.empty((k_,), dtype=torch.float64, device=dev)
-            ty = torch.from_numpy(np.ascontiguousarray(y)).to(dev) if rank == 0 else torch.empty((n_,), dtype=torch.float64, device=dev)
-            th = torch.tensor([h2 if rank == 0 else 0.0], dtype=torch.float64, device=dev)
-            for t in (tU, tS, ty, th):
-                dist.broadcast(t, 0)
-            if rank != 0:
-                U, S, y, h2 = tU.cpu().numpy(), tS.cpu().numpy(), ty.cpu().numpy(), float(th.item())
-                C = np.ones((n_, 1))
-            del tU
+            consts = par.broadcast_run_constants(consts, 0, cdev)
+            U, S, y, h2, C = consts["U"], consts["S"], consts["y"], float(consts["h2"][0]), consts["C"]
         eng.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=1.0, lrt_pvalue=1.0, n_limbs=args.limbs)
         info = eng.lmm_info()
         nrow = 5
@@ -613,12 +603,9 @@ def main():
     per_rank = [float(Vs) * args.steps / dt_local]
     fin_all = [frac_finite]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        g = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(g, torch.tensor([per_rank[0], frac_finite], dtype=torch.float64, device=dev))
-        per_rank = [float(x[0]) for x in g]; fin_all = [float(x[1]) for x in g]
+        dt = par.max_over_ranks(dt, cdev)
+        g = par.gather_floats([per_rank[0], frac_finite], cdev)
+        per_rank = [x[0] for x in g]; fin_all = [x[1] for x in g]
     assert min(fin_all) == 1.0, "a rank produced non-finite statistics: %s" % fin_all
 
     if rank == 0:

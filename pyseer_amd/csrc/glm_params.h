@@ -69,6 +69,13 @@ struct GlmParams {
     // pivots and the constant halves of the solve are computed once on the host.  Layout: L [m(m+1)/2, sidx], 1/D [m], y_c = L^-1 g_c [m],
     // x_c0 = L^-T (y_c / D) [m], m = Q + 1.  nullptr: the general kernel (k_glm_solve32<Q, true>).
     const double *b1;
+    // One-pass Firth iteration (firth_fast.hip; force_firth at N >= 4096 with Q <= 10): ff_tab = the monomials of degree <= 2 and <= 3 in
+    // (1, standardised covariates) as halves, hi and lo parts, in the A layout of v_mfma_f32_32x32x16_f16: [16-sample group][tile][hi, lo][64
+    // lanes] x 16 bytes (lane (m, h): row m of the tile, samples 16 g + 8 h .. + 7); ff_rec = per sample (padded to whole groups) the
+    // standardised covariates, s = 1 - 2 y, live = 1 (0 behind sample N), w0 = the null model's weight, as doubles (FFC<Q>::RS per sample).  null = the two-pass rounds.
+    const void *ff_tab;
+    const double *ff_rec;
+    const double *ff_inull;       // sum_i w0_i m2(i) over the degree-2 table's rows, with the table's own (hi + lo) values: the null model's covariate block of I
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
 #define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */

@@ -1,6 +1,7 @@
-"""Multi-GPU sharding of the k-mer stream: contiguous variant ranges per rank, per-run constants
-replicated, no collective on the data path.  The only cross-rank traffic is the end-of-run sum of the driver's four
-counters (loaded / pre-filtered / tested / printed, pyseer/__main__.py:831-834)."""
+"""Multi-GPU sharding of the k-mer stream: contiguous variant ranges per rank / per device, per-run constants
+replicated, no collective on the data path.  Two forms: one PROCESS per GPU under torch.distributed (bench.py; the helpers below carry its
+set-up broadcast and end-of-run reductions) and one process driving one context per GPU (the command line, pyseer_amd/__main__.py: one
+pipelined stream per device over its own range of the packed cache; ShardedEngine: a batch split across contexts behind the Engine interface)."""
 import numpy as np
 
 
@@ -11,27 +12,67 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def sum_counters(counters, group=None):
-    """All-reduce (SUM) of small integer counters across ranks; identity when torch.distributed is not initialised."""
+# ---- set-up and end-of-run traffic of a one-process-per-GPU job (bench.py under torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" in the
+# CPU tests).  `device`: where the collective's tensors live -- the rank's GPU for nccl, "cpu" for gloo.  None of this is on the data path.
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def ranks_connected(device="cpu"):
+    """How many ranks the collective library really connected: an all-reduce of ones (1 when torch.distributed is not initialised)."""
     import torch
-    import torch.distributed as dist
-    t = torch.as_tensor(np.asarray(counters, dtype=np.int64))
-    if dist.is_available() and dist.is_initialized():
-        if dist.get_backend(group) == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t.cpu().numpy()
+    dist = _dist()
+    if dist is None:
+        return 1
+    one = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(one)
+    return int(one.item())
 
 
-def gather_in_order(local_rows, group=None):
-    """Concatenate per-rank result arrays in rank order (= input order, which the reference guarantees even with
-    --cpu N since starmap preserves order, pyseer/__main__.py:541-568)."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return np.asarray(local_rows)
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, np.asarray(local_rows), group=group)
-    return np.concatenate(parts, axis=0)
+def broadcast_run_constants(arrays, src=0, device="cpu"):
+    """The per-run constants of the job ({name: float64 ndarray}, e.g. U, S, y, h2 of the LMM: rank `src` decomposes the kinship once)
+    -> the same dict on every rank.  Ranks other than `src` pass None.  Names and shapes travel first, then one broadcast per array."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return arrays
+    me = dist.get_rank()
+    meta = [[(k, tuple(np.asarray(v).shape)) for k, v in arrays.items()]] if me == src else [None]
+    dist.broadcast_object_list(meta, src=src)
+    out = {}
+    for name, shape in meta[0]:
+        if me == src:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(arrays[name], dtype=np.float64).reshape(shape))).to(device)
+        else:
+            t = torch.empty(shape, dtype=torch.float64, device=device)
+        dist.broadcast(t, src)
+        out[name] = arrays[name] if me == src else t.cpu().numpy()
+        del t
+    return out
+
+
+def max_over_ranks(x, device="cpu"):
+    """MAX of a float over the ranks (the job's wall time is its slowest rank's)."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_floats(values, device="cpu"):
+    """Every rank's small vector of floats, in rank order: list (one entry per rank) of lists."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return [[float(v) for v in values]]
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    g = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(g, mine)
+    return [[float(v) for v in t.cpu()] for t in g]
 
 
 class ShardedEngine(object):

@@ -212,25 +212,27 @@ def test_limb_accuracy_stress(h2_force):
         assert d[0] < tol and d[1] < tol and d[2] < 10 * tol, (L, d)
 
 
-def test_bench_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_on_one_gpu(tmp_path, world):
     """The N > 1 path of bench.py (rank 0 decomposes the kinship once and broadcasts it, every rank tests its own shard, MAX over ranks,
-    per-rank values gathered) launched exactly as the driver launches it, with both ranks on cuda:0 and the gloo backend standing in for
-    RCCL (a one-GPU box cannot host two RCCL ranks)."""
+    per-rank values gathered) launched exactly as the driver launches it -- at the driver's N = 2 and N = 8 -- with every rank on cuda:0 and
+    the gloo backend standing in for RCCL (a one-GPU box cannot host several RCCL ranks)."""
     import json
     import subprocess
     env = dict(os.environ); env["PYTHONPATH"] = ROOT
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--variants-per-step", "65536", "--backend", "gloo", "--one-device"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    vs = 65536 if world == 2 else 32768
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29517 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--variants-per-step", str(vs), "--backend", "gloo", "--one-device"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["world"] == 2 and len(d["per_rank_value"]) == 2 and d["finite_fraction"] == 1.0
+    assert d["n_gpus"] == world and d["world"] == world and len(d["per_rank_value"]) == world and d["finite_fraction"] == 1.0
     assert d["parity_checked"] == 64 and max(d["parity_max_rel_dev"].values()) < 1e-9
-    assert abs(d["value"] - 2 * 65536 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - world * vs * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d                                  # N = 1 only
-    assert d["rccl_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
+    assert d["rccl_ranks_seen"] == world and d["collective_backend"] == "gloo"
 
 
 def test_bench_one_rank_under_torchrun_equals_the_plain_launch():

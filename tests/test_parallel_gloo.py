@@ -23,19 +23,26 @@ def test_shard_bounds_partition():
 
 
 def _worker(rank, world, port, q):
+    """What bench.py does around its timed region under torch.distributed, on CPU tensors over gloo: the rank count check, the set-up broadcast
+    of the per-run constants from rank 0, every rank testing its own contiguous shard, MAX of the wall time, per-rank values in rank order."""
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    from pyseer_amd.parallel import shard_bounds, sum_counters, gather_in_order
+    from pyseer_amd import parallel as par
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(3)
-    K = (rng.random((101, 40)) < 0.3)
-    lo, hi = shard_bounds(K.shape[0], rank, world)
-    local = K[lo:hi].sum(axis=1).astype(np.float64)          # stand-in for a per-variant statistic
-    allr = gather_in_order(local)
-    cnt = sum_counters([hi - lo, int((local > 12).sum()), 0, 1])
+    seen = par.ranks_connected("cpu")
+    consts = None
     if rank == 0:
-        q.put((allr, cnt, K.sum(axis=1).astype(np.float64), int((K.sum(axis=1) > 12).sum())))
+        rng = np.random.default_rng(3)
+        consts = {"K": (rng.random((101, 40)) < 0.3).astype(np.float64), "h2": np.array([0.25]), "empty": np.zeros((0, 3))}
+    consts = par.broadcast_run_constants(consts, 0, "cpu")
+    K = consts["K"]
+    lo, hi = par.shard_bounds(K.shape[0], rank, world)
+    local = K[lo:hi].sum(axis=1)                              # stand-in for a per-variant statistic
+    slowest = par.max_over_ranks(1.0 + rank, "cpu")
+    g = par.gather_floats([float(hi - lo), float(local.sum()), float(consts["h2"][0])], "cpu")
+    if rank == 0:
+        q.put((seen, slowest, g, K.sum(), tuple(consts["empty"].shape)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,12 +54,19 @@ def test_two_rank_gloo_shard_and_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    allr, cnt, want, nbig = q.get(timeout=120)
+    seen, slowest, g, total, eshape = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert np.array_equal(allr, want)
-    assert cnt.tolist() == [101, nbig, 0, 2]
+    assert seen == 2 and slowest == 2.0 and eshape == (0, 3)
+    assert [x[0] for x in g] == [51.0, 50.0] and sum(x[1] for x in g) == total and [x[2] for x in g] == [0.25, 0.25]
+
+
+def test_helpers_without_a_process_group_are_the_identity():
+    from pyseer_amd import parallel as par
+    assert par.ranks_connected() == 1 and par.max_over_ranks(3.5) == 3.5 and par.gather_floats([1, 2]) == [[1.0, 2.0]]
+    d = {"a": np.arange(3.0)}
+    assert par.broadcast_run_constants(d) is d
 
 
 def test_a_failed_shard_is_rerun_on_another_context():

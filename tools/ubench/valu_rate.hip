@@ -3,6 +3,7 @@
 // at W waves per SIMD.  Build: hipcc -O3 --offload-arch=gfx950 valu_rate.hip -o valu_rate ; run: ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define ITERS 4096
 #define REP16(x) x x x x x x x x x x x x x x x x
@@ -116,9 +117,44 @@ template <int KIND> static void runv(const char *name, int w, double *o)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-18s W=%d: %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n", name, w, ms * 1e-3 * 2.4e9 / ((double)ITERS * 16 * w));
 }
+
+// MFMA beside the vector ALU within ONE wavefront: per iteration NM v_mfma_f32_32x32x16_f16 (independent accumulators) interleaved with NV
+// independent v_fma_f64 (8 chains).  If the two units overlap inside a wavefront, time = max of the two; if not, the sum.
+typedef _Float16 ub_v8h __attribute__((ext_vector_type(8)));
+typedef float ub_v16f __attribute__((ext_vector_type(16)));
+template <int NM, int NV>
+__global__ __launch_bounds__(256) void km(double *out)
+{
+    double a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i;
+    double b = 1.0000001, c = 1e-9;
+    ub_v16f acc[4]; for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    ub_v8h A, B; for (int r = 0; r < 8; ++r) { A[r] = (_Float16)(threadIdx.x * 0.001f + r); B[r] = (_Float16)(r * 0.5f); }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < NM) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[u]) : "v"(A), "v"(B));
+#pragma unroll
+            for (int q = 0; q < NV / 4; ++q) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[(u * (NV / 4) + q) & 7]) : "v"(b), "v"(c));
+        }
+    }
+    double s = 0; for (int i = 0; i < 8; ++i) s += a[i];
+    for (int t = 0; t < 4; ++t) s += acc[t][0] + acc[t][7];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NM, int NV> static void runm(int w, double *o)
+{
+    const int blocks = 256 * w;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((km<NM, NV>), dim3(blocks), dim3(256), 0, 0, o); hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL((km<NM, NV>), dim3(blocks), dim3(256), 0, 0, o); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("per iteration %d MFMA 32x32x16 f16 + %2d v_fma_f64, W=%d: %.1f cycles per iteration per SIMD at 2.4 GHz\n", NM, NV, w, ms * 1e-3 * 2.4e9 / ((double)ITERS * w));
+}
 int main()
 {
     double *o; float *of; hipMalloc(&o, 8 << 20); hipMalloc(&of, 4 << 20);
+    for (int w = 1; w <= 2; ++w) { runm<4, 0>(w, o); runm<0, 32>(w, o); runm<4, 32>(w, o); runm<4, 16>(w, o); runm<4, 64>(w, o); runm<1, 32>(w, o); runm<2, 32>(w, o); }
+    if (getenv("UB_MFMA_ONLY")) return 0;
     for (int w = 1; w <= 2; ++w) {
         run<0>("v_fma_f64", w, o, of, 2.4); run<6>("v_fma_f64 (SGPR operand)", w, o, of, 2.4); run<4>("v_mul_f64 / v_add_f64", w, o, of, 2.4);
         run<1>("v_fma_f32", w, o, of, 2.4); run<2>("v_pk_fma_f32", w, o, of, 2.4); run<3>("v_pk_fma_f32 op_sel_hi (broadcast)", w, o, of, 2.4);
