@@ -40,6 +40,9 @@ typedef double ff_v2d __attribute__((ext_vector_type(2)));
 #ifndef FF_ABL
 #define FF_ABL 0                   /* timing ablations (results meaningless): 1 = no MFMAs, 2 = no LDS-DMA / barriers, 4 = no sample arithmetic; 8 (results valid) = every fit finished by the exact kernel */
 #endif
+#ifndef FF_RHO
+#define FF_RHO 0.05               /* largest relative change of I's diagonal against the null model for a fit to be finished from the one-pass F */
+#endif
 #ifndef FF_STAGGER
 #define FF_STAGGER 0              /* s_sleep units (64 cycles) between the wavefronts of a block after every barrier */
 #endif
@@ -103,11 +106,13 @@ __device__ __forceinline__ void ff_row2k(float tv, const double (&V)[FFC<Q>::NH]
 }
 // row R of the degree-2 table against w: the entry I_{ab} of the covariate block (design columns other than k)
 template <int Q, int R>
-__device__ __forceinline__ void ff_row2i(float tv, const double *__restrict__ inull, double (&I)[FFC<Q>::NH])
+__device__ __forceinline__ void ff_row2i(float tv, const double *__restrict__ inull, double (&I)[FFC<Q>::NH], double &rho)
 {
     if constexpr (R < FFC<Q>::N2) {
         constexpr FFMono m = ff_dec2(R);
-        I[sidx(ff_design(m.a), ff_design(m.b))] = inull[R] + (double)tv;
+        const double v0 = inull[R];
+        I[sidx(ff_design(m.a), ff_design(m.b))] = v0 + (double)tv;
+        if constexpr (m.a == m.b) rho = fmax(rho, fabs((double)tv) / v0);       // how far the weights are from the null model's, on the diagonal
     }
 }
 // the 32 rows of one accumulator tile, every lane seeing all of them: register r of a lane holds row (r & 3) + 8 (r >> 2) + 4 h
@@ -133,9 +138,10 @@ __device__ __forceinline__ void ff_tile2k(const float (&row)[32], const double (
     (ff_row2k<Q, TILE * 32 + Rs>(row[Rs], V, g), ...);
 }
 template <int Q, int TILE, int... Rs>
-__device__ __forceinline__ void ff_tile2i(const float (&row)[32], const double *__restrict__ inull, double (&I)[FFC<Q>::NH], std::integer_sequence<int, Rs...>)
+__device__ __forceinline__ void ff_tile2i(const float (&row)[32], const double *__restrict__ inull, double (&I)[FFC<Q>::NH], double &rho,
+                                          std::integer_sequence<int, Rs...>)
 {
-    (ff_row2i<Q, TILE * 32 + Rs>(row[Rs], inull, I), ...);
+    (ff_row2i<Q, TILE * 32 + Rs>(row[Rs], inull, I, rho), ...);
 }
 template <int Q, int... Ts>
 __device__ __forceinline__ void ff_all3(const ff_v16f (&acc)[FFC<Q>::NACC], int h, float unscale, const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC],
@@ -167,7 +173,7 @@ __device__ __forceinline__ void ff_all2k(const ff_v16f (&acc)[FFC<Q>::NACC], int
 }
 template <int Q, int... Ts>
 __device__ __forceinline__ void ff_all2i(const ff_v16f (&acc)[FFC<Q>::NACC], int h, float unscale, const double *__restrict__ inull, double (&I)[FFC<Q>::NH],
-                                         std::integer_sequence<int, Ts...>)
+                                         double &rho, std::integer_sequence<int, Ts...>)
 {
     auto one = [&](auto tile) {
         constexpr int TL = decltype(tile)::value;
@@ -175,7 +181,7 @@ __device__ __forceinline__ void ff_all2i(const ff_v16f (&acc)[FFC<Q>::NACC], int
         ff_rows(acc[TL], h, row);
 #pragma unroll
         for (int r = 0; r < 32; ++r) row[r] *= unscale;
-        ff_tile2i<Q, TL>(row, inull, I, std::make_integer_sequence<int, 32>{});
+        ff_tile2i<Q, TL>(row, inull, I, rho, std::make_integer_sequence<int, 32>{});
     };
     (one(std::integral_constant<int, Ts>{}), ...);
 }
@@ -436,7 +442,8 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     double I[NH];
 #pragma unroll
     for (int a = 0; a < NH; ++a) I[a] = 0.0;
-    ff_all2i<Q>(acc, h, unscale, P.ff_inull, I, std::make_integer_sequence<int, T2>{});
+    double rho = 0.0;
+    ff_all2i<Q>(acc, h, unscale, P.ff_inull, I, rho, std::make_integer_sequence<int, T2>{});
     I[sidx(1, 0)] = Ik[0]; I[sidx(1, 1)] = Ik[0];
 #pragma unroll
     for (int j = 0; j < Q; ++j) I[sidx(2 + j, 1)] = Ik[1 + j];
@@ -518,8 +525,9 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     // The fit's LAST likelihood pass, saved (as k_firth_step2 does, firth_rounds.hip): the result is a step of ~1e-8 away, where F(beta + d) =
     // F(beta) - U.d / 2 (third-order terms ~ N |d|^3 < 1e-17) and I11(beta + d) = I11(beta) (1 + O(|d|)).  F here is the one-pass F: exact
     // log-likelihood, I = I(null) + the matrix-core sum of (w - w0) m2 (~1e-7 on log det), in the reference's columns (det I = det I_s prod s_j^2);
-    // I11 = sum w k in fp64 (the complement's: I00 - I11').  A last step above 1e-7 keeps the exact evaluation.
-    if (last && fin && dmax <= 1e-7 && !(FF_ABL & 8)) {
+    // I11 = sum w k in fp64 (the complement's: I00 - I11').  A last step above 1e-7 keeps the exact evaluation, and so does a fit whose weights
+    // have moved far from the null model's (rho > FF_RHO: a strong effect): the matrix-core sum's 1e-6 then shows in log det I at ~1e-6 rho.
+    if (last && fin && dmax <= 1e-7 && rho <= FF_RHO && !(FF_ABL & 8)) {
         double lsd = 0.0;
 #pragma unroll
         for (int j = 0; j < Q; ++j) lsd += log(P.wstd[Q + j]);

@@ -692,3 +692,43 @@ def test_strong_effects_and_awkward_covariates_sweep(N, q, V, seed):
     close(r["intercept"][~firth], want["intercept"][~firth], rtol=1e-7, atol=1e-12, what="intercept")
     close(r["bse"][~firth], want["bse"][~firth], rtol=6e-7, what="bse")
     close(r["pvalue"][~firth], want["pvalue"][~firth], rtol=1e-6, atol=1e-300, what="pvalue")
+
+
+@pytest.mark.parametrize("N,q,V", [(5000, 10, 4096), (4100, 1, 1024), (4099, 3, 777), (6007, 7, 1500), (4096, 10, 640), (8200, 5, 512)])
+def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
+    """Forced Firth at N >= 4096 (BASELINE config C4's mode): the one-pass iteration (firth_fast.hip: third-moment tensor and information matrix
+    on the matrix cores, fits finished in the kernel) against the exact two-pass rounds (SEERHIP_FIRTH_FAST=0).  Same flags; statistics to
+    1e-6 relative (kbeta: or 2e-8 absolute -- the penalty's share of the fixed point carries the matrix-core sums' 1e-6); sample counts that
+    are not multiples of 16 or 64, every supported design width, majority-carrier rows (taken by their complement), rare rows, rows no
+    iteration can fit (all carriers share the phenotype: those leave the fast passes for the exact kernels)."""
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(97 + N + q)
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    eta = -0.3 + 1.2 * W[:, 0] - (0.7 * W[:, 1] if q > 1 else 0.0)
+    y = (rng.random(N) < 1 / (1 + np.exp(-eta))).astype(float)
+    af = np.concatenate([rng.uniform(0.02, 0.98, V - V // 4), rng.uniform(0.0101, 0.03, V // 8), rng.uniform(0.97, 0.9899, V // 4 - V // 8)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K[: V // 10] = (rng.random((V // 10, N)) < (0.15 + 0.5 * y)[None, :]).astype(np.uint8)              # real effects
+    ones = np.where(y == 1)[0]
+    for r in range(V // 10, V // 10 + 8):                                                              # carriers only among the phenotype-1 samples
+        K[r] = 0; K[r, rng.choice(ones, 60 + 10 * (r % 5), replace=False)] = 1
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    bits = pack_variants(K)
+    out = {}
+    for mode, val in (("two", "0"), ("one", None)):
+        if val is None:
+            monkeypatch.delenv("SEERHIP_FIRTH_FAST", raising=False)
+        else:
+            monkeypatch.setenv("SEERHIP_FIRTH_FAST", val)
+        e = Engine(N); e.set_af_filter(0.01, 0.99); e.glm_setup(y, W, False, nl, nf, force_firth=True); out[mode] = e.glm_batch(bits); e.close()
+    a, b = out["two"], out["one"]
+    assert np.array_equal(a["flags"], b["flags"]), np.where(a["flags"] != b["flags"])[0][:10]
+    ok = np.isfinite(a["kbeta"])
+    assert ok.sum() > V // 2 and np.array_equal(ok, np.isfinite(b["kbeta"]))
+    close(b["pvalue"][ok], a["pvalue"][ok], rtol=1e-6, atol=1e-300, what="pvalue")
+    close(b["bse"][ok], a["bse"][ok], rtol=1e-6, what="bse")
+    close(b["kbeta"][ok], a["kbeta"][ok], rtol=1e-6, atol=2e-8, what="kbeta")
+    close(b["intercept"][ok], a["intercept"][ok], rtol=1e-6, atol=2e-8, what="intercept")
+    close(b["betas"][ok], a["betas"][ok], rtol=1e-6, atol=2e-8, what="betas")
