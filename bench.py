@@ -31,11 +31,12 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6     # gfx950 fp64 vector peak (SURVEY.md section 
 REFERENCE_PER_CORE = {"logistic": 112.0, "firth": 1.0, "lmm": 303.0}
 GLM_KERNELS = {False: "k_glm_fast<Q,true> (prefilter, routing) + k_glm_bitdot + k_glm_solve32 + k_glm_pass32(_split) + k_glm_score(_split) / k_glm_chord + k_glm_ll + "
                       "k_glm_dpass_pk + k_glm_finish (+ k_glm_slow_blk and the Firth kernels for routed rows)",
-               True: "k_glm_fast<Q,true> + k_glm_bitdot + k_firth_init2 + rounds of k_firth_eval2 / k_firth_step2 (+ k_firth_step<Q,true> behind the pivot guard, "
-                     "k_firth_blk past the hand-off)"}
+               True: "k_glm_fast<Q,true> + k_glm_bitdot + k_firth_init2 + passes of k_firth_fast (one sample pass per Firth iteration: eta / exp / log-likelihood / "
+                     "exact score in fp64 on the vector ALU, the information matrix and the penalty's third-moment tensor as f16 hi/lo MFMAs with fp32 accumulation; "
+                     "fits finished in the kernel) + k_firth_eval2 / k_firth_step2 (exact two-pass rounds) for the fits that leave the fast passes"}
 FP64_FLOP_PER_TEST = 5.0e7         # 2*k*N + 6k fp64 flop of the reference formulation, k=4999
 ALGO_BYTES_PER_TEST = 673          # ceil(N/8) in + 48 out
-PROFILE_DIRS = ("r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
+PROFILE_DIRS = ("r04", "r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -303,8 +304,10 @@ def measured_flops(tag):
     SQ_INSTS_VALU_MFMA_MOPS_F32 over one batch of the same synthetic workload (tools/profile_r02.sh)."""
     t, src = _profile_json("flops_%s.json" % tag)
     if t is None:
-        return None, None, None
-    return t["fp64_flops_per_variant"], t.get("fp32_flops_per_variant", 0.0), "%s: %s" % (src, t["source"])
+        return None, None, None, None, None
+    vi = t.get("counters", {}).get("SQ_INSTS_VALU")
+    return (t["fp64_flops_per_variant"], t.get("fp32_flops_per_variant", 0.0), "%s: %s" % (src, t["source"]), t.get("fp16_mfma_flops_per_variant", 0.0),
+            None if not vi else vi / t["variants_per_step"])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -313,7 +316,7 @@ def glm_roofline(cfg, q, Vs, kern_s, klaunch, rb):
     per step / the HIP-event time of the fit's kernels per step, against the fp64 vector peak; traffic from the committed FETCH/WRITE passes."""
     force = cfg == "C4"
     tag = cfg.lower()
-    f64, f32, fsrc = measured_flops(tag)
+    f64, f32, fsrc, f16, vinst = measured_flops(tag)
     traffic, traffic_src = measured_traffic(tag, Vs)
     achieved = None if f64 is None else f64 * Vs / kern_s / 1e12
     return {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -322,14 +325,20 @@ def glm_roofline(cfg, q, Vs, kern_s, klaunch, rb):
             "kernel": GLM_KERNELS[force], "kernel_ms": kern_s * 1e3, "launches": klaunch,
             "ops": "fp64 lane-flops actually executed per variant (PMC: 64 x (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64)) x variants per step "
                    "/ HIP-event time of those kernels per step; single-precision work (first Newton rounds, the Firth hat diagonal) is reported beside it, not added",
-            "fp64_flops_per_variant": f64, "fp32_flops_per_variant": f32, "flops_source": fsrc,
+            "fp64_flops_per_variant": f64, "fp32_flops_per_variant": f32, "fp16_mfma_flops_per_variant": f16, "flops_source": fsrc,
+            "mfma_f16_tflops": None if not f16 else f16 * Vs / kern_s / 1e12,
+            # what binds these kernels is the vector ALU's ISSUE rate, whatever the precision (fp64, packed fp32 and conversions each take one
+            # 4-cycle slot per wavefront instruction; tools/ubench/valu_rate.hip): wavefront-level VALU instructions per variant (PMC SQ_INSTS_VALU,
+            # MFMAs included) x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz)
+            "valu_wave_insts_per_variant": vinst,
+            "valu_issue_frac": None if not vinst else vinst * Vs * 4.0 / (1024.0 * kern_s * NOMINAL_SCLK_MHZ * 1e6),
             "hbm_algorithmic_GBps": (rb + (5 + q) * 8 + 4) * Vs / kern_s / 1e9}
 
 
 def glm_metric(cfg, N):
     force = cfg == "C4"
     return ("k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
-            "f64 (likelihood, information matrix, score) + f32 hat diagonal" if force
+            "f64 (eta, likelihood, score, solves) + f16 hi/lo MFMA with fp32 accumulation (information matrix, third-moment tensor of the penalty); f64 throughout for the fits the exact kernels take" if force
             else "f64 (score, likelihood, final information matrix) + f32 Hessian in the first Newton phase")
 
 

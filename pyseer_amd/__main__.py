@@ -666,9 +666,8 @@ def main(argv=None):
         # therefore handed on len(engs) iterations late.  Synchronous calls left the device idle for a third of every call (first chunk's
         # staging + upload at the head, the last chunk's kernels + download at the tail: 12.6 ms per 262 144-row block of which 8 ms were
         # kernels).  With one context the loop also announces the rows of the block it has read ahead (sh_prefetch_rows).
-        # SEERHIP_CLI_PIPELINE=0: synchronous calls.
         import collections
-        pipe = os.environ.get("SEERHIP_CLI_PIPELINE", "1") != "0"
+        pipe = True
         G = len(engs)
         pend = collections.deque()                        # (block, results, engine) handed to the engine, not yet to the sink
         blocks = iter(blocks)

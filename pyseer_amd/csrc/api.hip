@@ -67,7 +67,7 @@ struct sh_ctx {
     double err_norm_ulp = 0.0, err_norm_est_ulp = 0.0, lmm_tol = 1e-8, trace_M = 0.0; int err_norm_squarings = 0;
     uint8_t *d_flip = nullptr; uint64_t *d_T3 = nullptr; double *d_q3 = nullptr; int *d_rlist = nullptr, *d_rcount = nullptr;
     unsigned long long *d_bmax = nullptr; int64_t cap_ref = 0;
-    int qf_split = 1;             // 1: one block per (variant tile, limb) (SEERHIP_QF_SPLIT=0: one block per tile loops over the limbs)
+    int qf_split = 1;             // 1: one block per (variant tile, limb) (0: one block per tile loops over the limbs; not selectable any more)
     int qf_variant = 4;           // hot-kernel variant: 4 = k_lmm_quadform_i8w (one wavefront per SIMD; the launcher falls back to 0 where its conditions do not
                                   // hold), SEERHIP_QF=0 = k_lmm_quadform_i8 (two wavefronts per SIMD), other values = timing ablations (lmm_kernels.hip)
     // ---- GLM state
@@ -82,7 +82,7 @@ struct sh_ctx {
     int *h_nkeep = nullptr; hipEvent_t keep_ev = nullptr; bool keep_pending = false; int64_t keep_V = 0; double filtered_hint = 0.0;
     // ---- optional timing of the dominant kernel (sh_set_timing / sh_get_timing)
     int timing = 0;
-    int lin_tab = 1;                                  // SEERHIP_LIN=0: per-sample k_lmm_linear instead of the nibble tables
+    int lin_tab = 1;                                  // 0 would be the per-sample k_lmm_linear instead of the nibble tables
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
     // ---- pattern de-duplication (sh_set_dedup)
     int dedup = 0; int64_t dd_cap = 0, dd_capV = 0, dd_last_unique = -1;
@@ -435,8 +435,6 @@ sh_ctx *sh_create(int device, int n_samples)
     sh_ctx *c = new sh_ctx();
     c->device = device; c->N = n_samples;
     if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
-    if (const char *qs = std::getenv("SEERHIP_QF_SPLIT")) c->qf_split = std::atoi(qs);
-    if (const char *ql = std::getenv("SEERHIP_LIN")) c->lin_tab = std::atoi(ql);
     if (const char *ac = std::getenv("SEERHIP_AFCOMPACT")) c->af_compact = std::atoi(ac);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
@@ -645,7 +643,6 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     // E extra limbs below the L of the main pass (at most 7 in all: 0.49 * 256^7 is where fp64 itself ends); contracted only for the
     // variants whose a-posteriori bound exceeds lmm_tol
     int E = std::min(2, 7 - L);
-    if (const char *ev = std::getenv("SEERHIP_LMM_EXTRA")) E = std::max(0, std::min(E, std::atoi(ev)));
     const int Lt = L + E;
     const size_t gbytes = (size_t)Lt * NR * (NR + 1) * 8192;
     double *d_W = nullptr, *d_sgn = nullptr, *d_M = nullptr; unsigned long long *d_amax = nullptr;

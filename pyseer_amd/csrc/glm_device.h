@@ -70,11 +70,9 @@ __device__ __forceinline__ XWave xwave()
 }
 
 // wavefronts per 64 variants in the list-driven kernels: a function of the sample count only, so that results do not depend
-// on what else is in a batch.  SEERHIP_SPLIT=1|2|4|8 overrides it (A/B timing).
+// on what else is in a batch.
 static int glm_split_waves(int NB64)
 {
-    static const int forced = [] { const char *e = getenv("SEERHIP_SPLIT"); return e ? atoi(e) : 0; }();
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     return NB64 >= 64 ? 8 : NB64 >= 8 ? 4 : NB64 >= 4 ? 2 : 1;      // measured at N = 500 ... 5000
 }
 static size_t glm_split_lds(int S) { return S > 1 ? (size_t)((S - 1) * XW_CH + 2) * 64 * sizeof(double) : 0; }

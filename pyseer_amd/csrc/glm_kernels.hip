@@ -515,16 +515,6 @@ __global__ __launch_bounds__(CHORD ? 256 : 64, CHORD ? 1 : GLM_FAST_WAVES) void 
     }
     bool need_slow = want_fit && (P.newton_mode == 1);
     bool active = want_fit && !need_slow;
-    // tile mode (glm_tile.hip): this kernel only classifies; the fits run 16 variants per wavefront on the matrix pipe, from a dense list
-    const bool to_tile = active && P.tile_mode;
-    if (P.tile_mode) {
-        active = false;
-        const unsigned long long tm = __ballot(to_tile);
-        int base = 0;
-        if ((threadIdx.x & 63) == 0 && tm) base = atomicAdd(wk.tile_count, __popcll(tm));
-        base = __shfl(base, 0);
-        if (to_tile) wk.tile_list[base + __popcll(tm & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)v;
-    }
     int it = 0, pass = 0;
     // CHORD: this kernel only classifies; the fits run as rounds of lean kernels over lists (k_glm_pass32 ... k_glm_chord below)
     const bool chord_go = CHORD && active;
@@ -593,8 +583,8 @@ __global__ __launch_bounds__(CHORD ? 256 : 64, CHORD ? 1 : GLM_FAST_WAVES) void 
 #pragma unroll
     for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
     flags[v] = fl;
-    wk.state[v] = (want_fit && !need_slow && !to_tile && !chord_go) ? 1 : 0;
-    if (want_fit && !need_slow && !to_tile && !chord_go) {
+    wk.state[v] = (want_fit && !need_slow && !chord_go) ? 1 : 0;
+    if (want_fit && !need_slow && !chord_go) {
         if (P.ws) {                                                  // z' = (z - mean) / scale  =>  b = b' / scale, b0 = b0' - sum b' mean / scale
 #pragma unroll
             for (int j = 0; j < Q; ++j) { beta[2 + j] = beta[2 + j] / P.wstd[Q + j]; beta[0] = fma(-beta[2 + j], P.wstd[j], beta[0]); }

@@ -15,9 +15,9 @@ struct GlmParams {
     const double *ws;             // N x q covariates standardised per column (the fast Newton path iterates in these coordinates), or null
     const double *wstd;           // [2q] column means, then column scales, of that standardisation
     const double *ztz, *zty;      // Z^T Z (packed lower, (q+1) x (q+1)) and Z^T y for Z = [1, W]: the variant-independent part of the OLS normal equations
-    int firth_halv_handoff;       // rejected halvings of one step after which a variant leaves the rounds for k_firth_blk (SEERHIP_FIRTH_HALV_HANDOFF, default 6)
-    int firth_handoff;            // accepted Firth steps after which a variant leaves the rounds for k_firth_blk (SEERHIP_FIRTH_HANDOFF)
-    int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (SEERHIP_F32STEPS, default 3)
+    int firth_halv_handoff;       // rejected halvings of one step after which a variant leaves the rounds for k_firth_blk (default 6)
+    int firth_handoff;            // accepted Firth steps after which a variant leaves the rounds for k_firth_blk (16, or 0 for the routed variants of an ordinary run at N >= 768)
+    int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (default 3, 2 with the warm start)
     // Firth step halving (model.py:465-474).  Default: an increase of F within firth_noise * |F| (4 ulp) is evaluation noise, and a step
     // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_FIRTH_LITERAL=1 / SEERHIP_FIRTH_STRICT=1 set both
     // to 0: the reference's literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
@@ -34,8 +34,7 @@ struct GlmParams {
                                   // a0 = sum_i w0_i z_ij z_ik packed (j >= k), both in the standardised coordinates; null = plain fp64 pass
     int firth_warm;               // 1: Firth rounds start at fwarm = the null-model fit [b0, bz...] in the ORIGINAL covariate coordinates (force_firth only)
     double fwarm[16];
-    int tile_mode;                // 1: k_glm_fast only classifies and lists; the Newton fits run in k_glm_tile (glm_tile.hip)
-    int *dbg;                     // development counters (SEERHIP_GLM_DEBUG): [0] wave passes, [1] waves, [2] lane steps, [3] fitted lanes, [4] final-pass repeats
+    int *dbg;                     // development counters (unused: null): [0] wave passes, [1] waves, [2] lane steps, [3] fitted lanes, [4] final-pass repeats
     double f32_tol;               // a single-precision pass whose step is <= f32_tol ends the fast phase (the fp32 score's noise floor is ~1e-7)
     double fast_tol;              // largest step (any coordinate) at which the fast phase hands over to the final pass' exact Newton step
     // The fast phase as rounds of lean kernels over lists (glm_kernels.hip, "the fast phase as ROUNDS"): single-precision Newton rounds until a
@@ -59,7 +58,7 @@ struct GlmParams {
     const float *wfp, *yf, *w0f;  // packed-fp32 passes (pass32_pk): wfp = per pair of samples a record of Q + 2 float2 (standardised covariates, y, w0;
                                   // each (even sample, odd sample)); yf, w0f = y and w0 as float arrays (the odd last sample); null = unpacked passes
     const double *rec;            // per sample a record of Q + 1 doubles (standardised covariates, then y): k_glm_score / k_glm_ll
-    int firth_lean;               // bit 0: k_firth_eval<Q, true>, bit 1: k_firth_step<Q, true> (both when rec_o is set; SEERHIP_FIRTH_LEAN=1/2 selects one for A/B)
+    int firth_lean;               // bit 0: k_firth_eval<Q, true>, bit 1: k_firth_step<Q, true> (both when rec_o is set)
     const double *rec_f;          // Firth round kernels (firth_rounds.hip): per sample Q covariates as given, then s = 1 - 2 y
     const float *rec_pf;          // per PAIR of samples Q float2 = (even, odd) standardised covariates: k_firth_step2 (staged through LDS)
     const double *rec_o;          // the same with the covariates as given, y in {0, 1} only: the Firth rounds (info_pass_bin); null = info_pass

@@ -1106,7 +1106,7 @@ extern "C" hipError_t shk_glm_wide_lineage(hipStream_t st, const uint64_t *T, in
                                            int pc, int nlin, int *out)
 {
     if (pc > WIDE_LIN_PM) return hipErrorInvalidValue;
-    static const int blk = [] { const char *e = getenv("SEERHIP_WIDE_BLK"); return e ? atoi(e) : 1; }();
+    const int blk = 1;
     if (blk) hipLaunchKernelGGL(k_glm_wide_lineage_blk, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, N, X, pc, nlin, out);
     else hipLaunchKernelGGL(k_glm_wide_lineage, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, T, Vpad, V, N, NB64, X, pc, nlin, out);
     return hipGetLastError();

@@ -1044,8 +1044,8 @@ hipError_t shk_lmm_quadform(hipStream_t st, int variant, const int8_t *G, const 
     const bool wide_var = variant == 4 || variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 50 || variant == 441 || variant == 162 || variant == 35;
     if (wide_var && !wide_ok) variant = 0;
     // the extra-limb pass (variant 64: a launch sized for the whole batch over a short list, `nlimit`) runs the same kernel under its own name
-    // (template argument DM = 3); SEERHIP_QF_REFINE=0 keeps k_lmm_quadform_i8<64>
-    static const bool refine_wide = [] { const char *e = getenv("SEERHIP_QF_REFINE"); return !(e && atoi(e) == 0); }();
+    // (template argument DM = 3)
+    const bool refine_wide = true;
     if (variant == 64 && wide_ok && refine_wide) variant = 464;
     const bool wide = (wide_var && wide_ok) || variant == 464;       // 128 x 128 wave tiles, one wavefront per SIMD
     // rows_last = valid rows (samples) of the last 128-row tile; the wide kernel contracts only the 32-row sub-tiles that hold any (4, 2, 1, or none:

@@ -515,11 +515,6 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
         }
         counts[v] = cnt;
     });
-    if (std::getenv("SEERHIP_READER_DEBUG")) {
-        auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[reader] %lld lines: read+split %.3fs parse %.3fs\n", (long long)nv,
-                std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
-    }
     return nv;
 }
 

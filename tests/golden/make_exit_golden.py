@@ -188,7 +188,7 @@ def search(name, family, seed, N, q, par, want, n_want, max_tries, n_ctrl=6, bud
     t0 = time.time(); tries = 0; n_hit = 0; n_c = 0
     while tries < max_tries and (n_hit < n_want or n_c < n_ctrl) and time.time() - t0 < budget_s:
         k = next(gen); tries += 1
-        key = k.tobytes()
+        key = hash(k.tobytes())
         if key in seen:
             continue
         seen.add(key)
@@ -197,6 +197,8 @@ def search(name, family, seed, N, q, par, want, n_want, max_tries, n_ctrl=6, bud
             if nm >> i & 1:
                 hist[n_] = hist.get(n_, 0) + 1
         hit = bool(nm & BIT[want])
+        if hit or tries % 20000 == 0:
+            print("    [%s] candidate %d after %.0f s: notes %d%s" % (name, tries, time.time() - t0, nm, "  <-- " + want if hit else ""), flush=True)
         if (hit and n_hit < n_want) or (not hit and n_c < n_ctrl and tries % 2 == 0):
             kept.append((k, main, betas, nm, pf, fl)); n_hit += hit; n_c += (not hit)
     print("%-34s %6d candidates in %5.1f s: %d x %s, %d controls; notes seen %s" % (name, tries, time.time() - t0, n_hit, want, n_c, hist))

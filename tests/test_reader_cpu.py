@@ -399,3 +399,28 @@ def test_packed_cache_ranges_partition_the_rows(tmp_path, n_parts):
     # the parts hand over exactly the blocks of the single stream, in order
     assert len(got_blocks) == len(single) and all(np.array_equal(a, b) for a, b in zip(got_blocks, single))
     assert got_names == names_all and np.array_equal(np.concatenate(got_blocks, axis=0), bits_all)
+
+
+def test_parser_worker_count_does_not_change_the_rows(tmp_path, monkeypatch):
+    """SEERHIP_READER_THREADS (parser workers of the native reader; default min(48, cores)): one worker and five give the rows of the default."""
+    import gzip
+    samples = ["s%03d" % i for i in range(61)]
+    p = pd.Series(np.arange(61, dtype=float), index=samples)
+    rng = np.random.default_rng(8)
+    lines = []
+    for v in range(700):
+        car = [samples[i] for i in np.nonzero(rng.random(61) < 0.3)[0]]
+        lines.append("K%d%s | %s\n" % (v, "ACGT"[v % 4] * (v % 9), " ".join("%s:1" % s for s in car)))
+    path = str(tmp_path / "k.gz")
+    with gzip.open(path, "wt") as f:
+        f.writelines(lines)
+    got = {}
+    for nt in (None, "1", "5"):
+        if nt is None:
+            monkeypatch.delenv("SEERHIP_READER_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("SEERHIP_READER_THREADS", nt)
+        blocks = list(iter_packed_blocks_native(p, path, 0.0, 1.0, 128))
+        got[nt] = (np.concatenate([np.array(b.bits) for b in blocks]), b"".join(bytes(b.names_blob) for b in blocks))
+    assert np.array_equal(got[None][0], got["1"][0]) and np.array_equal(got[None][0], got["5"][0])
+    assert got[None][1] == got["1"][1] == got["5"][1] and got[None][0].shape[0] == 700

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round-4 profiling recipe (run on the GPU box through gpurun).  For every bench configuration:
+#   1. the bench line itself (C3 = the default invocation, i.e. what the driver runs, `extra` included)   -> bench_<cfg>.json
+#   2. rocprofv3 --kernel-trace --stats of the same command (without the CPU legs)                          -> stats_<cfg>/
+#   3. PMC passes in their own runs, one counter group per run (never combined with the trace domains gpurun refuses): FETCH_SIZE,
+#      WRITE_SIZE, GRBM_GUI_ACTIVE, SQ issue / wait cycles, fp64 / fp32 instruction counts (fixed effects), L2 hits and LDS (C3)     -> pmc_<cfg>_<group>/
+#      C3's passes run bench.py itself since round 3 (SEERHIP_BENCH_CPU_EIGH=1: rocSOLVER's eigensolver segfaults under counter collection;
+#      round 2 used a probe with random rows instead of the bench's data).
+# tools/summarize_prof.py collapses them into profiles/r04/.  CFGS / PMC=0 select a subset.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r04; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+CFGS=${CFGS:-"C3 C2 C2N5000 C4"}
+for c in $CFGS; do
+  if [ "$c" = "C3" ]; then python $R/bench.py --steps 10 --warmup 2 > $O/bench_$c.json 2> $O/bench_$c.err
+  else python $R/bench.py --config $c --steps 10 --warmup 2 > $O/bench_$c.json 2> $O/bench_$c.err; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$c -- python $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-extra --no-parity > $O/stats_$c.json 2> $O/stats_$c.err
+done
+pmc() {  # cfg group counters...
+  local c=$1 g=$2; shift 2
+  SEERHIP_BENCH_CPU_EIGH=1 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_${c}_$g -- python $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-extra > $O/pmc_${c}_$g.log 2>&1
+}
+for c in $CFGS; do
+  [ "${PMC:-1}" = "0" ] && continue
+  pmc $c fetch FETCH_SIZE
+  pmc $c write WRITE_SIZE
+  pmc $c grbm GRBM_GUI_ACTIVE
+  pmc $c sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES
+  if [ "$c" != "C3" ]; then
+    pmc $c f64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64
+    pmc $c f32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_MOPS_F32
+    pmc $c f16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_F16 SQ_INSTS_MFMA
+  else
+    pmc $c tcc TCC_HIT_sum TCC_MISS_sum
+    pmc $c lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_LDS
+  fi
+done
+python $R/tools/summarize_prof.py $O $R/gpurun_out/r04/profiles
+ls $R/gpurun_out/r04/profiles

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Collapse the rocprofv3 outputs of tools/profile_r03.sh (gpurun_out/prof_r03/) into the small files kept under profiles/r03/:
+"""Collapse the rocprofv3 outputs of tools/profile_r04.sh (gpurun_out/prof_r04/) into the small files kept under profiles/r04/:
   bench_<cfg>.json                         the bench lines
   rocprofv3_kernel_stats_<cfg>.csv         --kernel-trace --stats of the same command
   rocprofv3_pmc_summary_<cfg>.csv          per pass / kernel / counter: dispatches, sum, mean per dispatch
@@ -58,7 +58,7 @@ def main(src, dst):
             json.dump({"kernels": "k_lmm_quadform_i8w" if cfg == "C3" else "all k_glm_* / k_firth_* kernels of one step",
                        "variants_per_dispatch": V, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot.get("WRITE_SIZE"),
                        "fetch_correction": 2.0,
-                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r03.sh) on %s; gfx950: FETCH_SIZE "
+                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r04.sh) on %s; gfx950: FETCH_SIZE "
                                  "counts 64 B per 128-B request, hence x2 (MI355X_MICROARCH.md HBM section)"
                                  % ("bench.py --config %s --steps 1 --warmup 0 (the bench's own rows)" % cfg)},
                       open(os.path.join(dst, "traffic_%s.json" % tag), "w"), indent=1)
