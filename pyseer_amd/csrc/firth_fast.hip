@@ -54,18 +54,24 @@ typedef double ff_v2d __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int ff_tri(int a) { return a * (a + 1) / 2; }
 __host__ __device__ constexpr int ff_tet(int a) { return a * (a + 1) * (a + 2) / 6; }
 struct FFMono { int a, b, c; };
-// row r of the degree-2 table: z1_a z1_b, a >= b, r = tri(a) + b;  of the degree-3 table: a >= b >= c, r = tet(a) + tri(b) + c   (z1 = (1, z))
-__host__ __device__ constexpr FFMono ff_dec2(int r) { int a = 0; while (ff_tri(a + 1) <= r) ++a; return FFMono{a, r - ff_tri(a), 0}; }
-__host__ __device__ constexpr FFMono ff_dec3(int r) { int a = 0; while (ff_tet(a + 1) <= r) ++a; const FFMono m = ff_dec2(r - ff_tet(a)); return FFMono{a, m.a, m.b}; }
+// (z1 = (1, z), Z1 = Q + 1 entries.)  Degree-3 table: row r = tet(a) + tri(b) + c holds z1_a z1_b z1_c, a >= b >= c.  Degree-2 table: the Z1
+// monomials with the constant come first -- row a holds z1_a (a = 0: 1) -- so that tile 0 alone serves the k-row of I (sum w k z1_a); rows
+// Z1 + tri(a - 1) + (b - 1) hold z1_a z1_b for a >= b >= 1.
+__host__ __device__ constexpr FFMono ff_dec_tri(int r) { int a = 0; while (ff_tri(a + 1) <= r) ++a; return FFMono{a, r - ff_tri(a), 0}; }
+__host__ __device__ constexpr FFMono ff_dec3(int r) { int a = 0; while (ff_tet(a + 1) <= r) ++a; const FFMono m = ff_dec_tri(r - ff_tet(a)); return FFMono{a, m.a, m.b}; }
+__host__ __device__ constexpr FFMono ff_dec2(int r, int z1) { if (r < z1) return FFMono{r, 0, 0}; const FFMono m = ff_dec_tri(r - z1); return FFMono{m.a + 1, m.b + 1, 0}; }
+__host__ __device__ constexpr int ff_row2(int a, int b, int z1) { return b == 0 ? a : z1 + ff_tri(a - 1) + (b - 1); }
 __host__ __device__ constexpr int ff_design(int z1) { return z1 == 0 ? 0 : z1 + 1; }      // column of x = (1, k, z) that holds z1's entry
 
 template <int Q> struct FFC {
     static constexpr int Z1 = Q + 1, PC = Q + 2, NH = PC * (PC + 1) / 2;
     static constexpr int N2 = ff_tri(Z1), N3 = ff_tet(Z1);
-    static constexpr int T2 = (N2 + 31) / 32, T3 = (N3 + 31) / 32, NTA = T2 + T3, NACC = 2 * T2 + T3;
+    static constexpr int T2 = (N2 + 31) / 32, T3 = (N3 + 31) / 32, NTA = T2 + T3, NACC = 2 * T2 + T3 + 1, AWK = 2 * T2 + T3;   // (AWK: the k-row of I)
+    static_assert(Z1 <= 32, "the k-row of I lives in tile 0 of the degree-2 table");
     static constexpr int RS = (Q + 3 + 1) & ~1;           // doubles per sample record: z_s[Q], s = 1 - 2 y, live (1 / 0), w0 (the null model's weight), padding to 16 bytes
 };
 extern "C" int shk_firth_fast_supported(int Q) { return Q >= 1 && Q <= 10; }
+extern "C" int shk_firth_fast_row2(int Q, int a, int b) { return ff_row2(a, b, Q + 1); }
 extern "C" int shk_firth_fast_tiles(int Q, int *t2, int *t3, int *rs)
 {
     const int z1 = Q + 1, n2 = ff_tri(z1), n3 = ff_tet(z1);
@@ -98,7 +104,7 @@ template <int Q, int R>
 __device__ __forceinline__ void ff_row2k(float tv, const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC])
 {
     if constexpr (R < FFC<Q>::N2) {
-        constexpr FFMono m = ff_dec2(R);
+        constexpr FFMono m = ff_dec2(R, FFC<Q>::Z1);
         ff_contrib<FFC<Q>::PC, 1, ff_design(m.a), ff_design(m.b)>((double)tv, V, g);
         if constexpr (m.b == 0) ff_contrib<FFC<Q>::PC, 1, 1, ff_design(m.a)>((double)tv, V, g);
         if constexpr (m.a == 0 && m.b == 0) ff_contrib<FFC<Q>::PC, 1, 1, 1>((double)tv, V, g);
@@ -109,7 +115,7 @@ template <int Q, int R>
 __device__ __forceinline__ void ff_row2i(float tv, const double *__restrict__ inull, double (&I)[FFC<Q>::NH], double &rho)
 {
     if constexpr (R < FFC<Q>::N2) {
-        constexpr FFMono m = ff_dec2(R);
+        constexpr FFMono m = ff_dec2(R, FFC<Q>::Z1);
         const double v0 = inull[R];
         I[sidx(ff_design(m.a), ff_design(m.b))] = v0 + (double)tv;
         if constexpr (m.a == m.b) rho = fmax(rho, fabs((double)tv) / v0);       // how far the weights are from the null model's, on the diagonal
@@ -186,6 +192,27 @@ __device__ __forceinline__ void ff_all2i(const ff_v16f (&acc)[FFC<Q>::NACC], int
     (one(std::integral_constant<int, Ts>{}), ...);
 }
 
+// e^-x for x >= 0 to 1e-11 relative (degree 9; the fixed point needs eta -> mu to ~1e-9, the one-pass F sums 5000 log(1 + t): 2e-8): as exp_neg
+// (glm_device.h) with four terms less
+__device__ __forceinline__ double ff_exp_neg(double x)
+{
+    const double u = -fmin(x, 800.0);
+    const double kf = rint(u * 1.4426950408889634074);
+    double r = fma(kf, -6.93147180369123816490e-01, u);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    double p = 2.7557319223985893e-06;                       // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);                   // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
 __device__ __forceinline__ double ff_xor32(double x) { return __shfl_xor(x, 32); }
 
 // One pass at `cand` for the slots of fast_list: F (one-pass), I, U*, the next candidate; routing as described in the header.
@@ -199,7 +226,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
                   int *__restrict__ exact_list, int *__restrict__ exact_count, int64_t V, double *__restrict__ out, uint32_t *__restrict__ flags)
 {
     typedef FFC<Q> C;
-    constexpr int PC = C::PC, NH = C::NH, Z1 = C::Z1, RS = C::RS, T2 = C::T2, T3 = C::T3, NTA = C::NTA, NACC = C::NACC;
+    constexpr int PC = C::PC, NH = C::NH, RS = C::RS, T2 = C::T2, T3 = C::T3, NTA = C::NTA, NACC = C::NACC;
     const int cnt = *fast_count;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
@@ -235,11 +262,9 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    double nU[PC], Ik[Z1];                                 // -score = sum (mu - y) x;  k-row of I: sum w k z1
+    double nU[PC], Ik0 = 0.0;                              // -score = sum (mu - y) x;  I11 = sum w k
 #pragma unroll
     for (int a = 0; a < PC; ++a) nU[a] = 0.0;
-#pragma unroll
-    for (int a = 0; a < Z1; ++a) Ik[a] = 0.0;
     double apos = 0.0, prod = 1.0;
     int pexp = 0;
     // The run's tables reach the block through LDS: per 16-sample group the NTA x 2 fragment blocks of the monomial table (1 KB each: one
@@ -267,12 +292,12 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
                          : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
         }
     };
-    uint32_t Bw[2][4], Bc[2][4], Bk[2][4];                                  // this group's B operands: [hi, lo][4 x half2]
-    uint32_t Pw[2][4], Pc[2][4], Pk[2][4];                                  // the previous group's: its MFMAs are issued among this group's samples
+    uint32_t Bw[2][4], Bc[2][4], Bk[2][4], Bx[2][4];                        // this group's B operands (w - w0, c, c k, (w - w0) k): [hi, lo][4 x half2]
+    uint32_t Pw[2][4], Pc[2][4], Pk[2][4], Px[2][4];                        // the previous group's: its MFMAs are issued among this group's samples
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { Pw[q2][e] = 0u; Pc[q2][e] = 0u; Pk[q2][e] = 0u; }
+        for (int e = 0; e < 4; ++e) { Pw[q2][e] = 0u; Pc[q2][e] = 0u; Pk[q2][e] = 0u; Px[q2][e] = 0u; }
 
     // the MFMAs of tile `ta` of the A table (ta < T2: degree 2, against w and c k; else degree 3, against c) for the operands in P*
     auto tile_mfma = [&](int ta, const ff_v4u &ah, const ff_v4u &al) {
@@ -285,17 +310,17 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, a, 0, 0, 0);
         };
         if (FF_ABL & 1) { acc[ta < T2 ? ta : T2 + (ta - T2)][0] += __builtin_bit_cast(float, ah[0] ^ al[1]); return; }
-        if (ta < T2) { three(acc[ta], Pw); three(acc[T2 + T3 + ta], Pk); }
+        if (ta < T2) { three(acc[ta], Pw); three(acc[T2 + T3 + ta], Pk); if (ta == 0) three(acc[C::AWK], Px); }
         else three(acc[T2 + (ta - T2)], Pc);
     };
     // one sample: returns the scaled weights (w, c, c k) as floats
-    auto sample = [&](const double (&rc)[RS], uint32_t bit, float &wf, float &cf, float &kf) {
+    auto sample = [&](const double (&rc)[RS], uint32_t bit, float &wf, float &cf, float &kf, float &xf) {
         const double xd = (double)bit;
         double eta = fma(bs[1], xd, bs[0]);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(bs[2 + j], rc[j], eta);
         const double lv = rc[Q + 1];
-        const double t = exp_neg(fabs(eta)) * lv, u = 1.0 + t;
+        const double t = ff_exp_neg(fabs(eta)) * lv, u = 1.0 + t;
         double inv = __builtin_amdgcn_rcp(u);
         inv = fma(fma(-u, inv, 1.0), inv, inv);
         inv = fma(fma(-u, inv, 1.0), inv, inv);
@@ -306,12 +331,13 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         const double r = fma(0.5, rc[Q], hm) * lv;                              // mu - y = (mu - 1/2) + s / 2
         const double wx = wgt * xd;
         nU[0] += r; nU[1] = fma(xd, r, nU[1]);
-        Ik[0] += wx;
+        Ik0 += wx;                                                              // I11 = sum w k: the reference's bse^2, kept exact
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { nU[2 + j] = fma(rc[j], r, nU[2 + j]); Ik[1 + j] = fma(wx, rc[j], Ik[1 + j]); }
+        for (int j = 0; j < Q; ++j) nU[2 + j] = fma(rc[j], r, nU[2 + j]);
         wf = (float)((wgt - rc[Q + 2]) * FF_SCALE);                             // w - w0: I = I(null model) + sum (w - w0) m2, the sum an order of magnitude smaller than I
         cf = (float)(-(wgt * hm) * FF_SCALE);                                   // c = w (1/2 - mu)
         kf = bit ? cf : 0.0f;
+        xf = bit ? wf : 0.0f;
     };
     auto stash = [&](uint32_t (&B)[2][4], int e, float a, float b) {
         const ff_v2h hh = __builtin_convertvector(ff_v2f{a, b}, ff_v2h);
@@ -376,30 +402,28 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             ff_v4u ah[PER], al[PER];
-            float w0, c0, k0, w1, c1, k1;
+            float w0, c0, k0, x0, w1, c1, k1, x1;
             fetch_rec(buf, 2 * pp + 1, rb);
             slot_load(buf, pp, ah, al);
             __builtin_amdgcn_sched_barrier(0);
-            if (FF_ABL & 4) { w0 = (float)ra[0]; c0 = (float)ra[1]; k0 = (float)ra[2]; nU[pp] += ra[3]; }
-            else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0, k0);
+            if (FF_ABL & 4) { w0 = (float)ra[0]; c0 = (float)ra[1]; k0 = (float)ra[2]; x0 = k0; nU[pp] += ra[3]; }
+            else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0, k0, x0);
             // (the fences order instructions with side effects; plain arithmetic is placed wherever its operands allow.  Empty volatile asms that
             // "define" the even sample's results pin its arithmetic in front of the next fence, i.e. UNDER the LDS reads issued above)
-            asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(apos), "+v"(prod));
+            asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(apos), "+v"(prod), "+v"(Ik0));
 #pragma unroll
             for (int a = 0; a < PC; ++a) asm volatile("" : "+v"(nU[a]));
-#pragma unroll
-            for (int a = 0; a < Z1; ++a) asm volatile("" : "+v"(Ik[a]));
             __builtin_amdgcn_sched_barrier(0);
             if (pp < 3) fetch_rec(buf, 2 * pp + 2, ra); else fetch_rec(bufn, 0, ra);
             __builtin_amdgcn_sched_barrier(0);
-            if (FF_ABL & 4) { w1 = (float)rb[0]; c1 = (float)rb[1]; k1 = (float)rb[2]; nU[pp] += rb[3]; }
-            else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1, k1);
-            stash(Bw, pp, w0, w1); stash(Bc, pp, c0, c1); stash(Bk, pp, k0, k1);
+            if (FF_ABL & 4) { w1 = (float)rb[0]; c1 = (float)rb[1]; k1 = (float)rb[2]; x1 = k1; nU[pp] += rb[3]; }
+            else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1, k1, x1);
+            stash(Bw, pp, w0, w1); stash(Bc, pp, c0, c1); stash(Bk, pp, k0, k1); stash(Bx, pp, x0, x1);
             slot_mfma(pp, ah, al);
 #if FF_SCHED
             // one MFMA, then a run of vector instructions, and so on through the odd sample
 #pragma unroll
-            for (int k2 = 0; k2 < 12; ++k2) {
+            for (int k2 = 0; k2 < 15; ++k2) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, FF_SCHED, 0);
             }
@@ -409,7 +433,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { Pw[q2][e] = Bw[q2][e]; Pc[q2][e] = Bc[q2][e]; Pk[q2][e] = Bk[q2][e]; }
+            for (int e = 0; e < 4; ++e) { Pw[q2][e] = Bw[q2][e]; Pc[q2][e] = Bc[q2][e]; Pk[q2][e] = Bk[q2][e]; Px[q2][e] = Bx[q2][e]; }
         if ((g & 3) == 3) { int e2; prod = frexp(prod, &e2); pexp += e2; }
         if (!(FF_ABL & 2)) {
             // this wavefront's share of the NEXT iteration's tables has landed (the one after it may still be in flight), then the bare barrier:
@@ -431,8 +455,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     // ---- the two halves' partial sums ----------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int a = 0; a < PC; ++a) nU[a] += ff_xor32(nU[a]);
-#pragma unroll
-    for (int a = 0; a < Z1; ++a) Ik[a] += ff_xor32(Ik[a]);
+    Ik0 += ff_xor32(Ik0);
     { int e2; prod = frexp(prod, &e2); pexp += e2; }
     double lp = fma((double)pexp, 0.6931471805599453, log(prod));
     lp += ff_xor32(lp); apos += ff_xor32(apos);
@@ -444,9 +467,17 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     for (int a = 0; a < NH; ++a) I[a] = 0.0;
     double rho = 0.0;
     ff_all2i<Q>(acc, h, unscale, P.ff_inull, I, rho, std::make_integer_sequence<int, T2>{});
-    I[sidx(1, 0)] = Ik[0]; I[sidx(1, 1)] = Ik[0];
+    I[sidx(1, 0)] = Ik0; I[sidx(1, 1)] = Ik0;
+    {   // the k-row: sum w k z_j = (the null model's part: the carrier sums of w0 z_j, k_glm_bitdot; of the complement: the totals minus them)
+        // + the matrix-core sum of (w - w0) k z_j = rows 1..Q of the degree-2 table's tile 0
+        float row[32];
+        ff_rows(acc[C::AWK], h, row);
 #pragma unroll
-    for (int j = 0; j < Q; ++j) I[sidx(2 + j, 1)] = Ik[1 + j];
+        for (int j = 0; j < Q; ++j) {
+            const double cs = P.ch_bd[(int64_t)(1 + j) * Vpad + v];
+            I[sidx(2 + j, 1)] = (flip ? P.null_h[1 + j] - cs : cs) + (double)(row[1 + j] * unscale);
+        }
+    }
     double A[NH], det;
 #pragma unroll
     for (int a = 0; a < NH; ++a) A[a] = I[a];
@@ -532,7 +563,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
         for (int j = 0; j < Q; ++j) lsd += log(P.wstd[Q + j]);
         const double fitll = -(F - 0.5 * ud) + lsd;
-        const double i11 = flip ? i00 - Ik[0] : Ik[0];
+        const double i11 = flip ? i00 - Ik0 : Ik0;
         const double lrstat = -2.0 * (P.null_firth - fitll);
         double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
         const double b1 = cand[1] + d[1];
