@@ -359,21 +359,22 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     constexpr int PER = (NTA + 3) / 4;
     double ra[RS], rb[RS];
     uint64_t w64 = 0, wnext = T[v];
-    auto slot_load = [&](const char *buf, int pp, ff_v4u (&ah)[PER], ff_v4u (&al)[PER]) {
+    // fragments of the slot's tiles q2 = lo..hi-1 (tile q2 * 4 + pp)
+    auto slot_load = [&](const char *buf, int pp, int lo, int hi, ff_v4u (&ah)[PER], ff_v4u (&al)[PER]) {
 #pragma unroll
         for (int q2 = 0; q2 < PER; ++q2) {
             const int ta = q2 * 4 + pp;
-            if (ta < NTA) {
+            if (q2 >= lo && q2 < hi && ta < NTA) {
                 ah[q2] = *(const ff_v4u *)(buf + (ta * 2 + 0) * 1024 + lane * 16);
                 al[q2] = *(const ff_v4u *)(buf + (ta * 2 + 1) * 1024 + lane * 16);
             }
         }
     };
-    auto slot_mfma = [&](int pp, const ff_v4u (&ah)[PER], const ff_v4u (&al)[PER]) {
+    auto slot_mfma = [&](int pp, int lo, int hi, const ff_v4u (&ah)[PER], const ff_v4u (&al)[PER]) {
 #pragma unroll
         for (int q2 = 0; q2 < PER; ++q2) {
             const int ta = q2 * 4 + pp;
-            if (ta < NTA) tile_mfma(ta, ah[q2], al[q2]);
+            if (q2 >= lo && q2 < hi && ta < NTA) tile_mfma(ta, ah[q2], al[q2]);
         }
     };
     dma(0);
@@ -381,6 +382,8 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
     __syncthreads();
     fetch_rec(lds, 0, ra);
+    ff_v4u ah[PER], al[PER];                                                    // the slot's A fragments: [0] read a sample ahead of the rest
+    slot_load(lds, 0, 0, 1, ah, al);
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         if ((g & 3) == 0) {                                                     // the variant's next 64 presence bits, fetched four groups ahead
@@ -398,32 +401,43 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         const char *const bufn = lds + ((g + 1) % NRING) * STAGE;               // (landed: the end of the previous iteration waited for it)
         // A pair of samples = one slot.  LDS reads are issued a whole sample ahead of their use and the fences keep them there (left alone the
         // compiler clusters them in front of their first use: 22 exposed LDS latencies per group, a third of the kernel's time):
-        //   [record of the odd sample, the slot's A fragments]  |  even sample  |  [record of the next even sample]  |  odd sample + the slot's MFMAs
+        //   [record of the odd sample, fragments 1..]  |  even sample + the MFMAs of fragment 0  |  [record of the next even sample, the next
+        //   slot's fragment 0]  |  odd sample + the MFMAs of fragments 1..
+        // so that the slot's MFMAs are spread over both samples (the matrix core is busy 32 cycles per MFMA: all fifteen among one sample's
+        // hundred vector instructions and the MFMA issue waits for the pipe)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            ff_v4u ah[PER], al[PER];
             float w0, c0, k0, x0, w1, c1, k1, x1;
             fetch_rec(buf, 2 * pp + 1, rb);
-            slot_load(buf, pp, ah, al);
+            slot_load(buf, pp, 1, PER, ah, al);
             __builtin_amdgcn_sched_barrier(0);
             if (FF_ABL & 4) { w0 = (float)ra[0]; c0 = (float)ra[1]; k0 = (float)ra[2]; x0 = k0; nU[pp] += ra[3]; }
             else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0, k0, x0);
+            slot_mfma(pp, 0, 1, ah, al);
+#if FF_SCHED
+#pragma unroll
+            for (int k2 = 0; k2 < 9; ++k2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, FF_SCHED, 0);
+            }
+#endif
             // (the fences order instructions with side effects; plain arithmetic is placed wherever its operands allow.  Empty volatile asms that
             // "define" the even sample's results pin its arithmetic in front of the next fence, i.e. UNDER the LDS reads issued above)
             asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(apos), "+v"(prod), "+v"(Ik0));
 #pragma unroll
             for (int a = 0; a < PC; ++a) asm volatile("" : "+v"(nU[a]));
             __builtin_amdgcn_sched_barrier(0);
-            if (pp < 3) fetch_rec(buf, 2 * pp + 2, ra); else fetch_rec(bufn, 0, ra);
+            if (pp < 3) { fetch_rec(buf, 2 * pp + 2, ra); slot_load(buf, pp + 1, 0, 1, ah, al); }
+            else { fetch_rec(bufn, 0, ra); slot_load(bufn, 0, 0, 1, ah, al); }
             __builtin_amdgcn_sched_barrier(0);
             if (FF_ABL & 4) { w1 = (float)rb[0]; c1 = (float)rb[1]; k1 = (float)rb[2]; x1 = k1; nU[pp] += rb[3]; }
             else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1, k1, x1);
             stash(Bw, pp, w0, w1); stash(Bc, pp, c0, c1); stash(Bk, pp, k0, k1); stash(Bx, pp, x0, x1);
-            slot_mfma(pp, ah, al);
+            slot_mfma(pp, 1, PER, ah, al);
 #if FF_SCHED
-            // one MFMA, then a run of vector instructions, and so on through the odd sample
+            // one MFMA, then a run of vector instructions, and so on through the sample
 #pragma unroll
-            for (int k2 = 0; k2 < 15; ++k2) {
+            for (int k2 = 0; k2 < 9; ++k2) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, FF_SCHED, 0);
             }
@@ -435,21 +449,18 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Pw[q2][e] = Bw[q2][e]; Pc[q2][e] = Bc[q2][e]; Pk[q2][e] = Bk[q2][e]; Px[q2][e] = Bx[q2][e]; }
         if ((g & 3) == 3) { int e2; prod = frexp(prod, &e2); pexp += e2; }
-        if (!(FF_ABL & 2)) {
-            // this wavefront's share of the NEXT iteration's tables has landed (the one after it may still be in flight), then the bare barrier:
-            // everyone's has, and everyone is done reading this iteration's buffer.  (__syncthreads() would add a vmcnt(0) and wait for both)
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
-        }
+        // this wavefront's share of the NEXT iteration's tables has landed (the one after it may still be in flight), then the bare barrier:
+        // everyone's has, and everyone is done reading this iteration's buffer.  (__syncthreads() would add a vmcnt(0) and wait for both)
+        if (!(FF_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
     }
-    {                                                                           // the MFMAs of the last group
+    {                                                                           // the MFMAs of the last group (slot 0's first fragment is in hand)
         const char *const buf = lds + (NG % NRING) * STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            ff_v4u ah[PER], al[PER];
-            slot_load(buf, pp, ah, al);
-            slot_mfma(pp, ah, al);
+            slot_load(buf, pp, 0, PER, ah, al);
+            slot_mfma(pp, 0, PER, ah, al);
         }
     }
     // ---- the two halves' partial sums ----------------------------------------------------------------------------------------------------
