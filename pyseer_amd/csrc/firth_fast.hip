@@ -70,6 +70,7 @@ template <int Q> struct FFC {
     static_assert(Z1 <= 32, "the k-row of I lives in tile 0 of the degree-2 table");
     static constexpr int RS = (Q + 3 + 1) & ~1;           // doubles per sample record: z_s[Q], s = 1 - 2 y, live (1 / 0), w0 (the null model's weight), padding to 16 bytes
 };
+#ifndef FF_F32_TU
 extern "C" int shk_firth_fast_supported(int Q) { return Q >= 1 && Q <= 10; }
 extern "C" int shk_firth_fast_row2(int Q, int a, int b) { return ff_row2(a, b, Q + 1); }
 extern "C" int shk_firth_fast_tiles(int Q, int *t2, int *t3, int *rs)
@@ -78,6 +79,7 @@ extern "C" int shk_firth_fast_tiles(int Q, int *t2, int *t3, int *rs)
     *t2 = (n2 + 31) / 32; *t3 = (n3 + 31) / 32; *rs = (Q + 3 + 1) & ~1;
     return 0;
 }
+#endif
 
 // g_x += sum over the distinct arrangements of the multiset {A, B, C} of t V_yz: for every distinct element x, the other two (y, z) give
 // 2 t V_yz if y != z, t V_yy otherwise
@@ -219,7 +221,7 @@ __device__ __forceinline__ double ff_xor32(double x) { return __shfl_xor(x, 32);
 //   fw state on entry (as k_firth_eval2): beta = last accepted point, cand = the point to evaluate, fcur = one-pass F at beta, snp = norm of the
 //   step that led to beta, iter = accepted steps so far (-1: cand is the start vector, nothing to compare with).
 //   exact_list: slots for k_firth_eval2 (the finishing evaluation, or a fit that leaves the fast passes)
-template <int Q>
+template <int Q, bool F32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, FirthWork fw, const int *__restrict__ fast_list,
                   const int *__restrict__ fast_count, int *__restrict__ next_fast, int *__restrict__ next_fast_count,
@@ -242,6 +244,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     const int N = P.N;
     const int NG = (N + 15) >> 4;
     // beta (columns as given) -> the standardised basis x_s = (1, k, (z - m) / s):  b_s0 = b0 + sum m_j b_j,  b_s(2+j) = s_j b_(2+j)
+    typedef std::conditional_t<F32, float, double> RT;     // the arithmetic type of the sample loop
     double cand[PC], bs[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) cand[a] = fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s];
@@ -262,25 +265,29 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    double nU[PC], Ik0 = 0.0;                              // -score = sum (mu - y) x;  I11 = sum w k
+    RT nU[PC], Ik0 = 0;                                    // -score = sum (mu - y) x;  I11 = sum w k
+    RT bsr[PC];
 #pragma unroll
-    for (int a = 0; a < PC; ++a) nU[a] = 0.0;
+    for (int a = 0; a < PC; ++a) { nU[a] = 0; bsr[a] = (RT)bs[a]; }
     double apos = 0.0, prod = 1.0;
     int pexp = 0;
     // The run's tables reach the block through LDS: per 16-sample group the NTA x 2 fragment blocks of the monomial table (1 KB each: one
     // wave-wide LDS-DMA) and the group's 16 sample records (2 KB slot), double buffered; iteration g of the loop below reads records g and
     // the fragments of group g - 1 (the MFMAs trail the samples by one group).
-    constexpr int NPIECE = (NTA * 2 + 2 + 3) & ~3, NPW = NPIECE / 4, STAGE = NPIECE * 1024;     // 1 KB pieces, NPW per wavefront (the last ones padding)
+    constexpr int NPIECE = (NTA * 2 + 2 + 3) & ~3, STAGE = NPIECE * 1024;
+    // (the single-precision pass takes the tables' hi halves only: one product per tile, 2^-11 on sums that need 1e-5)
+    constexpr int NFETCH = F32 ? NTA + 2 : NTA * 2 + 2, NPW = (NFETCH + 3) / 4;     // 1 KB pieces, NPW per wavefront (the last ones padding)
     constexpr int NRING = 3;
     char *const lds = (char *)xw_lds;
     const char *const tab_g = (const char *)P.ff_tab;
-    const char *const rec_g = (const char *)P.ff_rec;
+    const char *const rec_g = F32 ? (const char *)P.ff_rec32 : (const char *)P.ff_rec;
     auto dma = [&](int gi) {                                                    // everything iteration gi reads, into buffer gi % NRING
         char *const buf = lds + (gi % NRING) * STAGE;
         const int gt = max(gi - 1, 0), gr = min(gi, NG - 1);
 #pragma unroll
         for (int q2 = 0; q2 < NPW; ++q2) {
-            const int pc = q2 * 4 + wave;
+            const int pf = q2 * 4 + wave;                                       // the pf-th piece fetched = piece pc of the stage
+            const int pc = !F32 ? pf : pf < NTA ? 2 * pf : NTA + pf;
             const char *src = pc < NTA * 2 ? tab_g + ((int64_t)gt * NTA * 2 + pc) * 1024 : rec_g + (int64_t)gr * (16 * RS * 8) + (pc - NTA * 2) * 1024;
             // (inline assembly, not __builtin_amdgcn_global_load_lds: the compiler cannot tell which LDS bytes a DMA in flight will write, so with
             // the builtin it puts s_waitcnt vmcnt(0) in front of the next LDS read -- the whole latency of the copy just issued, every
@@ -306,15 +313,40 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             const ff_v4u bh = {B[0][0], B[0][1], B[0][2], B[0][3]}, bl = {B[1][0], B[1][1], B[1][2], B[1][3]};
             const ff_v8h Bh = __builtin_bit_cast(ff_v8h, bh), Bl = __builtin_bit_cast(ff_v8h, bl);
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, a, 0, 0, 0);
+            if constexpr (!F32) {
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, a, 0, 0, 0);
+            }
         };
         if (FF_ABL & 1) { acc[ta < T2 ? ta : T2 + (ta - T2)][0] += __builtin_bit_cast(float, ah[0] ^ al[1]); return; }
         if (ta < T2) { three(acc[ta], Pw); three(acc[T2 + T3 + ta], Pk); if (ta == 0) three(acc[C::AWK], Px); }
         else three(acc[T2 + (ta - T2)], Pc);
     };
     // one sample: returns the scaled weights (w, c, c k) as floats
-    auto sample = [&](const double (&rc)[RS], uint32_t bit, float &wf, float &cf, float &kf, float &xf) {
+    auto sample = [&](const RT (&rc)[RS], uint32_t bit, float &wf, float &cf, float &kf, float &xf) {
+        if constexpr (F32) {
+            // the FIRST pass (at the start vector, some 1e-2 from the fit) in single precision: its step need not be better than the 1e-5 the
+            // next point is from the fit anyway; no log-likelihood (nothing to compare F with yet)
+            const float xd = (float)bit;
+            float eta = fmaf(bsr[1], xd, bsr[0]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) eta = fmaf(bsr[2 + j], rc[j], eta);
+            const float lv = rc[Q + 1];
+            const float t = __builtin_amdgcn_exp2f(fabsf(eta) * -1.4426950408889634f) * lv, u = 1.0f + t;
+            float inv = __builtin_amdgcn_rcpf(u);
+            inv = fmaf(fmaf(-u, inv, 1.0f), inv, inv);
+            const float wgt = (t * inv) * inv;
+            const float hm = copysignf(fmaf(-0.5f, t, 0.5f) * inv, eta);
+            const float r = fmaf(0.5f, rc[Q], hm) * lv;
+            nU[0] += r; nU[1] = fmaf(xd, r, nU[1]);
+            Ik0 = fmaf(wgt, xd, Ik0);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) nU[2 + j] = fmaf(rc[j], r, nU[2 + j]);
+            wf = (wgt - rc[Q + 2]) * (float)FF_SCALE;
+            cf = -(wgt * hm) * (float)FF_SCALE;
+            kf = bit ? cf : 0.0f;
+            xf = bit ? wf : 0.0f;
+        } else {
         const double xd = (double)bit;
         double eta = fma(bs[1], xd, bs[0]);
 #pragma unroll
@@ -338,18 +370,26 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         cf = (float)(-(wgt * hm) * FF_SCALE);                                   // c = w (1/2 - mu)
         kf = bit ? cf : 0.0f;
         xf = bit ? wf : 0.0f;
+        }
     };
     auto stash = [&](uint32_t (&B)[2][4], int e, float a, float b) {
         const ff_v2h hh = __builtin_convertvector(ff_v2f{a, b}, ff_v2h);
+        if constexpr (F32) { B[0][e] = __builtin_bit_cast(uint32_t, hh); B[1][e] = 0u; return; }
         const ff_v2f back = __builtin_convertvector(hh, ff_v2f);
         const ff_v2h ll = __builtin_convertvector(ff_v2f{a - back.x, b - back.y}, ff_v2h);
         B[0][e] = __builtin_bit_cast(uint32_t, hh); B[1][e] = __builtin_bit_cast(uint32_t, ll);
     };
     // sample j (0..7) of this lane's half of the group in buffer `buf`
-    auto fetch_rec = [&](const char *buf, int j, double (&rc)[RS]) {
-        const ff_v2d *r = (const ff_v2d *)(buf + NTA * 2048 + (8 * h + j) * (RS * 8));
+    auto fetch_rec = [&](const char *buf, int j, RT (&rc)[RS]) {
+        if constexpr (F32) {                                                    // (single-precision records: the same slots, half filled)
+            const ff_v2f *r = (const ff_v2f *)(buf + NTA * 2048 + (8 * h + j) * (RS * 8));
 #pragma unroll
-        for (int k2 = 0; k2 < RS / 2; ++k2) { const ff_v2d x = r[k2]; rc[2 * k2] = x.x; rc[2 * k2 + 1] = x.y; }
+            for (int k2 = 0; k2 < RS / 2; ++k2) { const ff_v2f x = r[k2]; rc[2 * k2] = x.x; rc[2 * k2 + 1] = x.y; }
+        } else {
+            const ff_v2d *r = (const ff_v2d *)(buf + NTA * 2048 + (8 * h + j) * (RS * 8));
+#pragma unroll
+            for (int k2 = 0; k2 < RS / 2; ++k2) { const ff_v2d x = r[k2]; rc[2 * k2] = x.x; rc[2 * k2 + 1] = x.y; }
+        }
     };
     // A group = 8 samples per lane = four pairs; the MFMAs of the PREVIOUS group's operands are issued AMONG the pairs' arithmetic (the matrix
     // core works beside the vector ALU only if the instruction stream alternates: sched_group_barrier), table tiles pp, pp + 4, pp + 8 ...
@@ -357,7 +397,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     // the pair.  The tables of iteration g + 2 are in flight while g computes (ring of NRING buffers): the end of an iteration waits for its
     // wavefront's share of g + 1 only.
     constexpr int PER = (NTA + 3) / 4;
-    double ra[RS], rb[RS];
+    RT ra[RS], rb[RS];
     uint64_t w64 = 0, wnext = T[v];
     // fragments of the slot's tiles q2 = lo..hi-1 (tile q2 * 4 + pp)
     auto slot_load = [&](const char *buf, int pp, int lo, int hi, ff_v4u (&ah)[PER], ff_v4u (&al)[PER]) {
@@ -366,7 +406,8 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             const int ta = q2 * 4 + pp;
             if (q2 >= lo && q2 < hi && ta < NTA) {
                 ah[q2] = *(const ff_v4u *)(buf + (ta * 2 + 0) * 1024 + lane * 16);
-                al[q2] = *(const ff_v4u *)(buf + (ta * 2 + 1) * 1024 + lane * 16);
+                if constexpr (!F32) al[q2] = *(const ff_v4u *)(buf + (ta * 2 + 1) * 1024 + lane * 16);
+                else al[q2] = ah[q2];
             }
         }
     };
@@ -423,7 +464,8 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #endif
             // (the fences order instructions with side effects; plain arithmetic is placed wherever its operands allow.  Empty volatile asms that
             // "define" the even sample's results pin its arithmetic in front of the next fence, i.e. UNDER the LDS reads issued above)
-            asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(apos), "+v"(prod), "+v"(Ik0));
+            if constexpr (F32) asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(Ik0));
+            else asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(apos), "+v"(prod), "+v"(Ik0));
 #pragma unroll
             for (int a = 0; a < PC; ++a) asm volatile("" : "+v"(nU[a]));
             __builtin_amdgcn_sched_barrier(0);
@@ -448,7 +490,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Pw[q2][e] = Bw[q2][e]; Pc[q2][e] = Bc[q2][e]; Pk[q2][e] = Bk[q2][e]; Px[q2][e] = Bx[q2][e]; }
-        if ((g & 3) == 3) { int e2; prod = frexp(prod, &e2); pexp += e2; }
+        if (!F32 && (g & 3) == 3) { int e2; prod = frexp(prod, &e2); pexp += e2; }
         // this wavefront's share of the NEXT iteration's tables has landed (the one after it may still be in flight), then the bare barrier:
         // everyone's has, and everyone is done reading this iteration's buffer.  (__syncthreads() would add a vmcnt(0) and wait for both)
         if (!(FF_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
@@ -464,13 +506,17 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         }
     }
     // ---- the two halves' partial sums ----------------------------------------------------------------------------------------------------
+    double nUd[PC], Ik0d;
 #pragma unroll
-    for (int a = 0; a < PC; ++a) nU[a] += ff_xor32(nU[a]);
-    Ik0 += ff_xor32(Ik0);
-    { int e2; prod = frexp(prod, &e2); pexp += e2; }
-    double lp = fma((double)pexp, 0.6931471805599453, log(prod));
-    lp += ff_xor32(lp); apos += ff_xor32(apos);
-    const double ll = -(apos + lp);
+    for (int a = 0; a < PC; ++a) { const double x = (double)nU[a]; nUd[a] = x + ff_xor32(x); }
+    { const double x = (double)Ik0; Ik0d = x + ff_xor32(x); }
+    double ll = 0.0;                                                        // (the single-precision pass has no likelihood: nothing to compare it with)
+    if constexpr (!F32) {
+        int e2; prod = frexp(prod, &e2); pexp += e2;
+        double lp = fma((double)pexp, 0.6931471805599453, log(prod));
+        lp += ff_xor32(lp); apos += ff_xor32(apos);
+        ll = -(apos + lp);
+    }
     // ---- I in the standardised basis (design order 0 = 1, 1 = k, 2.. = z), its factor, V ----------------------------------------------------
     const float unscale = (float)(1.0 / FF_SCALE);
     double I[NH];
@@ -478,7 +524,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     for (int a = 0; a < NH; ++a) I[a] = 0.0;
     double rho = 0.0;
     ff_all2i<Q>(acc, h, unscale, P.ff_inull, I, rho, std::make_integer_sequence<int, T2>{});
-    I[sidx(1, 0)] = Ik0; I[sidx(1, 1)] = Ik0;
+    I[sidx(1, 0)] = Ik0d; I[sidx(1, 1)] = Ik0d;
     {   // the k-row: sum w k z_j = (the null model's part: the carrier sums of w0 z_j, k_glm_bitdot; of the complement: the totals minus them)
         // + the matrix-core sum of (w - w0) k z_j = rows 1..Q of the degree-2 table's tile 0
         float row[32];
@@ -528,7 +574,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     ff_all2k<Q>(acc, h, unscale, Vm, gp, std::make_integer_sequence<int, T2>{});
     double U[PC], d[PC];
 #pragma unroll
-    for (int a = 0; a < PC; ++a) U[a] = gp[a] - nU[a];
+    for (int a = 0; a < PC; ++a) U[a] = gp[a] - nUd[a];
 #pragma unroll
     for (int a = 0; a < PC; ++a) {
         double acc2 = 0.0;
@@ -574,7 +620,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
         for (int j = 0; j < Q; ++j) lsd += log(P.wstd[Q + j]);
         const double fitll = -(F - 0.5 * ud) + lsd;
-        const double i11 = flip ? i00 - Ik0 : Ik0;
+        const double i11 = flip ? i00 - Ik0d : Ik0d;
         const double lrstat = -2.0 * (P.null_firth - fitll);
         double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
         const double b1 = cand[1] + d[1];
@@ -594,37 +640,57 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         if (!last) { fw.iter[s] = -1; }
         exact_list[atomicAdd(exact_count, 1)] = s;
     } else {
-        fw.st[(int64_t)fw_fcur<PC>() * cap + s] = F;
+        fw.st[(int64_t)fw_fcur<PC>() * cap + s] = F32 ? (double)INFINITY : F;
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = sn;
         next_fast[atomicAdd(next_fast_count, 1)] = s;
     }
 }
 
-template <int Q>
+template <int Q, bool F32>
 static hipError_t launch_firth_fast(hipStream_t st, int64_t n, const uint64_t *T, int64_t Vpad, GlmParams P, FirthWork fw, const int *in_list,
                                     const int *in_count, int *next_fast, int *next_fast_count, int *exact_list, int *exact_count, int64_t V, double *out,
                                     uint32_t *flags)
 {
     if (n <= 0) return hipSuccess;
     constexpr size_t lds = 3 * (size_t)((FFC<Q>::NTA * 2 + 2 + 3) & ~3) * 1024;
-    hipLaunchKernelGGL(k_firth_fast<Q>, dim3((unsigned)((n + 127) / 128)), dim3(256), lds, st, T, Vpad, P, fw, in_list, in_count, next_fast, next_fast_count,
+    hipLaunchKernelGGL((k_firth_fast<Q, F32>), dim3((unsigned)((n + 127) / 128)), dim3(256), lds, st, T, Vpad, P, fw, in_list, in_count, next_fast, next_fast_count,
                        exact_list, exact_count, V, out, flags);
     return hipGetLastError();
 }
 
-extern "C" hipError_t shk_firth_fast_launch(hipStream_t st, int Q, int64_t n, const uint64_t *T, int64_t Vpad, GlmParams P, double *fst, int *fiter,
-                                            int *fhalv, int *fvar, int64_t fcap, const int *in_list, const int *in_count, int *next_fast,
-                                            int *next_fast_count, int *exact_list, int *exact_count, int64_t V, double *out, uint32_t *flags)
+// Two translation units from this file (the kernel is large, and there are two per Q): firth_fast.o holds the fp64 kernels and the entry points,
+// firth_fast32.o (-DFF_F32_TU) the single-precision first pass.
+#ifdef FF_ONLY_Q
+#define FF_ALL_Q(X) X(FF_ONLY_Q)
+#else
+#define FF_ALL_Q(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#endif
+#define FF_LAUNCH_ARGS hipStream_t st, int Q, int64_t n, const uint64_t *T, int64_t Vpad, GlmParams P, double *fst, int *fiter, int *fhalv, int *fvar, \
+                       int64_t fcap, const int *in_list, const int *in_count, int *next_fast, int *next_fast_count, int *exact_list, int *exact_count, \
+                       int64_t V, double *out, uint32_t *flags
+#ifdef FF_F32_TU
+extern "C" hipError_t shk_firth_fast_launch32(FF_LAUNCH_ARGS)
 {
     FirthWork fw{fst, fiter, fhalv, fvar, fcap, nullptr, nullptr, nullptr, nullptr};
-#define FF_CASE(q) case q: return launch_firth_fast<q>(st, n, T, Vpad, P, fw, in_list, in_count, next_fast, next_fast_count, exact_list, exact_count, V, out, flags);
+#define FF_CASE(q) case q: return launch_firth_fast<q, true>(st, n, T, Vpad, P, fw, in_list, in_count, next_fast, next_fast_count, exact_list, exact_count, V, out, flags);
     switch (Q) {
-#ifdef FF_ONLY_Q
-        FF_CASE(FF_ONLY_Q)
-#else
-        FF_CASE(1) FF_CASE(2) FF_CASE(3) FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10)
-#endif
+        FF_ALL_Q(FF_CASE)
     default: return hipErrorInvalidValue;
     }
 #undef FF_CASE
 }
+#else
+extern "C" hipError_t shk_firth_fast_launch32(FF_LAUNCH_ARGS);
+extern "C" hipError_t shk_firth_fast_launch(FF_LAUNCH_ARGS, int f32)
+{
+    if (f32) return shk_firth_fast_launch32(st, Q, n, T, Vpad, P, fst, fiter, fhalv, fvar, fcap, in_list, in_count, next_fast, next_fast_count, exact_list,
+                                            exact_count, V, out, flags);
+    FirthWork fw{fst, fiter, fhalv, fvar, fcap, nullptr, nullptr, nullptr, nullptr};
+#define FF_CASE(q) case q: return launch_firth_fast<q, false>(st, n, T, Vpad, P, fw, in_list, in_count, next_fast, next_fast_count, exact_list, exact_count, V, out, flags);
+    switch (Q) {
+        FF_ALL_Q(FF_CASE)
+    default: return hipErrorInvalidValue;
+    }
+#undef FF_CASE
+}
+#endif

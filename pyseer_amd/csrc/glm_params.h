@@ -74,6 +74,7 @@ struct GlmParams {
     // standardised covariates, s = 1 - 2 y, live = 1 (0 behind sample N), w0 = the null model's weight, as doubles (FFC<Q>::RS per sample).  null = the two-pass rounds.
     const void *ff_tab;
     const double *ff_rec;
+    const float *ff_rec32;        // the same records in single precision (same slots, half filled): the first pass
     const double *ff_inull;       // sum_i w0_i m2(i) over the degree-2 table's rows, with the table's own (hi + lo) values: the null model's covariate block of I
 };
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
