@@ -1,6 +1,7 @@
 // api.hip -- host side of libseerhip.so: the flat C ABI declared in include/seerhip.h.
 // One-off per-run setup is done here in plain C++ (it is O(N^2 D) at most); everything per-variant is a HIP kernel.
 #include "common.h"
+#include "route.h"
 #include <string>
 #include <vector>
 #include <thread>
@@ -423,6 +424,7 @@ int sh_warmup(int device)
 sh_ctx *sh_create(int device, int n_samples)
 {
     int n = 0;
+    if (const std::string bad = sh_route_unknown(); !bad.empty()) { g_err = "SEERHIP_ROUTE: unknown item '" + bad + "' (keys: csrc/route.h)"; return nullptr; }
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device: libseerhip has no CPU fallback"; return nullptr; }
     if (device < 0 || device >= n) { g_err = "bad device index"; return nullptr; }
     if (n_samples < 2) { g_err = "n_samples must be >= 2"; return nullptr; }
@@ -435,7 +437,7 @@ sh_ctx *sh_create(int device, int n_samples)
     sh_ctx *c = new sh_ctx();
     c->device = device; c->N = n_samples;
     if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
-    if (const char *ac = std::getenv("SEERHIP_AFCOMPACT")) c->af_compact = std::atoi(ac);
+    if (const char *ac = sh_route("afcompact")) c->af_compact = std::atoi(ac);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
     return c;
@@ -700,7 +702,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
     c->trace_M = 0; for (int i = 0; i < N; ++i) c->trace_M += mdiag_h[i];
 
     c->k = k; c->D = D; c->L = L; c->DP = DP; c->E = E;
-    c->complement = ones_in_span && !std::getenv("SEERHIP_NO_COMPLEMENT");
+    c->complement = ones_in_span && !(sh_route("complement") && std::atoi(sh_route("complement")) == 0);
     if (const char *tv = std::getenv("SEERHIP_LMM_TOL")) c->lmm_tol = std::atof(tv);
     LmmFinParams &P = c->fin;
     P.N = N; P.D = D; P.continuous = continuous; P.n1 = n1; P.n0 = n0; P.yc_sum = ycs; P.yc_sq = ycq;
@@ -876,7 +878,7 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
             HIPCHK(hipMemsetAsync(c->d_nkeep, 0, sizeof(int), st));
             HIPCHK(shk_af_compact(st, 0, V, lo, KP, c->d_keep, c->d_nkeep, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr));
             HIPCHK(hipMemcpyAsync(c->h_nkeep, c->d_nkeep, sizeof(int), hipMemcpyDeviceToHost, st));
-            if (c->filtered_hint >= 0.03 || c->af_compact == 2) {                 // SEERHIP_AFCOMPACT=2: always count (tests)
+            if (c->filtered_hint >= 0.03 || c->af_compact == 2) {                 // SEERHIP_ROUTE afcompact=2: always count (tests)
                 HIPCHK(hipStreamSynchronize(st));
                 nk = *c->h_nkeep; c->filtered_hint = 1.0 - (double)nk / (double)V;
                 compact = nk * 100 <= V * 97;

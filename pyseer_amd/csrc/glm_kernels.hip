@@ -1489,65 +1489,6 @@ __global__ __launch_bounds__(256) void k_glm_bitdot(const uint64_t *__restrict__
     for (int c = 0; c < NE; ++c) P.ch_bd[(int64_t)c * Vpad + v] = acc[c];
 }
 
-// ---- kernel 2: phase B, the reference's all-fp64 iteration restarted for the listed variants -------------------------------
-template <int Q>
-__global__ __launch_bounds__(256) void k_glm_slow(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
-                                                 const double *__restrict__ y, const double *__restrict__ W, GlmParams P,
-                                                 GlmWork wk, uint32_t *__restrict__ flags,
-                                                 int *__restrict__ firth_list, int *__restrict__ firth_count)
-{
-    constexpr int PC = Q + 2;
-    const int cnt = *wk.slow_count;
-    if ((int64_t)blockIdx.x * 64 >= cnt) return;
-    const XWave xw = xwave();                                        // blockDim.x = 64 * glm_split_waves(N)
-    const int slot = blockIdx.x * 64 + xw.lane;
-    const bool live = slot < cnt;
-    const int64_t v = wk.slow_list[live ? slot : 0];
-    const int N = P.N, NB64 = P.NB64;
-    const double nobs = (double)N;
-    double beta[PC];
-#pragma unroll
-    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
-    beta[0] = P.ymean_logit;
-    int it = 0, status = 0;
-    bool active = live;                                              // kept identical in all the waves of the block
-    while (__any(active)) {
-        double H[PC * (PC + 1) / 2], g[PC], ll = 0.0, maxdev = 0.0;
-        if (active) info_pass<Q, true, false>(T, Vpad, v, N, NB64, y, W, beta, H, g, ll, maxdev, false, xw.w, xw.S);
-        xw_sum(xw, H); xw_sum(xw, g); xw_sum_max(xw, ll, maxdev);
-        if (active && xw.w == 0) {
-            if (it > 0 && maxdev <= 1e-8) { status = 1; active = false; }                      // _check_perfect_pred
-            else {
-                // newparams = oldparams - inv(H/n + 1e-10 I) . score/n   with H = -X^T W X   (optimizer.py:415-423)
-#pragma unroll
-                for (int a = 0; a < PC * (PC + 1) / 2; ++a) H[a] = H[a] / nobs;
-#pragma unroll
-                for (int a = 0; a < PC; ++a) { H[sidx(a, a)] -= 1e-10; g[a] = g[a] / nobs; }
-                double det;
-                if (!ldl_factor<PC>(H, 0.0, &det)) { status = 2; active = false; }
-                else {
-                    ldl_solve<PC>(H, g);
-                    bool moving = false;
-#pragma unroll
-                    for (int a = 0; a < PC; ++a) { beta[a] += g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
-                    ++it;
-                    if (!moving || it >= 35) active = false;
-                }
-            }
-        }
-        xw_bcast(xw, beta, active);
-    }
-    if (!live || xw.w != 0) return;
-    if (status == 0) {
-        wk.state[v] = 1;
-#pragma unroll
-        for (int a = 0; a < PC; ++a) wk.bw[(int64_t)a * Vpad + v] = beta[a];
-    } else {
-        flags[v] |= (status == 1) ? SH_NOTE_PERFECT_SEP : SH_NOTE_MATRIX_INV;                   // model.py:345-352
-        const int s2 = atomicAdd(firth_count, 1); firth_list[s2] = (int)v;
-    }
-}
-
 // the decisions of model.py:332-344, 384 on a finished fit, and its output row (shared by k_glm_final and k_glm_finish)
 template <int Q>
 __device__ __forceinline__ void glm_emit(int status, double bse1, double llf, double (&beta)[Q + 2], bool standardised, int64_t v, int64_t V,
@@ -1575,7 +1516,7 @@ __device__ __forceinline__ void glm_emit(int status, double bse1, double llf, do
     if (to_firth) { const int slot = atomicAdd(firth_count, 1); firth_list[slot] = (int)v; }
 }
 
-// ---- the fp64 restart, one WORKGROUP per listed variant (the default; k_glm_slow above is kept behind SEERHIP_SLOW=wave) ----------------
+// ---- the fp64 restart, one WORKGROUP per listed variant (round 2's lane-per-variant form is gone) ----------------
 // The restart list is short in every ordinary batch (nothing on the benchmark rows, a handful of separated or ill-conditioned k-mers in real
 // data), and with a lane per variant each of its ~8 iterations is a walk over N / S samples by one wavefront, then k_glm_final's walk over all
 // N: 1.5-4 ms for a single listed variant, whatever the batch.  Here 256 threads share a variant's samples (thread t: t, t + 256, ...),
@@ -2038,142 +1979,9 @@ __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmP
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
 
-// =====================================================================================================================
-// Firth-penalised logistic regression (model.py:414-504) -- one listed variant per lane
-// =====================================================================================================================
-template <int Q>
-__global__ __launch_bounds__(64) void k_glm_firth(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V,
-                                                  const double *__restrict__ y, const double *__restrict__ W,
-                                                  GlmParams P, const int *__restrict__ firth_list,
-                                                  const int *__restrict__ firth_count,
-                                                  double *__restrict__ out, uint32_t *__restrict__ flags,
-                                                  int *__restrict__ pinv_list, int *__restrict__ pinv_count)
-{
-    constexpr int PC = Q + 2;
-    const double SING_TOL = 1e-12;      // relative pivot size below which numpy's pinv (rcond 1e-15) may differ from inv
-    const int cnt = *firth_count;
-    if ((int64_t)blockIdx.x * 64 >= cnt) return;
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    const bool live = slot < cnt;
-    const int64_t v = firth_list[live ? slot : 0];
-    const int N = P.N, NB64 = P.NB64;
-
-    double beta[PC], cand[PC], A[PC * (PC + 1) / 2], dummy[PC];
-#pragma unroll
-    for (int a = 0; a < PC; ++a) beta[a] = 0.0;
-    beta[0] = P.ymean_logit;
-    double ll, maxdev, det;
-    // F(beta_0)
-    info_pass<Q, false, true>(T, Vpad, v, N, NB64, y, W, beta, A, dummy, ll, maxdev);
-    double i11 = A[sidx(1, 1)];
-    bool singular = !ldl_factor<PC>(A, SING_TOL, &det);
-    double Fcur = -(ll + 0.5 * log(det));                       // firth_likelihood, model.py:410-411
-    double Fcand = Fcur, i11c = i11;
-    int state = (live && !singular) ? 0 : 3;          // 0: needs a score pass (new outer iteration), 1: needs F(cand), 2: converged, 3: done/failed
-    int iter = 0, halvings = 0;
-    double sn_prev = INFINITY;
-    bool failed = false;
-    while (__any(state < 2)) {
-        if (state == 0) {
-            // ---- penalised score at beta with the factored information A = L D L^T:  h_i = w_i x_i^T I^-1 x_i
-            double U[PC], dinv[PC];
-#pragma unroll
-            for (int a = 0; a < PC; ++a) { U[a] = 0.0; dinv[a] = 1.0 / A[sidx(a, a)]; }
-            for (int sb = 0; sb < NB64; ++sb) {
-                const uint64_t w64 = T[(int64_t)sb * Vpad + v];
-                const int nb = min(64, N - sb * 64);
-                for (int b = 0; b < nb; ++b) {
-                    const int i = sb * 64 + b;
-                    double x[PC];
-                    x[0] = 1.0; x[1] = (double)(unsigned)((w64 >> b) & 1ull);
-#pragma unroll
-                    for (int j = 0; j < Q; ++j) x[2 + j] = W[(int64_t)i * Q + j];
-                    double eta = 0.0;
-#pragma unroll
-                    for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
-                    const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
-                    double zt[PC]; double qf = 0.0;
-#pragma unroll
-                    for (int a = 0; a < PC; ++a) {
-                        double s = x[a];
-#pragma unroll
-                        for (int k = 0; k < a; ++k) s = fma(-A[sidx(a, k)], zt[k], s);
-                        zt[a] = s;
-                        qf = fma(s * s, dinv[a], qf);
-                    }
-                    const double h = wgt * qf;                               // diagonal of the hat matrix, model.py:455-462
-                    const double res = y[i] - mu + h * (0.5 - mu);
-#pragma unroll
-                    for (int a = 0; a < PC; ++a) U[a] = fma(x[a], res, U[a]);
-                }
-            }
-            ldl_solve<PC>(A, U);                                             // var_covar_mat . U, model.py:463
-#pragma unroll
-            for (int a = 0; a < PC; ++a) cand[a] = beta[a] + U[a];
-            halvings = 0;
-            state = 1;
-        }
-        if (state == 1) {
-            info_pass<Q, false, true>(T, Vpad, v, N, NB64, y, W, cand, A, dummy, ll, maxdev);
-            i11c = A[sidx(1, 1)];
-            if (!ldl_factor<PC>(A, SING_TOL, &det)) { singular = true; state = 3; }
-            Fcand = -(ll + 0.5 * log(det));
-            double stepmax = 0.0;
-#pragma unroll
-            for (int a = 0; a < PC; ++a) stepmax = fmax(stepmax, fabs(cand[a] - beta[a]));
-            // F(new) > F(old) is decided by rounding noise once the step is ~1e-7 (|dF| ~ step^2 << ulp(F)); the reference then
-            // flips coins until one lands (moving beta by < 1e-10) or, rarely, exhausts step_limit on a 1-ulp tie.  Accept such
-            // steps outright: same result to 1e-10, no spurious 'firth-fail', no 50-pass stalls of the whole wavefront.
-            const bool noise_step = stepmax < P.firth_accept;
-            if (state == 3) {
-            } else if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !noise_step) {    // step halving, model.py:467-474
-                // once beta + 0.5 (cand - beta) returns cand bit for bit every later comparison repeats this one: the reference walks on to
-                // j > step_limit and gives up (model.py:471-473); same verdict, without the walk
-                bool moved = false;
-#pragma unroll
-                for (int a = 0; a < PC; ++a) { const double nc = beta[a] + 0.5 * (cand[a] - beta[a]); moved = moved || (nc != cand[a]); cand[a] = nc; }
-                if (++halvings > 1000 || !moved) { failed = true; state = 3; }
-            } else {
-                double sn = 0.0;
-#pragma unroll
-                for (int a = 0; a < PC; ++a) { const double d = cand[a] - beta[a]; sn = fma(d, d, sn); beta[a] = cand[a]; }
-                sn = sqrt(sn);
-                Fcur = Fcand; i11 = i11c;
-                const bool conv = (iter > 0) && (sn_prev < 1e-4);            // tests the PREVIOUS step, model.py:477-479
-                sn_prev = sn;
-                ++iter;
-                if (conv) state = 2;
-                else if (iter >= 1000) { failed = true; state = 3; }         // step_limit exhausted, model.py:482-484
-                else state = 0;
-            }
-        }
-    }
-    if (!live) return;
-    if (singular) {                     // handled by k_glm_firth_pinv (numpy.linalg.pinv semantics, model.py:450)
-        const int s2 = atomicAdd(pinv_count, 1); pinv_list[s2] = (int)v;
-        return;
-    }
-    uint32_t fl = flags[v];
-    if (failed) {
-        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                           // model.py:357-362
-        out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
-#pragma unroll
-        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
-    } else {
-        const double fitll = -Fcur;
-        const double lrstat = -2.0 * (P.null_firth - fitll);
-        double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
-        out[V + v] = pval; out[2 * V + v] = beta[1]; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0];   // bse = sqrt(I11), model.py:491
-#pragma unroll
-        for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j];
-        if (pval > P.lrtt || !isfinite(pval) || !isfinite(beta[1])) fl |= SH_NOTE_LRT_FILTER | SH_FLAG_FILTER;
-    }
-    flags[v] = fl;
-}
-
 
 // =====================================================================================================================
-// Firth as a device-resident state machine (the default; k_glm_firth above is the single-kernel form kept for A/B).
+// Firth as a device-resident state machine (round 1's single-kernel form is gone).
 //
 // fit_firth (model.py:414-504) alternates two sample passes: the penalised score at beta (hat diagonal through the factored
 // information) and the penalised likelihood at a candidate (a fresh information matrix, its determinant, the step-halving
@@ -3336,11 +3144,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
         } else hipLaunchKernelGGL((k_glm_fast<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
     }
     else if (which == 4) {
-        static const bool wave_form = [] { const char *e = getenv("SEERHIP_SLOW"); return e && std::string(e) == "wave"; }();
-        if (wave_form) {
-            const int S = std::min(4, glm_split_waves(P.NB64));  // 400+ VGPRs per lane: at most four wavefronts per block
-            hipLaunchKernelGGL(k_glm_slow<Q>, grid, dim3(64 * S), glm_split_lds(S), st, T, Vpad, V, y, W, P, wk, flags, flist, fcount);
-        } else hipLaunchKernelGGL(k_glm_slow_blk<Q>, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
+        hipLaunchKernelGGL(k_glm_slow_blk<Q>, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount);
     }
     else if (which == 5) {
         if (Q > 0 && P.a0 && P.w0 && P.zz && P.ws) {
@@ -3348,7 +3152,7 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
             hipLaunchKernelGGL((k_glm_final<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount, 2);
         } else hipLaunchKernelGGL((k_glm_final<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, P, wk, out, flags, flist, fcount, 1);
     }
-    else if (which == 1) hipLaunchKernelGGL(k_glm_firth<Q>, grid, blk, 0, st, T, Vpad, V, y, W, P, flist, fcount, out, flags, plist, pcount);
+    else if (which == 1) return hipErrorInvalidValue;                // (the single-kernel Firth form of round 1 is gone: firth_rounds.hip)
     else if (which == 3) hipLaunchKernelGGL(k_glm_firth_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else if (which == 6) hipLaunchKernelGGL(k_glm_ols_pinv<Q>, dim3(512), dim3(256), 0, st, T, Vpad, V, y, W, P, plist, pcount, out, flags);
     else if (which > 6) return hipErrorInvalidValue;

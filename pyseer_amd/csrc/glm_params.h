@@ -23,7 +23,7 @@ struct GlmParams {
     // to 0: the reference's literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
     double firth_noise, firth_accept;
     int firth_last_taylor;        // 1 (default with the noise rules): k_firth_step2 finishes a fit whose stop rule is already met and whose step is <= 1e-7
-                                  // without the last likelihood pass (F to second order, I11 from the factor on record); SEERHIP_FIRTH_LAST=0 turns it off
+                                  // without the last likelihood pass (F to second order, I11 from the factor on record); SEERHIP_ROUTE firth_last=0 turns it off
     // Warm start of the fast Newton phase: the maximum-likelihood fit WITHOUT the variant column, [b0, bz...] in the coordinates that phase
     // iterates in (standardised covariates), computed once per run (sh_glm_setup).  The likelihood is concave, so the iteration reaches the
     // same fixed point as from the reference's start vector (model.py:323-324) in about half the steps; anything that does not converge

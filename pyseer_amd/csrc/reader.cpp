@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include "route.h"
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -325,6 +326,7 @@ void sh_reader_set_concurrency(int n_readers) { g_reader_concurrency.store(n_rea
 sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int n_samples)
 {
     if (!path || !sample_names || n_samples < 1) { g_rerr = "bad argument"; return nullptr; }
+    if (const std::string bad = sh_route_unknown(); !bad.empty()) { g_rerr = "SEERHIP_ROUTE: unknown item '" + bad + "' (keys: csrc/route.h)"; return nullptr; }
     sh_reader *r = new sh_reader();
     r->n = n_samples;
     r->index.build(sample_names, n_samples);
@@ -348,8 +350,8 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
         r->map = (const uint8_t *)m;
         madvise(m, r->map_len, MADV_SEQUENTIAL);
     }
-    if (const char *sb = std::getenv("SEERHIP_READER_SLAB")) r->slab_bytes = std::max<size_t>(70000, (size_t)std::atoll(sb));
-    if (const char *pb = std::getenv("SEERHIP_READER_PAD")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
+    if (const char *sb = sh_route("reader_slab")) r->slab_bytes = std::max<size_t>(70000, (size_t)std::atoll(sb));
+    if (const char *pb = sh_route("reader_pad")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
     if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
@@ -396,7 +398,6 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
 {
     if (!r || !bits || !counts || !names || !name_off || max_variants < 1) { g_rerr = "bad argument"; return -1; }
     if (row_bytes * 8 < r->n) { g_rerr = "row_bytes too small"; return -1; }
-    auto t0 = std::chrono::steady_clock::now();
     std::vector<std::pair<const char *, const char *>> lines;   // [begin, end) without the newline; they point into slabs held until the end of the call
     const char *ptr0 = nullptr;
     if (r->gz) {
@@ -455,7 +456,7 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
                 if (!r->bridge.empty()) { --r->cur; break; }                             // finish this call here; the next one bridges again
                 const char *nsend = nx.data + nx.len;
                 const void *nl2 = memchr(nx.data, '\n', nx.len);
-                if (!nl2 && !(nx.last)) { g_rerr = "a line longer than a whole read slab: raise SEERHIP_READER_SLAB"; return -1; }
+                if (!nl2 && !(nx.last)) { g_rerr = "a line longer than a whole read slab: raise SEERHIP_ROUTE reader_slab"; return -1; }
                 const char *le = nl2 ? (const char *)nl2 : nsend;
                 r->bridge.assign(lstart, send); r->bridge.insert(r->bridge.end(), nx.data, le);
                 lines.emplace_back(r->bridge.data(), r->bridge.data() + r->bridge.size());
@@ -468,7 +469,6 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     (void)cur_after;
     const int64_t nv = (int64_t)lines.size();
     if (nv == 0) return 0;
-    auto t1 = std::chrono::steady_clock::now();
     // ---- names (serial: offsets), presence (parallel).  Unitig names run to tens of kilobases: the total is measured BEFORE anything is
     // written, and a call that does not fit is refused without consuming its lines (-2; sh_reader_names_needed() says how much to bring)
     std::vector<std::pair<const char *, const char *>> nm((size_t)nv);

@@ -1,0 +1,60 @@
+// Test hook: ONE environment variable that forces the routes a run would otherwise choose from its data, so that the tests can put every
+// fallback kernel under the same inputs (tests/test_glm_gpu.py::test_logistic_fit_paths_agree and friends).  Not a tuning interface.
+//   SEERHIP_ROUTE="key=value,key=value,..."      unknown keys are an error (sh_create / sh_reader_open refuse)
+// Keys (default in brackets):
+//   chord=0          [1]  logistic: fp64-score Newton passes instead of the chord rounds (the form a run without covariates takes)
+//   chord_n32=K      [5]  single-precision Newton rounds before the chord rounds (1..8); stragglers restart in fp64
+//   chord_enter=X    [5e-3] step below which a variant enters the chord rounds
+//   bitdot=0         [1]  first Newton step by a sample pass, k_glm_final instead of the finishing kernels
+//   first_bordered=0 [1]  first Newton step through the general (Q+2)^2 solve
+//   pk=0             [1]  the passes without the packed single-precision records
+//   warm=0           [1]  no null-model warm start (the reference's start vector)
+//   fin_rounds=0     [1]  k_glm_final for every variant
+//   ll_first=0       [1]  score pass first, likelihood pass last
+//   newton=1         [0]  every variant through the all-fp64 kernel (the reference's trajectory)
+//   firth_last=0     [1]  Firth rounds: the last likelihood pass taken instead of carried over the last step
+//   firth_first32=0  [1]  one-pass Firth: the first pass in fp64 like the others
+//   afcompact=M      [1]  0: never compact AF / prefilter-rejected rows before the kernels, 2: always
+//   complement=0     [1]  LMM: rows with more than N/2 carriers stored as given
+//   reader_slab=B, reader_pad=B   reader: bytes per decoded slab / carried over between slabs
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+static inline const char *const *sh_route_keys()
+{
+    static const char *const keys[] = {"chord", "chord_n32", "chord_enter", "bitdot", "first_bordered", "pk", "warm", "fin_rounds", "ll_first", "newton",
+                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", nullptr};
+    return keys;
+}
+// the value of `key` in SEERHIP_ROUTE, or nullptr (the returned string lives until the calling thread's next sh_route)
+static inline const char *sh_route(const char *key)
+{
+    const char *e = std::getenv("SEERHIP_ROUTE");
+    if (!e) return nullptr;
+    static thread_local std::string val;
+    const size_t kl = std::strlen(key);
+    for (const char *p = e; *p;) {
+        const char *end = std::strchr(p, ','); if (!end) end = p + std::strlen(p);
+        const char *eq = (const char *)std::memchr(p, '=', (size_t)(end - p));
+        if (eq && (size_t)(eq - p) == kl && std::memcmp(p, key, kl) == 0) { val.assign(eq + 1, end); return val.c_str(); }
+        p = *end ? end + 1 : end;
+    }
+    return nullptr;
+}
+// empty when every key of SEERHIP_ROUTE is known, else the offending item
+static inline std::string sh_route_unknown()
+{
+    const char *e = std::getenv("SEERHIP_ROUTE");
+    if (!e) return std::string();
+    for (const char *p = e; *p;) {
+        const char *end = std::strchr(p, ','); if (!end) end = p + std::strlen(p);
+        const char *eq = (const char *)std::memchr(p, '=', (size_t)(end - p));
+        bool ok = false;
+        if (eq) for (const char *const *k = sh_route_keys(); *k; ++k) if (std::strlen(*k) == (size_t)(eq - p) && std::memcmp(*k, p, (size_t)(eq - p)) == 0) ok = true;
+        if (!ok && end > p) return std::string(p, end);
+        p = *end ? end + 1 : end;
+    }
+    return std::string();
+}

@@ -114,7 +114,7 @@ def test_forced_firth_golden(path):
 @pytest.mark.parametrize("N,q", [(5000, 10), (1500, 6), (900, 0)])
 def test_firth_last_pass_saved_changes_nothing_at_the_bar(N, q, monkeypatch):
     """Forced Firth (C4's mode): by default k_firth_step2 finishes a fit whose stop rule is already met from the beta before its last candidate
-    (F to second order, I11 from the factor on record) instead of taking the likelihood pass there; SEERHIP_FIRTH_LAST=0 takes the pass.  Same
+    (F to second order, I11 from the factor on record) instead of taking the likelihood pass there; SEERHIP_ROUTE=firth_last=0 takes the pass.  Same
     flags, kbeta / intercept / betas identical (the candidate is formed by the same instructions), p-value to 1e-9, bse to 1e-7."""
     from pyseer_amd.engine import Engine, pack_variants
     from pyseer_amd.model import fit_null
@@ -131,9 +131,9 @@ def test_firth_last_pass_saved_changes_nothing_at_the_bar(N, q, monkeypatch):
     bits = pack_variants(K)
     out = []
     for last in ("1", "0"):
-        monkeypatch.setenv("SEERHIP_FIRTH_LAST", last)
+        monkeypatch.setenv("SEERHIP_ROUTE", "firth_last=" + last)
         e = Engine(N); e.set_af_filter(0.01, 0.99); e.glm_setup(y, W, False, nl, nf, force_firth=True); out.append(e.glm_batch(bits)); e.close()
-    monkeypatch.delenv("SEERHIP_FIRTH_LAST")
+    monkeypatch.delenv("SEERHIP_ROUTE")
     a, b = out
     assert np.array_equal(a["flags"], b["flags"])
     ok = np.isfinite(b["kbeta"])
@@ -513,7 +513,7 @@ def test_af_compaction_changes_nothing(cont, dedup, monkeypatch):
     bits = pack_variants(K)
     res = []
     for mode in ("2", "0", "1"):
-        monkeypatch.setenv("SEERHIP_AFCOMPACT", mode)
+        monkeypatch.setenv("SEERHIP_ROUTE", "afcompact=" + mode)
         e = Engine(N); e.set_af_filter(0.01, 0.99); e.set_dedup(dedup)
         e.glm_setup(y, W, cont, nl, nf)
         res.append(e.glm_batch(bits)); res.append(e.glm_batch(bits)); e.close()
@@ -586,7 +586,7 @@ def test_prefilter_compaction_changes_nothing(dedup, monkeypatch):
     bits = pack_variants(K)
     res = []
     for mode in ("2", "0", "1"):
-        monkeypatch.setenv("SEERHIP_AFCOMPACT", mode)
+        monkeypatch.setenv("SEERHIP_ROUTE", "afcompact=" + mode)
         e = Engine(N); e.set_af_filter(0.01, 0.99); e.set_dedup(dedup)
         e.glm_setup(y, W, False, nl, nf, pret, 1.0)
         res.append(e.glm_batch(bits)); res.append(e.glm_batch(bits)); e.close()
@@ -630,29 +630,28 @@ def test_logistic_fit_paths_agree(N, q, monkeypatch):
     want = orc.fixed_effects_batch(y, K.astype(float), W, False, 1.0, 1.0, nl, nf)
     bits = pack_variants(K)
 
-    def run(**env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    def run(**route):                                            # the one test hook: csrc/route.h
+        if route:
+            monkeypatch.setenv("SEERHIP_ROUTE", ",".join("%s=%s" % kv for kv in route.items()))
         e = Engine(N); e.glm_setup(y, W, False, nl, nf); r = e.glm_batch(bits); e.close()
-        for k in env:
-            monkeypatch.delenv(k)
+        if route:
+            monkeypatch.delenv("SEERHIP_ROUTE")
         return r
     base = run()
     firth = (want["notes"] & 0x7C) != 0
     for f in ("prep", "pvalue", "kbeta", "bse", "intercept"):
         close(base[f][~firth], want[f][~firth], what=f)
     assert ((base["flags"] & 0x1FF) == want["notes"]).all()
-    routes = [dict(SEERHIP_CHORD="0"),                               # the three-kernel form
-              dict(SEERHIP_CHORD_ENTER="5e-2"),                      # early hand-over: several chord rounds per variant
-              dict(SEERHIP_CHORD_N32="2"),                           # stragglers of the Newton rounds restarted in fp64 (workgroup kernel)
-              dict(SEERHIP_CHORD_N32="2", SEERHIP_SLOW="wave"),      # ... by the lane-per-variant kernels
-              dict(SEERHIP_BITDOT="0"),                              # first step by a pass, k_glm_final instead of the finishing kernels
-              dict(SEERHIP_FIN_ROUNDS="0"), dict(SEERHIP_PK="0"), dict(SEERHIP_WARM="0"), dict(SEERHIP_NEWTON="1"),
-              dict(SEERHIP_LL_FIRST="0"),                            # score pass first, likelihood pass last (one more fp64 pass per variant)
-              dict(SEERHIP_LL_FIRST="0", SEERHIP_CHORD_ENTER="5e-2"),
-              dict(SEERHIP_FIRTH_LAST="0"),                          # the routed variants' Firth fits take their last likelihood pass
-              dict(SEERHIP_FIRST_BORDERED="0"),                      # the first Newton step through the general 12 x 12 kernel (product: bordered solve)
-              dict(SEERHIP_FIRST_BORDERED="0", SEERHIP_CHORD_ENTER="5e-2")]
+    routes = [dict(chord="0"),                                       # the three-kernel form (what a run without covariates takes)
+              dict(chord_enter="5e-2"),                              # early hand-over: several chord rounds per variant
+              dict(chord_n32="2"),                                   # stragglers of the Newton rounds restarted in fp64 (workgroup kernel)
+              dict(bitdot="0"),                                      # first step by a pass, k_glm_final instead of the finishing kernels
+              dict(fin_rounds="0"), dict(pk="0"), dict(warm="0"), dict(newton="1"),
+              dict(ll_first="0"),                                    # score pass first, likelihood pass last (one more fp64 pass per variant)
+              dict(ll_first="0", chord_enter="5e-2"),
+              dict(firth_last="0"),                                  # the routed variants' Firth fits take their last likelihood pass
+              dict(first_bordered="0"),                              # the first Newton step through the general 12 x 12 kernel (product: bordered solve)
+              dict(first_bordered="0", chord_enter="5e-2")]
     for env in routes:
         r = run(**env)
         assert (r["flags"] == base["flags"]).all(), env

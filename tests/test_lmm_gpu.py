@@ -481,7 +481,7 @@ def test_af_compaction_changes_nothing(engine_mod, frac_rare, monkeypatch):
     bits = pack(Kv)
     res = []
     for on in ("2", "0", "1"):                                     # 2 = count every batch, 0 = never compact, 1 = default (adaptive)
-        monkeypatch.setenv("SEERHIP_AFCOMPACT", on)
+        monkeypatch.setenv("SEERHIP_ROUTE", "afcompact=" + on)
         e = Engine(N); e.set_af_filter(0.01, 0.99)
         e.lmm_setup(U, S, y, covar, 0.41)
         res.append(e.lmm_batch(bits)); res.append(e.lmm_batch(bits)); e.close()       # the second call of a context knows the first one's count
@@ -511,7 +511,7 @@ def test_prefilter_compaction_changes_nothing(engine_mod, monkeypatch):
     bits = pack(Kv)
     res = []
     for on in ("2", "0", "1"):
-        monkeypatch.setenv("SEERHIP_AFCOMPACT", on)
+        monkeypatch.setenv("SEERHIP_ROUTE", "afcompact=" + on)
         e = Engine(N); e.set_af_filter(0.01, 0.99)
         e.lmm_setup(U, S, y, covar, 0.33, continuous=False, filter_pvalue=pret, lrt_pvalue=0.5)
         res.append(e.lmm_batch(bits)); res.append(e.lmm_batch(bits)); e.close()
@@ -570,7 +570,7 @@ def test_extra_limb_pass_is_as_good_as_more_limbs(engine_mod):
 
 
 def test_complemented_rows_change_nothing_but_rounding(engine_mod, monkeypatch):
-    """Rows with more than N/2 carriers are stored complemented (k_repack_bits); SEERHIP_NO_COMPLEMENT=1 (read by sh_lmm_setup) stores
+    """Rows with more than N/2 carriers are stored complemented (k_repack_bits); SEERHIP_ROUTE=complement=0 (read by sh_lmm_setup) stores
     them as given.  Same statistics up to the quantisation of G, counts / prefilter / flags identical, with covariates and a continuous
     phenotype as well."""
     Engine, pack = engine_mod
@@ -582,10 +582,10 @@ def test_complemented_rows_change_nothing_but_rounding(engine_mod, monkeypatch):
         e = Engine(N); e.set_af_filter(0.01, 0.99)
         e.lmm_setup(U, S, y, covar, 0.41, continuous=cont, filter_pvalue=0.7)
         a = e.lmm_batch(pack(Kv))
-        monkeypatch.setenv("SEERHIP_NO_COMPLEMENT", "1")
+        monkeypatch.setenv("SEERHIP_ROUTE", "complement=0")
         e.lmm_setup(U, S, y, covar, 0.41, continuous=cont, filter_pvalue=0.7)
         b = e.lmm_batch(pack(Kv))
-        monkeypatch.delenv("SEERHIP_NO_COMPLEMENT")
+        monkeypatch.delenv("SEERHIP_ROUTE")
         e.close()
         assert np.array_equal(a["flags"], b["flags"]) and np.array_equal(np.isnan(a["prep"]), np.isnan(b["prep"]))
         assert _dev(a["prep"], b["prep"]) < (1e-12 if cont else 1e-300)    # binary: integer counts, identical; Welch sums: by subtraction

@@ -105,8 +105,7 @@ def test_buffer_stays_bounded_over_many_blocks(tmp_path, monkeypatch):
         lines.append("K%06d | %s\n" % (v, " ".join("%s:1" % samples[i] for i in carriers)))
     text = "".join(lines).encode()
     assert len(text) > 40 << 20
-    monkeypatch.setenv("SEERHIP_READER_SLAB", str(1 << 20))
-    monkeypatch.setenv("SEERHIP_READER_PAD", str(1 << 18))
+    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=%d,reader_pad=%d" % (1 << 20, 1 << 18))
     for name, blob in (("big.gz", gzip.compress(text, 1)), ("big.txt", text)):
         path = str(tmp_path / name)
         open(path, "wb").write(blob)
@@ -173,7 +172,7 @@ def test_every_container_gives_the_same_blocks(tmp_path, monkeypatch):
              "bgzf.gz": _bgzf(text)}
     co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
     files["fixed.gz"] = co.compress(text) + co.flush()
-    monkeypatch.setenv("SEERHIP_READER_SLAB", "50000")             # many slabs, member and block boundaries inside them
+    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=50000")             # many slabs, member and block boundaries inside them
     want = None
     for name, blob in files.items():
         path = str(tmp_path / name)
@@ -217,7 +216,7 @@ def test_lines_longer_than_the_pad_and_blocks_spanning_many_slabs(tmp_path, monk
     text = _kmer_text(samples, 700, 21)[:-1]                       # no trailing newline
     want = None
     for slab, pad, bs in ((1 << 24, 1 << 20, 97), (70000, 32768, 97), (70000, 32768, 5000), (200000, 32768, 1)):
-        monkeypatch.setenv("SEERHIP_READER_SLAB", str(slab)); monkeypatch.setenv("SEERHIP_READER_PAD", str(pad))
+        monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=%d,reader_pad=%d" % (slab, pad))
         for name, blob in (("t.txt", text), ("t.gz", gzip.compress(text, 6)), ("t.bgzf.gz", _bgzf(text))):
             path = str(tmp_path / name)
             open(path, "wb").write(blob)
@@ -230,7 +229,7 @@ def test_lines_longer_than_the_pad_and_blocks_spanning_many_slabs(tmp_path, monk
     # lines of ~45 KB against a 32 KB pad: the bridge
     samples2 = ["s%05d" % i for i in range(6000)]
     text2 = _kmer_text(samples2, 60, 22)
-    monkeypatch.setenv("SEERHIP_READER_SLAB", "100000"); monkeypatch.setenv("SEERHIP_READER_PAD", "32768")
+    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=100000,reader_pad=32768")
     ref = None
     for name, blob in (("u.txt", text2), ("u.gz", gzip.compress(text2, 6))):
         path = str(tmp_path / name); open(path, "wb").write(blob)
@@ -239,7 +238,7 @@ def test_lines_longer_than_the_pad_and_blocks_spanning_many_slabs(tmp_path, monk
         if ref is None:
             ref = cur; assert len(cur[0]) == 60
         assert cur[0] == ref[0] and np.array_equal(cur[1], ref[1])
-    monkeypatch.setenv("SEERHIP_READER_SLAB", str(1 << 24)); monkeypatch.setenv("SEERHIP_READER_PAD", str(1 << 20))
+    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=%d,reader_pad=%d" % (1 << 24, 1 << 20))
     big = [(n, b.copy()) for n, b, c in NativeKmerReader(str(tmp_path / "u.gz"), samples2, 7)]
     assert sum((g[0] for g in big), []) == ref[0] and np.array_equal(np.concatenate([g[1] for g in big]), ref[1])
 
@@ -306,7 +305,7 @@ def test_block_larger_than_any_fixed_number_of_slabs_does_not_hang(tmp_path, mon
             "for names, bits, counts in NativeKmerReader(sys.argv[1], s, 10000):\n"
             "    n += len(names); c += int(counts.sum())\n"
             "print(n, c)\n")
-    env = dict(os.environ, SEERHIP_READER_SLAB="70000", SEERHIP_READER_PAD="32768",
+    env = dict(os.environ, SEERHIP_ROUTE="reader_slab=70000,reader_pad=32768",
                PYTHONPATH=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     out = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -424,3 +423,14 @@ def test_parser_worker_count_does_not_change_the_rows(tmp_path, monkeypatch):
         got[nt] = (np.concatenate([np.array(b.bits) for b in blocks]), b"".join(bytes(b.names_blob) for b in blocks))
     assert np.array_equal(got[None][0], got["1"][0]) and np.array_equal(got[None][0], got["5"][0])
     assert got[None][1] == got["1"][1] == got["5"][1] and got[None][0].shape[0] == 700
+
+
+def test_an_unknown_route_key_is_refused(tmp_path, monkeypatch):
+    """SEERHIP_ROUTE (csrc/route.h) is the one hook the tests force routes with; a key nobody reads is an error, not a silently ignored typo."""
+    p = tmp_path / "k.txt"
+    p.write_text("AAAC | s0:1 s1:1\n")
+    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=70000,reader_pda=32768")
+    with pytest.raises(IOError, match="reader_pda=32768"):
+        NativeKmerReader(str(p), ["s0", "s1"])
+    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=70000,reader_pad=32768")
+    r = NativeKmerReader(str(p), ["s0", "s1"]); r.close()

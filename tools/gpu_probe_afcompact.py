@@ -15,7 +15,7 @@ for frac in (0.0, 0.02, 0.1, 0.3, 0.6):
         rare = torch.randperm(V, device=dev)[:nr]
         b[rare] = 0; b[rare, 0] = 1                                  # one carrier: AF = 1/N < 1 %
     for on in ("0", "1"):
-        os.environ["SEERHIP_AFCOMPACT"] = on
+        os.environ["SEERHIP_ROUTE"] = "afcompact=" + on
         e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
         e.lmm_setup(U, S, y, C, h2)
         for _ in range(4): e.lmm_batch_dev(b)
@@ -41,7 +41,7 @@ for frac in (0.0, 0.1, 0.3, 0.6):
         rare = torch.randperm(Vg, device=dev)[:nr]
         b[rare] = 0; b[rare, 0] = 1
     for on in ("0", "1"):
-        os.environ["SEERHIP_AFCOMPACT"] = on
+        os.environ["SEERHIP_ROUTE"] = "afcompact=" + on
         e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
         e.glm_setup(yb, W, False, nl, nf)
         for _ in range(4): e.glm_batch_dev(b)
@@ -55,7 +55,7 @@ for frac in (0.0, 0.1, 0.3, 0.6):
 # ---- --filter-pvalue: almost every row fails the prefilter and is never fitted
 for pret in (1.0, 1e-2, 1e-4):
     for on in ("0", "1"):
-        os.environ["SEERHIP_AFCOMPACT"] = on
+        os.environ["SEERHIP_ROUTE"] = "afcompact=" + on
         e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
         e.glm_setup(yb, W, False, nl, nf, pret, 1.0)
         b = bits[:Vg]
@@ -71,7 +71,7 @@ for pret in (1.0, 1e-2, 1e-4):
 # ---- --filter-pvalue with --lmm: pre-filtered variants never reach the quadratic form
 for pret in (1.0, 1e-2):
     for on in ("0", "1"):
-        os.environ["SEERHIP_AFCOMPACT"] = on
+        os.environ["SEERHIP_ROUTE"] = "afcompact=" + on
         e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
         e.lmm_setup(U, S, y, C, h2, continuous=False, filter_pvalue=pret, lrt_pvalue=1.0)
         for _ in range(4): e.lmm_batch_dev(bits)
