@@ -174,7 +174,41 @@ def design_rare(rng, N, q, slope):
     return y, m, rows()
 
 
-FAMILIES = {"strongcov": design_strong_covariate, "strongeff": design_strong_effect, "lattice": design_lattice_separable,
+def design_rare_screened(rng, N, q, slope):
+    """firth-fail, looked for where it can be found: rows that are bad-chisq BY CONSTRUCTION (all carriers but at most one in one phenotype
+    class: a 2x2 cell <= 1, so every one of them goes through fit_firth), pre-screened by the C restatement (oracle/seer_oracle.c, which sums
+    the log-likelihood in numpy's order) -- only the rows IT calls firth-fail, and a control per batch, are handed to the reference, which
+    has the last word on every row kept."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import oracle as orc
+    m = rng.standard_normal((N, q)); m = m / np.abs(m).max(axis=0) if q else m
+    eta = -0.3 + (slope * m[:, 0] if q else 0.0) - (m[:, 1] if q > 1 else 0.0)
+    y = (rng.random(N) < sigmoid(eta)).astype(float)
+    nl, nf = nulls(y, m, q)
+    cls = [np.where(y == 0)[0], np.where(y == 1)[0]]
+    lo, hi = max(2, int(0.011 * N) + 1), max(4, int(0.05 * N))
+
+    def rows():
+        screened = 0
+        while True:
+            B = 20000
+            K = np.zeros((B, N))
+            for b in range(B):
+                c = int(rng.integers(lo, hi)); a = int(rng.integers(0, 2)); other = int(rng.random() < 0.5)
+                K[b, rng.choice(cls[a], min(c - other, cls[a].size), replace=False)] = 1
+                if other:
+                    K[b, rng.choice(cls[1 - a], 1)] = 1
+            res = orc.fixed_effects_batch(y, K, m if q else None, False, 1.0, 1.0, nl, nf)
+            flagged = np.where(res["notes"] & BIT["firth-fail"])[0]
+            screened += B
+            print("    screened %d rows, the restatement flags %d of this batch" % (screened, flagged.size), flush=True)
+            for b in flagged:
+                yield K[b]
+            yield K[0]
+    return y, m, rows()
+
+
+FAMILIES = {"rarescreened": design_rare_screened, "strongcov": design_strong_covariate, "strongeff": design_strong_effect, "lattice": design_lattice_separable,
             "rare": design_rare}
 
 
@@ -254,6 +288,11 @@ if __name__ == "__main__":
         # summation order, 1 in 6e4 at N = 1000): `--long SEED N q MINUTES` is the hours-long search, one process per seed
         seed, N_, q_, minutes = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
         search("glm_exit_firthfail_N%d_q%d_s%d" % (N_, q_, seed), "rare", seed, N_, q_, 1.5, "firth-fail", 2, 10 ** 9, n_ctrl=4, budget_s=60 * minutes)
+        sys.exit(0)
+    if only == "--screened":
+        # the same search with the C restatement in front (design_rare_screened): --screened SEED N q MINUTES
+        seed, N_, q_, minutes = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
+        search("glm_exit_firthfail_N%d_q%d_s%d" % (N_, q_, seed), "rarescreened", seed, N_, q_, 1.5, "firth-fail", 4, 10 ** 9, n_ctrl=4, budget_s=60 * minutes)
         sys.exit(0)
     for j in jobs:
         if only and only not in j[0]:

@@ -47,6 +47,15 @@ def test_fixed_effects_golden(path):
     dup = np.zeros(main.shape[0], bool)
     if "bincov" in path:
         dup[[8, 9]] = True
+    # A `firth-fail` of the reference that it does not repeat with the samples in another order (perm_notes, make_exit_golden.py) is its
+    # rounding-noise failure: F at the candidate exceeds F at the iterate by the last bits of an N-term sum, for
+    # every halving.  Such a row may come back as the reference has it, OR as the reference has it in the other orders -- the whole row
+    # then: notes, and every statistic to 1e-6 (checked at the end); it is left out of the comparisons with the reference's NaNs.
+    fl = r["flags"]
+    alt_row = np.zeros(main.shape[0], bool)
+    if "perm_notes" in d.files:
+        alt_row = ((d["notes"] & 0x40) != 0) & ((d["perm_notes"] & 0x40) == 0).all(axis=1) & ((fl & 0x1FF) != d["notes"])
+    dup = dup | alt_row
     close(r["prep"], main[:, 0], what="prep")
     close(r["pvalue"][~dup], main[~dup, 1], atol=1e-300, what="pvalue")
     # rows the reference fitted by Newton / OLS: 1e-6 relative, no slack.  Rows it sent through fit_firth (notes bits 2-6): 1e-6 relative, and
@@ -58,7 +67,7 @@ def test_fixed_effects_golden(path):
         close(r[f][~firth], main[~firth, j], what=f)
     if int(d["q"]):
         close(r["betas"][plain], d["betas"][plain], atol=1e-12, what="betas")
-        assert np.isnan(r["betas"][~tested]).all()
+        assert np.isnan(r["betas"][~tested & ~alt_row]).all()
     fr = firth & tested
     needed = 0
     if fr.any():
@@ -76,9 +85,18 @@ def test_fixed_effects_golden(path):
             good, nt = golden_firth_rows_close(r["betas"][fr, c], d["betas"][fr, c], vc, "b", allr); needed += nt
             assert good.all(), ("betas", c, np.where(fr)[0][~good][:5])
     print("%s: %d Firth-routed rows, %d statistic values needed the tie detector" % (os.path.basename(path), int(fr.sum()), needed))
-    fl = r["flags"]
-    assert ((fl & 0x1FF) == d["notes"]).all(), np.argwhere((fl & 0x1FF) != d["notes"]).ravel()
-    assert (((fl >> 16) & 1) == d["prefilter"]).all() and (((fl >> 17) & 1) == d["filter"]).all()
+    same = ~alt_row
+    for v in np.where(alt_row)[0]:
+        alt = [j for j in range(d["perm_notes"].shape[1]) if (fl[v] & 0x1FF) == d["perm_notes"][v, j]]
+        assert alt, (v, fl[v] & 0x1FF, d["perm_notes"][v])
+        pm = d["perm_main"][v, alt[0]]
+        close(np.array([r["prep"][v], r["pvalue"][v], r["kbeta"][v], r["bse"][v], r["intercept"][v]]), pm, atol=1e-300,
+              what="row %d as the reference has it in another sample order" % v)
+        if int(d["q"]):
+            close(r["betas"][v], d["perm_betas"][v, alt[0]], atol=1e-12, what="betas of row %d" % v)
+        print("%s: row %d is a rounding-noise firth-fail of the reference; fitted here as the reference fits it in another sample order" % (os.path.basename(path), v))
+    assert ((fl & 0x1FF)[same] == d["notes"][same]).all(), np.argwhere(((fl & 0x1FF) != d["notes"]) & same).ravel()
+    assert (((fl >> 16) & 1) == d["prefilter"]).all() and (((fl >> 17) & 1)[same] == d["filter"][same]).all()
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "glm_*.npz"))))
