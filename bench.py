@@ -33,7 +33,8 @@ GLM_KERNELS = {False: "k_glm_fast<Q,true> (prefilter, routing) + k_glm_bitdot + 
                       "k_glm_dpass_pk + k_glm_finish (+ k_glm_slow_blk and the Firth kernels for routed rows)",
                True: "k_glm_fast<Q,true> + k_glm_bitdot + k_firth_init2 + passes of k_firth_fast (one sample pass per Firth iteration: eta / exp / log-likelihood / "
                      "exact score in fp64 on the vector ALU, the information matrix and the penalty's third-moment tensor as f16 hi/lo MFMAs with fp32 accumulation; "
-                     "fits finished in the kernel) + k_firth_eval2 / k_firth_step2 (exact two-pass rounds) for the fits that leave the fast passes"}
+                     "the first pass, at the start vector, in single precision with one f16 product per tile; fits finished in the kernel) + k_firth_eval2 / "
+                     "k_firth_step2 (exact two-pass rounds) for the fits that leave the fast passes"}
 FP64_FLOP_PER_TEST = 5.0e7         # 2*k*N + 6k fp64 flop of the reference formulation, k=4999
 ALGO_BYTES_PER_TEST = 673          # ceil(N/8) in + 48 out
 PROFILE_DIRS = ("r04", "r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
@@ -324,7 +325,9 @@ def glm_roofline(cfg, q, Vs, kern_s, klaunch, rb):
             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "kernel": GLM_KERNELS[force], "kernel_ms": kern_s * 1e3, "launches": klaunch,
             "ops": "fp64 lane-flops actually executed per variant (PMC: 64 x (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64)) x variants per step "
-                   "/ HIP-event time of those kernels per step; single-precision work (first Newton rounds, the Firth hat diagonal) is reported beside it, not added",
+                   "/ HIP-event time of those kernels per step; single-precision work (first Newton rounds, the first Firth pass) and the f16 MFMA work are reported beside it, not "
+                   "added.  This fraction falls when a round removes fp64 arithmetic (C4: 4.76 M fp64 flop per variant in round 3, 1.03 M now, at 1.8x the "
+                   "variants/s): valu_issue_frac is the one that says how busy the binding unit is",
             "fp64_flops_per_variant": f64, "fp32_flops_per_variant": f32, "fp16_mfma_flops_per_variant": f16, "flops_source": fsrc,
             "mfma_f16_tflops": None if not f16 else f16 * Vs / kern_s / 1e12,
             # what binds these kernels is the vector ALU's ISSUE rate, whatever the precision (fp64, packed fp32 and conversions each take one
@@ -338,7 +341,7 @@ def glm_roofline(cfg, q, Vs, kern_s, klaunch, rb):
 def glm_metric(cfg, N):
     force = cfg == "C4"
     return ("k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
-            "f64 (eta, likelihood, score, solves) + f16 hi/lo MFMA with fp32 accumulation (information matrix, third-moment tensor of the penalty); f64 throughout for the fits the exact kernels take" if force
+            "f64 (eta, likelihood, score, solves) + f16 hi/lo MFMA with fp32 accumulation (information matrix, third-moment tensor of the penalty); f32 for the first of the ~3 passes (its step is 1e-5 from the fit at best); f64 throughout for the fits the exact kernels take" if force
             else "f64 (score, likelihood, final information matrix) + f32 Hessian in the first Newton phase")
 
 
