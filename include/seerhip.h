@@ -205,6 +205,9 @@ int64_t     sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, in
 int64_t     sh_reader_names_needed(sh_reader *r);
 /* bytes of inflated text currently buffered (bounded by one block of lines + one read slab; for tests) */
 int64_t     sh_reader_buffered(sh_reader *r);
+/* gzip members decoded on several threads (csrc/inflate_par.h): chunks accepted so far that started from a SEARCHED block head (0: the
+ * stream was decoded by one thread -- small file, stored/fixed blocks only, SEERHIP_READER=serial, BGZF, plain text). */
+int64_t     sh_reader_par_chunks(sh_reader *r);
 
 /* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */
 int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);

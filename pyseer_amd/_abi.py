@@ -62,6 +62,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_int64)]),
     "sh_reader_names_needed": (C.c_int64, [C.c_void_p]),
     "sh_reader_buffered": (C.c_int64, [C.c_void_p]),
+    "sh_reader_par_chunks": (C.c_int64, [C.c_void_p]),
     "sh_format_rows": (C.c_int64, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.POINTER(c_dp), C.c_int, c_dp,
                                    C.c_int, c_u8p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.c_int, c_u32p, C.c_char_p,
                                    C.c_int64]),

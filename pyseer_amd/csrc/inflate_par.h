@@ -1,0 +1,193 @@
+// inflate_par.h -- ONE gzip member decoded by several threads (reader.cpp: produce_gzip_parallel).
+//
+// A DEFLATE stream is sequential twice over: a block can only be found by decoding the one before it, and a match may copy from the 32 KB
+// of text before its block.  Both are worked around the way pugz does it (Kerbiriou & Chikhi 2019, "Parallel decompression of gzip-compressed
+// files and random access to DNA sequences"), restated here for the k-mer text:
+//   1. the compressed bytes are cut into chunks; in every chunk but the first a thread LOOKS for the head of a dynamic-Huffman block, bit
+//      offset by bit offset: the 17 header bits, a complete code-length code, complete literal/length and distance codes, and a first stretch
+//      of symbols that decodes to printable text.  Chance passes all of that about never; if it does, step 3 finds out.
+//   2. every chunk is decoded from its block head to the next chunk's, into 16-bit symbols: a literal is its byte, and a copy that reaches
+//      back before the chunk's first byte copies MARKERS -- the decoder starts with 32 768 of them in front of its output, marker k standing
+//      for byte k of the unknown window -- so matches are plain 16-bit copies and need no special case.
+//   3. in stream order: chunk j is accepted iff chunk j-1 was accepted and ENDED on the very bit chunk j started from (so a false block head
+//      costs its chunk, nothing else); its window is the last 32 KB of the text before it, known once chunk j-1's last 32 KB are resolved;
+//      the symbols of all accepted chunks are then translated to bytes in parallel.
+// The first chunk of a round starts from the exact position the previous round ended on, with the real window in front of it: same code,
+// no markers.  The member's CRC-32 and ISIZE are checked by the caller as for the one-thread decoder.  Test infrastructure: zlib
+// (tests/test_reader_cpu.py decodes the same files through python's gzip and through SEERHIP_READER=serial).
+#pragma once
+#include <vector>
+#include "inflate_fast.h"
+
+namespace shinf {
+
+static const uint32_t PAR_WIN = 32768;
+
+static inline uint64_t par_bitpos(const Decoder &d, const uint8_t *base) { return (uint64_t)(d.in - base) * 8 - (uint64_t)d.bitcnt; }
+static inline void par_seek(Decoder &d, const uint8_t *base, const uint8_t *end, uint64_t bit)
+{
+    d.in = base + (bit >> 3); d.in_end = end; d.bitbuf = 0; d.bitcnt = 0; d.err = nullptr;
+    d.refill(); d.drop((int)(bit & 7));
+    d.state = Decoder::BLOCK_HEAD; d.raw = true; d.last_block = false;
+}
+
+struct ParChunk {
+    uint64_t start_bit = 0, stop_bit = ~0ull;     // decode from a block head at start_bit up to the first block head at or after stop_bit
+    bool exact = false;                            // the window in front is real text (sym[0 .. PAR_WIN) hold bytes where known)
+    std::vector<uint16_t> sym;                     // PAR_WIN window entries, then the chunk's text as symbols
+    size_t n = 0;                                  // symbols of text (sym[PAR_WIN .. PAR_WIN + n))
+    uint64_t end_bit = 0; bool hit_final = false, ok = false; const char *err = nullptr;
+};
+
+static inline bool par_is_text(const uint16_t *p, const uint16_t *e)
+{
+    for (; p < e; ++p) {
+        const uint16_t s = *p;
+        if (s < 0x8000 && !(s == '\n' || s == '\t' || s == '\r' || (s >= 32 && s < 127))) return false;
+    }
+    return true;
+}
+
+// Decode blocks into c.sym from c.start_bit.  `probe`: stop after `probe_syms` symbols or one block, and insist on printable literals
+// (the search for a block head); returns false if anything is wrong.
+static bool par_decode(Decoder &d, const uint8_t *base, const uint8_t *end, ParChunk &c, bool probe = false, size_t probe_syms = 0)
+{
+    par_seek(d, base, end, c.start_bit);
+    if (c.sym.size() < PAR_WIN + (1u << 16)) c.sym.resize(PAR_WIN + (1u << 16));
+    uint16_t *buf = c.sym.data();
+    uint16_t *out = buf + PAR_WIN, *lim = buf + c.sym.size();
+    auto grow = [&](size_t need) {
+        const size_t at = (size_t)(out - buf);
+        if ((size_t)(lim - out) >= need) return;
+        c.sym.resize(std::max(c.sym.size() + need, c.sym.size() + c.sym.size() / 2));
+        buf = c.sym.data(); out = buf + at; lim = buf + c.sym.size();
+    };
+    int blocks = 0;
+    for (;;) {
+        if (d.state == Decoder::BLOCK_HEAD) {
+            const uint64_t pos = par_bitpos(d, base);
+            if (!probe && pos >= c.stop_bit) { c.end_bit = pos; c.ok = true; break; }
+            if (probe && blocks == 1) { c.end_bit = pos; c.ok = true; break; }
+            if (!d.read_block_head()) { c.err = d.err; return false; }
+            ++blocks;
+            continue;
+        }
+        if (d.state == Decoder::STORED) {
+            size_t left = d.stored_left;
+            if (left > (size_t)(d.in_end - d.in)) { c.err = "truncated stored block"; return false; }
+            grow(left + 8);
+            for (size_t i = 0; i < left; ++i) out[i] = d.in[i];
+            out += left; d.in += left; d.stored_left = 0;
+            if (d.last_block) { c.end_bit = par_bitpos(d, base); c.hit_final = true; c.ok = true; break; }
+            d.state = Decoder::BLOCK_HEAD;
+            continue;
+        }
+        if (d.state != Decoder::CODES) { c.err = d.err ? d.err : "unexpected decoder state"; return false; }
+        // ---- the symbols of one block (inflate_fast.h's loop, 16-bit stores) ----
+        bool eob = false;
+        while (!eob) {
+            if ((size_t)(lim - out) < 1200) grow(1u << 20);             // (strictly more than the inner loop's margin: it must make progress)
+            if (probe && (size_t)(out - (buf + PAR_WIN)) >= probe_syms) {
+                if (!par_is_text(buf + PAR_WIN, out)) { c.err = "not text"; return false; }
+                c.end_bit = par_bitpos(d, base); c.ok = true; c.n = (size_t)(out - (buf + PAR_WIN)); return true;
+            }
+            uint16_t *const stop = lim - 600;
+            while (out < stop) {
+                const bool full = d.refill();
+                uint32_t e = d.ll[d.peek(LL_BITS)];
+                if (e & F_SUB) { const int r = e & 0x1F, sb = (e >> 8) & 0x1F; d.drop(r); e = d.ll[(e >> 16) + d.peek(sb)]; }
+                if (!full) {
+                    if (d.bitcnt < (int)(e & 0x1F)) { c.err = "truncated deflate stream"; return false; }
+                    if (e & F_LIT) { d.drop(e & 0x1F); *out++ = (uint16_t)((e >> 16) & 0xFF); continue; }
+                } else if (e & F_LIT) {
+                    d.drop(e & 0x1F); *out++ = (uint16_t)((e >> 16) & 0xFF);
+                    e = d.ll[d.peek(LL_BITS)];
+                    if (e & F_SUB) { const int r = e & 0x1F, sb = (e >> 8) & 0x1F; d.drop(r); e = d.ll[(e >> 16) + d.peek(sb)]; }
+                    if (e & F_LIT) {
+                        d.drop(e & 0x1F); *out++ = (uint16_t)((e >> 16) & 0xFF);
+                        e = d.ll[d.peek(LL_BITS)];
+                        if (e & F_SUB) { const int r = e & 0x1F, sb = (e >> 8) & 0x1F; d.drop(r); e = d.ll[(e >> 16) + d.peek(sb)]; }
+                        if (e & F_LIT) { d.drop(e & 0x1F); *out++ = (uint16_t)((e >> 16) & 0xFF); continue; }
+                    }
+                    d.refill();
+                }
+                d.drop(e & 0x1F);
+                if (e & F_EOB) {
+                    if (d.bitcnt < 0) { c.err = "truncated deflate stream"; return false; }
+                    eob = true; break;
+                }
+                if ((e >> 16) == 0) { c.err = "invalid literal/length symbol"; return false; }
+                const int xb = (e >> 8) & 0x1F;
+                const uint32_t len = (e >> 16) + d.peek(xb); d.drop(xb);
+                if (d.bitcnt < 32) d.refill();
+                uint32_t dc = d.dd[d.peek(D_BITS)];
+                if (dc & F_SUB) { const int r = dc & 0x1F, sb = (dc >> 8) & 0x1F; d.drop(r); dc = d.dd[(dc >> 16) + d.peek(sb)]; }
+                if ((dc >> 16) == 0) { c.err = "invalid distance symbol"; return false; }
+                d.drop(dc & 0x1F);
+                const int dxb = (dc >> 8) & 0x1F;
+                const uint32_t dist = (dc >> 16) + d.peek(dxb); d.drop(dxb);
+                if (d.bitcnt < 0) { c.err = "truncated deflate stream"; return false; }
+                const uint16_t *src = out - dist;                       // (dist <= 32768 = the window in front of the output: always inside the buffer)
+                uint16_t *dst = out;
+                out += len;
+                if (dist >= 4) { do { memcpy(dst, src, 8); dst += 4; src += 4; } while (dst < out); }
+                else { do { *dst++ = *src++; } while (dst < out); }
+            }
+        }
+        if (probe && !par_is_text(buf + PAR_WIN, out)) { c.err = "not text"; return false; }     // a block head found by search must give text
+        if (d.last_block) { c.end_bit = par_bitpos(d, base); c.hit_final = true; c.ok = true; break; }
+        d.state = Decoder::BLOCK_HEAD;
+    }
+    c.n = (size_t)(out - (buf + PAR_WIN));
+    return true;
+}
+
+// The first bit offset in [from, to) at which a dynamic block head stands the tests of step 1, or ~0.
+static uint64_t par_find_block(const uint8_t *base, const uint8_t *end, uint64_t from, uint64_t to, Decoder &d, ParChunk &scratch)
+{
+    const uint64_t total_bits = (uint64_t)(end - base) * 8;
+    if (to > total_bits - 64 * 8) to = total_bits > 64 * 8 ? total_bits - 64 * 8 : 0;       // (the quick test reads 16 bytes ahead)
+    for (uint64_t bit = from; bit < to; ++bit) {
+        const uint8_t *p = base + (bit >> 3);
+        const int sh = (int)(bit & 7);
+        uint64_t w = load64(p) >> sh;                                   // >= 57 bits
+        // BFINAL (either), BTYPE = 2 (bits 1-2 = 0b10, LSB first: bit1 = 0, bit2 = 1), HLIT <= 29, HDIST <= 29
+        if (((w >> 1) & 3) != 2) continue;
+        const uint32_t hlit = (uint32_t)(w >> 3) & 31, hdist = (uint32_t)(w >> 8) & 31, hclen = (uint32_t)(w >> 13) & 15;
+        if (hlit > 29 || hdist > 29) continue;
+        // the code-length code: (hclen + 4) x 3 bits, must be complete
+        const int nc = (int)hclen + 4;
+        w >>= 17;                                                       // 40+ bits left: 13 lengths; the rest from a second load
+        int count[8] = {0};
+        uint64_t w2 = load64(p + 7) >> sh;                              // bits 56.. of the stream at this offset
+        for (int i = 0; i < nc; ++i) {
+            uint32_t l;
+            if (i < 13) { l = (uint32_t)(w & 7); w >>= 3; }
+            else { const int off = 17 + 3 * i - 56; l = (uint32_t)(w2 >> off) & 7; }
+            count[l]++;                                             // (the order the lengths are stored in does not matter to completeness)
+        }
+        int left = 1, used = 0;
+        bool bad = false;
+        for (int l = 1; l <= 7; ++l) { left <<= 1; left -= count[l]; used += count[l]; if (left < 0) { bad = true; break; } }
+        if (bad || (left > 0 && used != 1)) continue;
+        // the full tests: both codes complete, a first stretch of printable text
+        scratch.start_bit = bit; scratch.ok = false; scratch.err = nullptr; scratch.hit_final = false;
+        if (par_decode(d, base, end, scratch, true, 4096) && scratch.ok) return bit;
+    }
+    return ~0ull;
+}
+
+// sym -> bytes with the chunk's window (win[0 .. PAR_WIN), of which the last `avail` are real); false if a marker points before them
+static bool par_translate(const uint16_t *sym, size_t n, const uint8_t *win, uint32_t avail, uint8_t *dst)
+{
+    bool ok = true;
+    const uint32_t first = PAR_WIN - avail;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t s = sym[i];
+        if (s < 0x8000) dst[i] = (uint8_t)s;
+        else { const uint32_t k = s & 0x7FFF; if (k < first) ok = false; dst[i] = win[k]; }
+    }
+    return ok;
+}
+
+}  // namespace shinf

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdlib>
 #include "route.h"
+#include "inflate_par.h"
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -121,6 +122,8 @@ struct sh_reader {
     std::mutex mu; std::condition_variable cv_put, cv_get, cv_free;
     std::deque<Slab> queue; std::vector<char *> free_bufs; std::vector<char *> all_bufs; bool stop = false;
     size_t slab_bytes = 16u << 20, pad_bytes = 1u << 20, depth = 3;
+    std::atomic<int64_t> par_accepted{0}; // chunks accepted from a searched block head (sh_reader_par_chunks)
+    size_t par_chunk = 1u << 20;         // compressed bytes per thread and round of the parallel gzip decoder (inflate_par.h)
     int mode = 0;                        // 0 plain, 1 gzip, 2 BGZF
     std::unique_ptr<ParPool> pool, pool_bgzf;   // parser / CRC workers; member-parallel BGZF decoding (the producer's)
     // consumer
@@ -243,6 +246,152 @@ static void produce_gzip(sh_reader *r)
     }
 }
 
+// One gzip member on several threads (inflate_par.h): rounds of `W` chunks of compressed bytes -- find block heads, decode to symbols with
+// markers, accept the chain, resolve the windows in order, translate into slab buffers in parallel.  Members of a multi-member file follow
+// one another through the same rounds.
+static void produce_gzip_parallel(sh_reader *r)
+{
+    using namespace shinf;
+    const uint8_t *const base = r->map, *const end = r->map + r->map_len;
+    const size_t PAD = r->pad_bytes, SB = r->slab_bytes, CH = r->par_chunk;
+    ParPool *pool = r->pool_bgzf.get();
+    const int W = (int)pool->th.size() + 1;
+    std::vector<ParChunk> ch((size_t)W), scratch((size_t)W);
+    std::vector<Decoder> dec((size_t)W);
+    std::vector<char> tail;                                          // the last PAD bytes of text handed on (slab pads)
+    std::vector<uint8_t> wins((size_t)W * PAR_WIN);
+    std::vector<uint32_t> avail((size_t)W);
+    Decoder hd; hd.begin(base, end);
+    uint64_t member_out = 0, pos_bit = 0;
+    bool in_member = false;
+    auto fail = [&](const std::string &msg) { Slab sl; sl.err = "gzip: " + msg; sl.last = true; put_slab(r, std::move(sl)); };
+    for (;;) {
+        if (!in_member) {
+            hd.state = Decoder::HEADER;
+            if (!hd.read_gzip_header()) {
+                if (hd.state == Decoder::DONE) { Slab sl; sl.last = true; put_slab(r, std::move(sl)); }
+                else fail(hd.err ? hd.err : "error");
+                return;
+            }
+            in_member = true; member_out = 0; pos_bit = (uint64_t)(hd.in - base) * 8;
+        }
+        // ---- plan: chunk 0 from the exact position, chunk j from the first block head found at or after byte (pos + j CH) -------------------
+        const size_t pos_byte = (size_t)(pos_bit >> 3);
+        int nplan = 1;
+        while (nplan < W && pos_byte + (size_t)nplan * CH + 65536 < (size_t)(end - base)) ++nplan;
+        std::vector<uint64_t> starts((size_t)nplan, ~0ull);
+        starts[0] = pos_bit;
+        pool->run(nplan - 1, 1, [&](int64_t i) {
+            const int j = (int)i + 1;
+            const uint64_t from = (uint64_t)(pos_byte + (size_t)j * CH) * 8, to = (uint64_t)(pos_byte + (size_t)(j + 1) * CH) * 8;
+            ParChunk &sc = scratch[(size_t)j];
+            if (sc.sym.size() < PAR_WIN + 65536) sc.sym.resize(PAR_WIN + 65536);
+            for (uint32_t k = 0; k < PAR_WIN; ++k) sc.sym[k] = (uint16_t)(0x8000u | k);
+            starts[(size_t)j] = par_find_block(base, end, from, to, dec[(size_t)j], sc);
+        });
+        std::vector<int> plan;                                       // chunks that have a start
+        for (int j = 0; j < nplan; ++j) if (starts[(size_t)j] != ~0ull) plan.push_back(j);
+        const int np = (int)plan.size();
+        // ---- decode ----------------------------------------------------------------------------------------------------------------------
+        const uint32_t avail0 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(PAR_WIN, member_out), tail.size());
+        pool->run(np, 1, [&](int64_t i) {
+            ParChunk &c = ch[(size_t)i];
+            c.start_bit = starts[(size_t)plan[(size_t)i]];
+            c.stop_bit = i + 1 < np ? starts[(size_t)plan[(size_t)i + 1]] : ~0ull;
+            if (i + 1 == np && nplan == W) c.stop_bit = (uint64_t)(pos_byte + (size_t)W * CH) * 8;   // a full round: the last chunk ends with its share (else: the member's end)
+            c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0; c.exact = i == 0;
+            if (c.sym.size() < PAR_WIN + 65536) c.sym.resize(PAR_WIN + 65536);
+            for (uint32_t k = 0; k < PAR_WIN; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
+            if (i == 0) for (uint32_t k = 0; k < avail0; ++k) c.sym[PAR_WIN - 1 - k] = (uint8_t)tail[tail.size() - 1 - k];
+            par_decode(dec[(size_t)i], base, end, c);
+        });
+        // ---- accept the chain -------------------------------------------------------------------------------------------------------------
+        if (!ch[0].ok) { fail(ch[0].err ? ch[0].err : "error"); return; }
+        int nv = 1;
+        while (nv < np && !ch[(size_t)nv - 1].hit_final && ch[(size_t)nv].ok && ch[(size_t)nv - 1].end_bit == ch[(size_t)nv].start_bit) ++nv;
+        const ParChunk &lastc = ch[(size_t)nv - 1];
+        r->par_accepted += nv - 1;
+        // ---- windows, in order ------------------------------------------------------------------------------------------------------------
+        avail[0] = avail0;
+        for (uint32_t k = 0; k < PAR_WIN; ++k) wins[k] = (uint8_t)(ch[0].sym[k] & 0xFF);
+        bool refs_ok = true;
+        for (int j = 0; j + 1 < nv; ++j) {
+            const ParChunk &c = ch[(size_t)j];
+            const uint8_t *w = wins.data() + (size_t)j * PAR_WIN; uint8_t *wn = wins.data() + (size_t)(j + 1) * PAR_WIN;
+            if (c.n >= PAR_WIN) refs_ok &= par_translate(c.sym.data() + PAR_WIN + c.n - PAR_WIN, PAR_WIN, w, avail[(size_t)j], wn);
+            else {
+                memcpy(wn, w + c.n, PAR_WIN - c.n);
+                refs_ok &= par_translate(c.sym.data() + PAR_WIN, c.n, w, avail[(size_t)j], wn + PAR_WIN - c.n);
+            }
+            avail[(size_t)j + 1] = (uint32_t)std::min<uint64_t>(PAR_WIN, (uint64_t)avail[(size_t)j] + c.n);
+        }
+        // ---- the member's trailer, if this round reached it ---------------------------------------------------------------------------------
+        size_t total = 0;
+        std::vector<size_t> first((size_t)nv + 1, 0);
+        for (int j = 0; j < nv; ++j) { first[(size_t)j] = total; total += ch[(size_t)j].n; }
+        first[(size_t)nv] = total;
+        std::string err;
+        if (!refs_ok) err = "gzip: distance too far back";
+        member_out += total;
+        bool last = false, member_ends = false; uint32_t crc = 0;
+        if (err.empty() && lastc.hit_final) {
+            // CRC-32 (checked by the consumer over whole slabs), ISIZE; then the next member's header, or the end
+            const uint8_t *t = base + ((lastc.end_bit + 7) >> 3);
+            if (end - t < 8) err = "gzip: truncated gzip trailer";
+            else {
+                crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                if (isize != (uint32_t)member_out) err = "gzip: gzip length check failed";
+                member_ends = true;
+                hd.in = t + 8; hd.bitbuf = 0; hd.bitcnt = 0; in_member = false;
+                // peek: is there another member?  (zero padding after the last one is accepted, anything else is an error -- read_gzip_header)
+                Decoder pk = hd; pk.state = Decoder::HEADER;
+                if (!pk.read_gzip_header()) { if (pk.state == Decoder::DONE) last = true; else if (err.empty()) err = std::string("gzip: ") + (pk.err ? pk.err : "error"); }
+            }
+        } else if (err.empty()) pos_bit = lastc.end_bit;
+        // ---- slabs, one at a time (put_slab's depth bounds the buffers in flight), each translated by all threads ---------------------------
+        const size_t nslab = std::max<size_t>(1, (total + SB - 1) / SB);
+        const size_t PIECE = 1u << 18;
+        struct Piece { int j; size_t off, cnt; uint8_t *dst; };
+        std::vector<Piece> pieces;
+        int jc = 0;                                                  // the chunk the next slab starts in
+        for (size_t k = 0; k < nslab; ++k) {
+            char *buf = get_buf(r);
+            if (!buf) return;
+            Slab sl; sl.mem = buf; sl.data = buf + PAD; sl.len = std::min(SB, total - k * SB);
+            const size_t g0 = k * SB, g1 = g0 + sl.len;
+            pieces.clear();
+            while (jc < nv && first[(size_t)jc + 1] <= g0) ++jc;
+            for (int j = jc; j < nv && first[(size_t)j] < g1; ++j) {
+                size_t off = g0 > first[(size_t)j] ? g0 - first[(size_t)j] : 0;
+                const size_t off_end = std::min(ch[(size_t)j].n, g1 - first[(size_t)j]);
+                while (off < off_end) {
+                    const size_t cnt = std::min(PIECE, off_end - off);
+                    pieces.push_back(Piece{j, off, cnt, (uint8_t *)buf + PAD + (first[(size_t)j] + off - g0)});
+                    off += cnt;
+                }
+            }
+            std::atomic<int> bad{0};
+            pool->run((int64_t)pieces.size(), 1, [&](int64_t i) {
+                const Piece &pc = pieces[(size_t)i];
+                if (!par_translate(ch[(size_t)pc.j].sym.data() + PAR_WIN + pc.off, pc.cnt, wins.data() + (size_t)pc.j * PAR_WIN, avail[(size_t)pc.j], pc.dst)) ++bad;
+            });
+            if (bad && err.empty()) { err = "gzip: distance too far back"; member_ends = false; }
+            memcpy(sl.mem + PAD - tail.size(), tail.data(), tail.size());
+            sl.pad = tail.size();
+            keep_tail(tail, PAD, sl.data, sl.len);
+            const bool fin_slab = k + 1 == nslab || bad;
+            if (fin_slab) {
+                if (member_ends) sl.ends.push_back(MemberEndAt{sl.len, crc});
+                sl.err = err; sl.last = last || !err.empty();
+            }
+            const bool fin = sl.last;
+            if (!put_slab(r, std::move(sl))) return;
+            if (fin) return;
+        }
+    }
+}
+
 // BGZF member at p: total compressed size, or 0 if p is not a BGZF member header
 static size_t bgzf_member(const uint8_t *p, const uint8_t *end)
 {
@@ -355,8 +504,12 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
     if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
-    r->producer = std::thread([r] {
-        if (r->mode == 0) produce_plain(r); else if (r->mode == 1) produce_gzip(r); else produce_bgzf(r);
+    // one gzip member on several threads (inflate_par.h) unless SEERHIP_READER=serial, or there is nothing to share out
+    if (const char *cb = sh_route("reader_chunk")) r->par_chunk = std::max<size_t>(4096, (size_t)std::atoll(cb));
+    const bool par = r->mode == 1 && nt >= 3 && !(sel && std::string(sel) == "serial") && r->map_len >= 2 * r->par_chunk;
+    if (par) r->pool_bgzf.reset(new ParPool(std::max(2, std::min(24, nt * 3 / 4)) - 1));
+    r->producer = std::thread([r, par] {
+        if (r->mode == 0) produce_plain(r); else if (r->mode == 1) { if (par) produce_gzip_parallel(r); else produce_gzip(r); } else produce_bgzf(r);
     });
     return r;
 }
@@ -519,6 +672,7 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
 }
 
 int64_t sh_reader_names_needed(sh_reader *r) { return r ? r->names_needed : 0; }
+int64_t sh_reader_par_chunks(sh_reader *r) { return r ? r->par_accepted.load() : 0; }
 int64_t sh_reader_buffered(sh_reader *r)
 {
     if (!r) return 0;

@@ -17,6 +17,7 @@
 //   afcompact=M      [1]  0: never compact AF / prefilter-rejected rows before the kernels, 2: always
 //   complement=0     [1]  LMM: rows with more than N/2 carriers stored as given
 //   reader_slab=B, reader_pad=B   reader: bytes per decoded slab / carried over between slabs
+//   reader_chunk=B   [1 MB] compressed bytes per thread and round of the parallel gzip decoder (small values: many chunks in a small file)
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +26,7 @@
 static inline const char *const *sh_route_keys()
 {
     static const char *const keys[] = {"chord", "chord_n32", "chord_enter", "bitdot", "first_bordered", "pk", "warm", "fin_rounds", "ll_first", "newton",
-                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", nullptr};
+                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", "reader_chunk", nullptr};
     return keys;
 }
 // the value of `key` in SEERHIP_ROUTE, or nullptr (the returned string lives until the calling thread's next sh_route)

@@ -162,7 +162,8 @@ def _kmer_text(samples, nlines, seed):
 
 def test_every_container_gives_the_same_blocks(tmp_path, monkeypatch):
     """Plain text, single-member gzip (levels 1/6/9, stored blocks), concatenated members, BGZF, and zlib's own gzread as the yardstick:
-    the in-tree inflate (csrc/inflate_fast.h) and the member-parallel BGZF path hand the parser the same bytes."""
+    the in-tree inflate (csrc/inflate_fast.h) on one thread (SEERHIP_READER=serial) and on several (csrc/inflate_par.h; by default only for
+    files of two chunks or more, so the chunk is made tiny here) and the member-parallel BGZF path hand the parser the same bytes."""
     import zlib
     samples = ["iso%03d" % i for i in range(150)]
     text = _kmer_text(samples, 1200, 5)
@@ -177,19 +178,82 @@ def test_every_container_gives_the_same_blocks(tmp_path, monkeypatch):
     for name, blob in files.items():
         path = str(tmp_path / name)
         open(path, "wb").write(blob)
-        for sel in ("", "zlib"):
+        for sel in ("", "zlib", "serial", "par4096", "par20000"):
             if sel:
                 if name == "plain.txt":
                     continue
-                monkeypatch.setenv("SEERHIP_READER", sel)
+                if sel.startswith("par"):                                   # one member on several threads (csrc/inflate_par.h), tiny chunks
+                    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=50000,reader_chunk=" + sel[3:])
+                else:
+                    monkeypatch.setenv("SEERHIP_READER", sel)
             got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples, 97)]
             monkeypatch.delenv("SEERHIP_READER", raising=False)
+            monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=50000")
             names = sum((g[0] for g in got), [])
             bits = np.concatenate([g[1] for g in got]); counts = np.concatenate([g[2] for g in got])
             if want is None:
                 want = (names, bits, counts)
                 assert len(names) == 1200
             assert names == want[0] and np.array_equal(bits, want[1]) and np.array_equal(counts, want[2]), (name, sel)
+
+
+def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
+    """csrc/inflate_par.h (block heads searched for, chunks decoded to symbols with window markers, the chain accepted in order): the rows
+    of the one-thread decoder, for compression levels 1/6/9, several members, a member with stored and fixed-Huffman blocks between dynamic
+    ones, chunk sizes below and above a block, 3 and 8 reader threads; the several-thread path did run (sh_reader_par_chunks); a flipped
+    bit anywhere is an error, never a silently different block.  Reference: one gzip.open stream, pyseer/input.py:271-276."""
+    import zlib, pytest
+    samples = ["iso%03d" % i for i in range(150)]
+    text = _kmer_text(samples, 7000, 6)
+    cut = [len(text) // 5, 2 * len(text) // 5, 3 * len(text) // 5]
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    mixed = co.compress(text[:cut[0]]) + co.flush(zlib.Z_FULL_FLUSH)
+    co2 = zlib.compressobj(0, zlib.DEFLATED, -15)                      # the same member continued by hand: stored, fixed, dynamic again
+    files = {"l1.gz": gzip.compress(text, 1), "l6.gz": gzip.compress(text, 6), "l9.gz": gzip.compress(text, 9),
+             "multi.gz": gzip.compress(text[:cut[1]], 6) + gzip.compress(b"", 6) + gzip.compress(text[cut[1]:], 9)}
+    def raw(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, last=False):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        out = c.compress(data)
+        return out + (c.flush() if last else c.flush(zlib.Z_FULL_FLUSH))
+    body = (raw(text[:cut[0]], 6) + raw(text[cut[0]:cut[0] + 70000], 0) + raw(text[cut[0] + 70000:cut[1]], 6, zlib.Z_FIXED)
+            + raw(text[cut[1]:], 6, last=True))
+    files["mixed.gz"] = (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff" + body
+                         + (zlib.crc32(text) & 0xFFFFFFFF).to_bytes(4, "little") + (len(text) & 0xFFFFFFFF).to_bytes(4, "little"))
+    assert gzip.decompress(files["mixed.gz"]) == text
+    del co, co2, mixed
+    def read(path, route, sel=None, threads=None):
+        monkeypatch.setenv("SEERHIP_ROUTE", route)
+        for k, v in (("SEERHIP_READER", sel), ("SEERHIP_READER_THREADS", threads)):
+            if v is None: monkeypatch.delenv(k, raising=False)
+            else: monkeypatch.setenv(k, v)
+        rd = NativeKmerReader(path, samples, 1000)
+        names, bits, counts, pc = [], [], [], 0
+        for n, b, c in rd:
+            names += n; bits.append(b.copy()); counts.append(c.copy())
+            if rd._h: pc = int(rd._lib.sh_reader_par_chunks(rd._h))
+        return names, np.concatenate(bits), np.concatenate(counts), pc
+    seen_small = False
+    for name, blob in files.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        want = read(path, "reader_slab=300000", "serial")
+        assert len(want[0]) == 7000 and want[3] == 0
+        for chunk in (8192, 40000):
+            for threads in ("3", "8"):
+                got = read(path, "reader_slab=300000,reader_chunk=%d" % chunk, None, threads)
+                assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (name, chunk, threads)
+                assert got[3] > 0 or chunk == 8192, (name, chunk, threads)      # (a chunk smaller than a block may hold no block head)
+                seen_small = seen_small or (chunk == 8192 and got[3] > 0)
+    assert seen_small
+    # corruption: a flipped bit early, in the middle, near the end, in the CRC; truncation
+    good = files["l6.gz"]
+    bad = [good[:k] + bytes([good[k] ^ 0x10]) + good[k + 1:] for k in (len(good) // 7, len(good) // 2, len(good) - 3000, len(good) - 6)]
+    bad.append(good[:len(good) - 40])
+    for k, blob in enumerate(bad):
+        path = str(tmp_path / ("bad%d.gz" % k))
+        open(path, "wb").write(blob)
+        with pytest.raises(IOError):
+            read(path, "reader_slab=300000,reader_chunk=8192", None, "8")
 
 
 def test_corrupt_gzip_is_reported(tmp_path):

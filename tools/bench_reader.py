@@ -1,5 +1,6 @@
 """Throughput of the native k-mer reader (csrc/reader.cpp) on a synthetic k-mer file, N samples x V k-mers, by container:
-plain text, gzip through zlib's gzread (SEERHIP_READER=zlib, the round-1 path), gzip through the in-tree inflate, BGZF (member-parallel).
+plain text, gzip through zlib's gzread (SEERHIP_READER=zlib, the round-1 path), gzip through the in-tree inflate on one thread
+(SEERHIP_READER=serial) and on several (the default, csrc/inflate_par.h), BGZF (member-parallel).
 No GPU involved; run it on the GPU host to see what feeds the engine there.  Prints one JSON line."""
 import gzip, json, os, struct, sys, time, zlib
 import numpy as np
@@ -34,7 +35,7 @@ with open(d + "/k.bgzf.gz", "wb") as f:
 gen = time.time() - t0
 res = {"n_samples": N, "kmers": V, "text_MB": len(text) / 1e6, "gz_MB": os.path.getsize(d + "/k.gz") / 1e6, "cores": os.cpu_count(), "generate_s": gen}
 want = None
-for tag, path, env in (("plain", "k.txt", None), ("gzip_zlib", "k.gz", "zlib"), ("gzip_fast", "k.gz", None), ("bgzf", "k.bgzf.gz", None)):
+for tag, path, env in (("plain", "k.txt", None), ("gzip_zlib", "k.gz", "zlib"), ("gzip_fast", "k.gz", "serial"), ("gzip_par", "k.gz", None), ("bgzf", "k.bgzf.gz", None)):
     if env: os.environ["SEERHIP_READER"] = env
     else: os.environ.pop("SEERHIP_READER", None)
     best = 0.0
