@@ -17,6 +17,7 @@
 // (tests/test_reader_cpu.py decodes the same files through python's gzip and through SEERHIP_READER=serial).
 #pragma once
 #include <vector>
+#include <emmintrin.h>
 #include "inflate_fast.h"
 
 namespace shinf {
@@ -177,15 +178,26 @@ static uint64_t par_find_block(const uint8_t *base, const uint8_t *end, uint64_t
     return ~0ull;
 }
 
-// sym -> bytes with the chunk's window (win[0 .. PAR_WIN), of which the last `avail` are real); false if a marker points before them
+// sym -> bytes with the chunk's window (win[0 .. PAR_WIN), of which the last `avail` are real); false if a marker points before them.
+// Sixteen symbols at a time while none of them is a marker (SSE2: or, movemask of the top bits, packus); markers one by one.
 static bool par_translate(const uint16_t *sym, size_t n, const uint8_t *win, uint32_t avail, uint8_t *dst)
 {
     bool ok = true;
     const uint32_t first = PAR_WIN - avail;
-    for (size_t i = 0; i < n; ++i) {
-        const uint16_t s = sym[i];
-        if (s < 0x8000) dst[i] = (uint8_t)s;
-        else { const uint32_t k = s & 0x7FFF; if (k < first) ok = false; dst[i] = win[k]; }
+    size_t i = 0;
+    while (i < n) {
+        while (i + 16 <= n) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(sym + i)), b = _mm_loadu_si128((const __m128i *)(sym + i + 8));
+            if (_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA) break;                  // a marker among the sixteen
+            _mm_storeu_si128((__m128i *)(dst + i), _mm_packus_epi16(a, b));
+            i += 16;
+        }
+        const size_t e = std::min(n, i + 16);
+        for (; i < e; ++i) {
+            const uint16_t s = sym[i];
+            if (s < 0x8000) dst[i] = (uint8_t)s;
+            else { const uint32_t k = s & 0x7FFF; if (k < first) ok = false; dst[i] = win[k]; }
+        }
     }
     return ok;
 }

@@ -106,6 +106,7 @@ struct Slab {
     char *mem = nullptr;                                        // owned buffer to recycle (nullptr: a window of the mapping)
     bool last = false; std::string err;
     std::vector<MemberEndAt> ends;                              // gzip members that end inside this slab: offset, CRC-32 of the trailer
+    std::vector<uint32_t> nl; bool indexed = false;             // offsets of the newlines in data[0 .. len) (index_newlines, on first use)
 };
 
 struct sh_reader {
@@ -123,7 +124,8 @@ struct sh_reader {
     std::deque<Slab> queue; std::vector<char *> free_bufs; std::vector<char *> all_bufs; bool stop = false;
     size_t slab_bytes = 16u << 20, pad_bytes = 1u << 20, depth = 3;
     std::atomic<int64_t> par_accepted{0}; // chunks accepted from a searched block head (sh_reader_par_chunks)
-    size_t par_chunk = 1u << 20;         // compressed bytes per thread and round of the parallel gzip decoder (inflate_par.h)
+    size_t par_chunk = 1u << 20;         // most compressed bytes per region of the parallel gzip decoder (inflate_par.h)
+    int par_workers = 0;                 //   its decoding threads
     int mode = 0;                        // 0 plain, 1 gzip, 2 BGZF
     std::unique_ptr<ParPool> pool, pool_bgzf;   // parser / CRC workers; member-parallel BGZF decoding (the producer's)
     // consumer
@@ -246,148 +248,156 @@ static void produce_gzip(sh_reader *r)
     }
 }
 
-// One gzip member on several threads (inflate_par.h): rounds of `W` chunks of compressed bytes -- find block heads, decode to symbols with
-// markers, accept the chain, resolve the windows in order, translate into slab buffers in parallel.  Members of a multi-member file follow
-// one another through the same rounds.
+// One gzip member on several threads (inflate_par.h), as a continuous pipeline.  The compressed bytes are cut into regions on a grid that is
+// fixed as it is handed out; `W` decoding threads take regions in order: find the first block head in the region, decode from it up to the
+// first block head at or after the region's end, into 16-bit symbols with window markers.  The producer thread is the ACCEPTOR: it walks the
+// regions in order knowing the exact bit position the stream has reached; a region whose decode started on that very bit is accepted, any
+// other (no head found, a false head, a member boundary inside) is decoded again by the acceptor itself from the exact position -- so a wrong
+// guess costs time, never bytes.  Accepted symbols are translated against the 32 KB of text before them (kept by the acceptor) into slab
+// buffers by a few helper threads and handed to the parser; decoding runs ahead by at most 2 W regions.
 static void produce_gzip_parallel(sh_reader *r)
 {
     using namespace shinf;
     const uint8_t *const base = r->map, *const end = r->map + r->map_len;
-    const size_t PAD = r->pad_bytes, SB = r->slab_bytes, CH = r->par_chunk;
-    ParPool *pool = r->pool_bgzf.get();
-    const int W = (int)pool->th.size() + 1;
-    std::vector<ParChunk> ch((size_t)W), scratch((size_t)W);
-    std::vector<Decoder> dec((size_t)W);
+    const size_t LEN = r->map_len, PAD = r->pad_bytes, SB = r->slab_bytes, CHMAX = r->par_chunk, CHMIN = std::min<size_t>(65536, r->par_chunk);
+    const int W = std::max(1, r->par_workers), INFL = 2 * W;
+    ParPool *tpool = r->pool_bgzf.get();                              // the acceptor's translation helpers
+    struct Task { ParChunk c; uint64_t from_bit = 0, to_bit = 0; int64_t id = -1; bool done = false; };
+    std::vector<Task> slots((size_t)INFL);
+    std::mutex mu; std::condition_variable cv_w, cv_a;
+    int64_t next_id = 0, consumed = 0;                                // regions handed out / regions the acceptor is through with
+    size_t next_from = 0, ch_cur = std::min<size_t>(CHMAX, std::max<size_t>(CHMIN, 1u << 18));
+    bool exhausted = LEN == 0, quit = false;
+    std::vector<std::thread> workers;
+    for (int w = 0; w < W; ++w) workers.emplace_back([&] {
+        std::unique_ptr<Decoder> dec(new Decoder);
+        for (;;) {
+            Task *t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_w.wait(lk, [&] { return quit || exhausted || next_id < consumed + INFL; });
+                if (quit || exhausted) return;
+                t = &slots[(size_t)(next_id % INFL)];
+                t->id = next_id++; t->done = false;
+                size_t to = next_from + ch_cur;
+                if (to >= LEN || LEN - to < ch_cur / 2 + 4096) { to = LEN; exhausted = true; }
+                t->from_bit = (uint64_t)next_from * 8; t->to_bit = to == LEN ? ~0ull : (uint64_t)to * 8;
+                next_from = to;
+            }
+            ParChunk &c = t->c;
+            if (c.sym.size() < PAR_WIN + 65536) c.sym.resize(PAR_WIN + 65536);
+            for (uint32_t k = 0; k < PAR_WIN; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
+            c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0; c.exact = false;
+            const uint64_t start = par_find_block(base, end, t->from_bit, t->to_bit == ~0ull ? (uint64_t)LEN * 8 : t->to_bit, *dec, c);
+            c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0;
+            if (start != ~0ull) { c.start_bit = start; c.stop_bit = t->to_bit; par_decode(*dec, base, end, c); }
+            { std::lock_guard<std::mutex> lk(mu); t->done = true; }
+            cv_a.notify_all();
+        }
+    });
+    struct Joiner { std::mutex &mu; bool &quit; std::condition_variable &cv; std::vector<std::thread> &th;
+                    ~Joiner() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); for (auto &t : th) t.join(); } } joiner{mu, quit, cv_w, workers};
+
     std::vector<char> tail;                                          // the last PAD bytes of text handed on (slab pads)
-    std::vector<uint8_t> wins((size_t)W * PAR_WIN);
-    std::vector<uint32_t> avail((size_t)W);
+    std::vector<uint8_t> hist(PAR_WIN, 0), hist2(PAR_WIN, 0);        // the 32 KB of text before the next chunk, right-aligned; `avail` of them real
+    uint32_t avail = 0;
+    Slab cur; size_t fill = 0; bool have = false;                    // the slab being filled
+    auto flush = [&](bool last, const std::string &err) -> bool {    // hands `cur` on (an empty one if there is none and something must be said)
+        if (!have) { char *buf = get_buf(r); if (!buf) return false; cur = Slab(); cur.mem = buf; cur.data = buf + PAD; fill = 0; }
+        have = false;
+        cur.len = fill;
+        memcpy(cur.mem + PAD - tail.size(), tail.data(), tail.size());
+        cur.pad = tail.size();
+        keep_tail(tail, PAD, cur.data, cur.len);
+        cur.err = err; cur.last = last || !err.empty();
+        return put_slab(r, std::move(cur));
+    };
     Decoder hd; hd.begin(base, end);
+    std::unique_ptr<Decoder> redo_dec(new Decoder);
+    ParChunk redo;
     uint64_t member_out = 0, pos_bit = 0;
     bool in_member = false;
-    auto fail = [&](const std::string &msg) { Slab sl; sl.err = "gzip: " + msg; sl.last = true; put_slab(r, std::move(sl)); };
+    int64_t j = 0;                                                   // the region the exact position lies in (or an earlier one, not yet let go)
+    struct Piece { size_t off, cnt; uint8_t *dst; };
+    std::vector<Piece> pieces;
     for (;;) {
         if (!in_member) {
             hd.state = Decoder::HEADER;
             if (!hd.read_gzip_header()) {
-                if (hd.state == Decoder::DONE) { Slab sl; sl.last = true; put_slab(r, std::move(sl)); }
-                else fail(hd.err ? hd.err : "error");
+                if (hd.state == Decoder::DONE) flush(true, std::string());
+                else flush(true, std::string("gzip: ") + (hd.err ? hd.err : "error"));
                 return;
             }
-            in_member = true; member_out = 0; pos_bit = (uint64_t)(hd.in - base) * 8;
+            in_member = true; member_out = 0; avail = 0; pos_bit = (uint64_t)(hd.in - base) * 8;
         }
-        // ---- plan: chunk 0 from the exact position, chunk j from the first block head found at or after byte (pos + j CH) -------------------
-        const size_t pos_byte = (size_t)(pos_bit >> 3);
-        int nplan = 1;
-        while (nplan < W && pos_byte + (size_t)nplan * CH + 65536 < (size_t)(end - base)) ++nplan;
-        std::vector<uint64_t> starts((size_t)nplan, ~0ull);
-        starts[0] = pos_bit;
-        pool->run(nplan - 1, 1, [&](int64_t i) {
-            const int j = (int)i + 1;
-            const uint64_t from = (uint64_t)(pos_byte + (size_t)j * CH) * 8, to = (uint64_t)(pos_byte + (size_t)(j + 1) * CH) * 8;
-            ParChunk &sc = scratch[(size_t)j];
-            if (sc.sym.size() < PAR_WIN + 65536) sc.sym.resize(PAR_WIN + 65536);
-            for (uint32_t k = 0; k < PAR_WIN; ++k) sc.sym[k] = (uint16_t)(0x8000u | k);
-            starts[(size_t)j] = par_find_block(base, end, from, to, dec[(size_t)j], sc);
-        });
-        std::vector<int> plan;                                       // chunks that have a start
-        for (int j = 0; j < nplan; ++j) if (starts[(size_t)j] != ~0ull) plan.push_back(j);
-        const int np = (int)plan.size();
-        // ---- decode ----------------------------------------------------------------------------------------------------------------------
-        const uint32_t avail0 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(PAR_WIN, member_out), tail.size());
-        pool->run(np, 1, [&](int64_t i) {
-            ParChunk &c = ch[(size_t)i];
-            c.start_bit = starts[(size_t)plan[(size_t)i]];
-            c.stop_bit = i + 1 < np ? starts[(size_t)plan[(size_t)i + 1]] : ~0ull;
-            if (i + 1 == np && nplan == W) c.stop_bit = (uint64_t)(pos_byte + (size_t)W * CH) * 8;   // a full round: the last chunk ends with its share (else: the member's end)
-            c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0; c.exact = i == 0;
-            if (c.sym.size() < PAR_WIN + 65536) c.sym.resize(PAR_WIN + 65536);
-            for (uint32_t k = 0; k < PAR_WIN; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
-            if (i == 0) for (uint32_t k = 0; k < avail0; ++k) c.sym[PAR_WIN - 1 - k] = (uint8_t)tail[tail.size() - 1 - k];
-            par_decode(dec[(size_t)i], base, end, c);
-        });
-        // ---- accept the chain -------------------------------------------------------------------------------------------------------------
-        if (!ch[0].ok) { fail(ch[0].err ? ch[0].err : "error"); return; }
-        int nv = 1;
-        while (nv < np && !ch[(size_t)nv - 1].hit_final && ch[(size_t)nv].ok && ch[(size_t)nv - 1].end_bit == ch[(size_t)nv].start_bit) ++nv;
-        const ParChunk &lastc = ch[(size_t)nv - 1];
-        r->par_accepted += nv - 1;
-        // ---- windows, in order ------------------------------------------------------------------------------------------------------------
-        avail[0] = avail0;
-        for (uint32_t k = 0; k < PAR_WIN; ++k) wins[k] = (uint8_t)(ch[0].sym[k] & 0xFF);
+        // ---- the region the position lies in --------------------------------------------------------------------------------------------
+        Task *t = nullptr;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            if (exhausted && j >= next_id) break;                      // (cannot happen: the last region runs to the end of the file)
+            t = &slots[(size_t)(j % INFL)];
+            cv_a.wait(lk, [&] { return t->id == j && t->done; });
+            if (t->to_bit != ~0ull && t->to_bit <= pos_bit) { ++j; consumed = j; lk.unlock(); cv_w.notify_all(); t = nullptr; continue; }
+            break;
+        }
+        if (!t) { flush(true, "gzip: internal error (no region for the position)"); return; }
+        ParChunk *c = &t->c;
+        if (c->ok && c->start_bit == pos_bit) ++r->par_accepted;
+        else {
+            redo.start_bit = pos_bit; redo.stop_bit = t->to_bit;
+            if (redo.sym.size() < PAR_WIN + 65536) redo.sym.resize(PAR_WIN + 65536);
+            for (uint32_t k = 0; k < PAR_WIN; ++k) redo.sym[k] = (uint16_t)(0x8000u | k);
+            redo.ok = false; redo.hit_final = false; redo.err = nullptr; redo.n = 0;
+            par_decode(*redo_dec, base, end, redo);
+            if (!redo.ok) { flush(true, std::string("gzip: ") + (redo.err ? redo.err : "error")); return; }
+            c = &redo;
+        }
+        // ---- its text: the next window first (in order, 32 K symbols), then everything into slabs by the helpers ---------------------------
+        const uint16_t *sym = c->sym.data() + PAR_WIN;
         bool refs_ok = true;
-        for (int j = 0; j + 1 < nv; ++j) {
-            const ParChunk &c = ch[(size_t)j];
-            const uint8_t *w = wins.data() + (size_t)j * PAR_WIN; uint8_t *wn = wins.data() + (size_t)(j + 1) * PAR_WIN;
-            if (c.n >= PAR_WIN) refs_ok &= par_translate(c.sym.data() + PAR_WIN + c.n - PAR_WIN, PAR_WIN, w, avail[(size_t)j], wn);
-            else {
-                memcpy(wn, w + c.n, PAR_WIN - c.n);
-                refs_ok &= par_translate(c.sym.data() + PAR_WIN, c.n, w, avail[(size_t)j], wn + PAR_WIN - c.n);
-            }
-            avail[(size_t)j + 1] = (uint32_t)std::min<uint64_t>(PAR_WIN, (uint64_t)avail[(size_t)j] + c.n);
+        if (c->n >= PAR_WIN) refs_ok &= par_translate(sym + c->n - PAR_WIN, PAR_WIN, hist.data(), avail, hist2.data());
+        else {
+            memcpy(hist2.data(), hist.data() + c->n, PAR_WIN - c->n);
+            refs_ok &= par_translate(sym, c->n, hist.data(), avail, hist2.data() + PAR_WIN - c->n);
         }
-        // ---- the member's trailer, if this round reached it ---------------------------------------------------------------------------------
-        size_t total = 0;
-        std::vector<size_t> first((size_t)nv + 1, 0);
-        for (int j = 0; j < nv; ++j) { first[(size_t)j] = total; total += ch[(size_t)j].n; }
-        first[(size_t)nv] = total;
         std::string err;
-        if (!refs_ok) err = "gzip: distance too far back";
-        member_out += total;
-        bool last = false, member_ends = false; uint32_t crc = 0;
-        if (err.empty() && lastc.hit_final) {
-            // CRC-32 (checked by the consumer over whole slabs), ISIZE; then the next member's header, or the end
-            const uint8_t *t = base + ((lastc.end_bit + 7) >> 3);
-            if (end - t < 8) err = "gzip: truncated gzip trailer";
-            else {
-                crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-                const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-                if (isize != (uint32_t)member_out) err = "gzip: gzip length check failed";
-                member_ends = true;
-                hd.in = t + 8; hd.bitbuf = 0; hd.bitcnt = 0; in_member = false;
-                // peek: is there another member?  (zero padding after the last one is accepted, anything else is an error -- read_gzip_header)
-                Decoder pk = hd; pk.state = Decoder::HEADER;
-                if (!pk.read_gzip_header()) { if (pk.state == Decoder::DONE) last = true; else if (err.empty()) err = std::string("gzip: ") + (pk.err ? pk.err : "error"); }
-            }
-        } else if (err.empty()) pos_bit = lastc.end_bit;
-        // ---- slabs, one at a time (put_slab's depth bounds the buffers in flight), each translated by all threads ---------------------------
-        const size_t nslab = std::max<size_t>(1, (total + SB - 1) / SB);
-        const size_t PIECE = 1u << 18;
-        struct Piece { int j; size_t off, cnt; uint8_t *dst; };
-        std::vector<Piece> pieces;
-        int jc = 0;                                                  // the chunk the next slab starts in
-        for (size_t k = 0; k < nslab; ++k) {
-            char *buf = get_buf(r);
-            if (!buf) return;
-            Slab sl; sl.mem = buf; sl.data = buf + PAD; sl.len = std::min(SB, total - k * SB);
-            const size_t g0 = k * SB, g1 = g0 + sl.len;
+        size_t off = 0;
+        while (off < c->n) {
+            if (!have) { char *buf = get_buf(r); if (!buf) return; cur = Slab(); cur.mem = buf; cur.data = buf + PAD; fill = 0; have = true; }
+            const size_t cnt = std::min(c->n - off, SB - fill);
             pieces.clear();
-            while (jc < nv && first[(size_t)jc + 1] <= g0) ++jc;
-            for (int j = jc; j < nv && first[(size_t)j] < g1; ++j) {
-                size_t off = g0 > first[(size_t)j] ? g0 - first[(size_t)j] : 0;
-                const size_t off_end = std::min(ch[(size_t)j].n, g1 - first[(size_t)j]);
-                while (off < off_end) {
-                    const size_t cnt = std::min(PIECE, off_end - off);
-                    pieces.push_back(Piece{j, off, cnt, (uint8_t *)buf + PAD + (first[(size_t)j] + off - g0)});
-                    off += cnt;
-                }
-            }
+            const size_t PIECE = 1u << 18;
+            for (size_t o = 0; o < cnt; o += PIECE) pieces.push_back(Piece{off + o, std::min(PIECE, cnt - o), (uint8_t *)cur.mem + PAD + fill + o});
             std::atomic<int> bad{0};
-            pool->run((int64_t)pieces.size(), 1, [&](int64_t i) {
+            tpool->run((int64_t)pieces.size(), 1, [&](int64_t i) {
                 const Piece &pc = pieces[(size_t)i];
-                if (!par_translate(ch[(size_t)pc.j].sym.data() + PAR_WIN + pc.off, pc.cnt, wins.data() + (size_t)pc.j * PAR_WIN, avail[(size_t)pc.j], pc.dst)) ++bad;
+                if (!par_translate(sym + pc.off, pc.cnt, hist.data(), avail, pc.dst)) ++bad;
             });
-            if (bad && err.empty()) { err = "gzip: distance too far back"; member_ends = false; }
-            memcpy(sl.mem + PAD - tail.size(), tail.data(), tail.size());
-            sl.pad = tail.size();
-            keep_tail(tail, PAD, sl.data, sl.len);
-            const bool fin_slab = k + 1 == nslab || bad;
-            if (fin_slab) {
-                if (member_ends) sl.ends.push_back(MemberEndAt{sl.len, crc});
-                sl.err = err; sl.last = last || !err.empty();
-            }
-            const bool fin = sl.last;
-            if (!put_slab(r, std::move(sl))) return;
-            if (fin) return;
+            if (bad) refs_ok = false;
+            fill += cnt; off += cnt;
+            if (fill == SB && !refs_ok) break;
+            if (fill == SB) { if (!flush(false, std::string())) return; }
+        }
+        if (!refs_ok) { flush(true, "gzip: distance too far back"); return; }
+        hist.swap(hist2);
+        avail = (uint32_t)std::min<uint64_t>(PAR_WIN, (uint64_t)avail + c->n);
+        member_out += c->n;
+        pos_bit = c->end_bit;
+        if (c->n > 0 && c->end_bit > c->start_bit) {                  // the next regions sized for ~3 MB of text each
+            const double ratio = (double)c->n / ((double)(c->end_bit - c->start_bit) / 8.0);
+            const size_t want = (size_t)std::min<double>((double)CHMAX, std::max<double>((double)CHMIN, 3.0e6 / std::max(1.0, ratio)));
+            std::lock_guard<std::mutex> lk(mu); ch_cur = want;
+        }
+        if (c->hit_final) {
+            // the trailer: CRC-32 (checked by the consumer over whole slabs), ISIZE; then the next member's header, or the end
+            const uint8_t *tr = base + ((c->end_bit + 7) >> 3);
+            if (end - tr < 8) { flush(true, "gzip: truncated gzip trailer"); return; }
+            const uint32_t crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+            const uint32_t isize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+            if (isize != (uint32_t)member_out) { flush(true, "gzip: gzip length check failed"); return; }
+            if (!have) { char *buf = get_buf(r); if (!buf) return; cur = Slab(); cur.mem = buf; cur.data = buf + PAD; fill = 0; have = true; }
+            cur.ends.push_back(MemberEndAt{fill, crc});
+            hd.in = tr + 8; hd.bitbuf = 0; hd.bitcnt = 0; in_member = false;
         }
     }
 }
@@ -505,9 +515,14 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
     if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
     // one gzip member on several threads (inflate_par.h) unless SEERHIP_READER=serial, or there is nothing to share out
-    if (const char *cb = sh_route("reader_chunk")) r->par_chunk = std::max<size_t>(4096, (size_t)std::atoll(cb));
-    const bool par = r->mode == 1 && nt >= 3 && !(sel && std::string(sel) == "serial") && r->map_len >= 2 * r->par_chunk;
-    if (par) r->pool_bgzf.reset(new ParPool(std::max(2, std::min(24, nt * 3 / 4)) - 1));
+    size_t par_min = 1u << 20;
+    if (const char *cb = sh_route("reader_chunk")) { r->par_chunk = std::max<size_t>(4096, (size_t)std::atoll(cb)); par_min = 2 * r->par_chunk; }
+    const bool par = r->mode == 1 && nt >= 3 && !(sel && std::string(sel) == "serial") && r->map_len >= par_min;
+    if (par) {
+        r->par_workers = std::max(2, std::min(32, nt * 2 / 3));
+        if (const char *cw = sh_route("reader_workers")) r->par_workers = std::max(1, std::atoi(cw));
+        r->pool_bgzf.reset(new ParPool(std::max(1, std::min(8, nt / 4))));
+    }
     r->producer = std::thread([r, par] {
         if (r->mode == 0) produce_plain(r); else if (r->mode == 1) { if (par) produce_gzip_parallel(r); else produce_gzip(r); } else produce_bgzf(r);
     });
@@ -541,6 +556,28 @@ static bool next_slab(sh_reader *r, bool *failed)
     if (sl.last) r->eof = true;
     r->held.push_back(std::move(sl));
     return true;
+}
+
+// The newlines of a slab, found by all parser threads at once the first time a call walks into it (one memchr loop over the 150 MB of a
+// 4096-line block at N = 5000 took as long as parsing them on 48 threads: plain text 230 k -> see profiles/r04/bench_reader.json).
+static void index_newlines(sh_reader *r, Slab &s)
+{
+    if (s.indexed) return;
+    s.indexed = true;
+    const size_t PIECE = 1u << 17, np = (s.len + PIECE - 1) / PIECE;
+    if (np <= 1) {
+        for (const char *p = s.data, *e = s.data + s.len; p < e;) { const void *q = memchr(p, '\n', (size_t)(e - p)); if (!q) break; s.nl.push_back((uint32_t)((const char *)q - s.data)); p = (const char *)q + 1; }
+        return;
+    }
+    std::vector<std::vector<uint32_t>> part(np);
+    r->pool->run((int64_t)np, 1, [&](int64_t i) {
+        const char *p = s.data + (size_t)i * PIECE, *e = s.data + std::min(s.len, (size_t)(i + 1) * PIECE);
+        auto &v = part[(size_t)i];
+        while (p < e) { const void *q = memchr(p, '\n', (size_t)(e - p)); if (!q) break; v.push_back((uint32_t)((const char *)q - s.data)); p = (const char *)q + 1; }
+    });
+    size_t tot = 0; for (auto &v : part) tot += v.size();
+    s.nl.reserve(tot);
+    for (auto &v : part) s.nl.insert(s.nl.end(), v.begin(), v.end());
 }
 
 // Parses up to max_variants lines.  bits: max_variants * row_bytes (zeroed here); counts[v] = carriers among the phenotyped
@@ -586,11 +623,17 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
         r->bridge.clear();
         const char *lstart = r->ptr;                                   // start of the line being scanned (may lie in the pad of held[cur])
         const char *scan = r->ptr;
+        size_t cur_indexed = (size_t)-1, nli = 0;                      // the slab `nli` walks, the next entry of its newline index
         while ((int64_t)lines.size() < max_variants) {
-            const Slab &s = r->held[r->cur];
+            Slab &s = r->held[r->cur];
             const char *send = s.data + s.len;
-            const void *nl = scan < send ? memchr(scan, '\n', (size_t)(send - scan)) : nullptr;
-            if (nl) { lines.emplace_back(lstart, (const char *)nl); lstart = scan = (const char *)nl + 1; continue; }
+            if (cur_indexed != r->cur) {
+                index_newlines(r, s);
+                const uint32_t from = scan > s.data ? (uint32_t)(scan - s.data) : 0u;
+                nli = (size_t)(std::lower_bound(s.nl.begin(), s.nl.end(), from) - s.nl.begin());
+                cur_indexed = r->cur;
+            }
+            if (nli < s.nl.size()) { const char *nl = s.data + s.nl[nli++]; lines.emplace_back(lstart, nl); lstart = scan = nl + 1; continue; }
             // the slab is exhausted with `part` bytes of an unfinished line
             const size_t part = (size_t)(send - lstart);
             if (r->cur + 1 >= r->held.size()) {
