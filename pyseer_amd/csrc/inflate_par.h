@@ -17,6 +17,8 @@
 // (tests/test_reader_cpu.py decodes the same files through python's gzip and through SEERHIP_READER=serial).
 #pragma once
 #include <vector>
+#include <new>
+#include <cstdlib>
 #include <emmintrin.h>
 #include "inflate_fast.h"
 
@@ -32,10 +34,23 @@ static inline void par_seek(Decoder &d, const uint8_t *base, const uint8_t *end,
     d.state = Decoder::BLOCK_HEAD; d.raw = true; d.last_block = false;
 }
 
+// the symbols of a chunk: grown by realloc (large blocks move by page remapping: no copy, no zero fill, no second round of page faults --
+// a std::vector grown to 900 MB of symbols decoded at 88 MB/s, its second use at 940)
+struct SymBuf {
+    uint16_t *p = nullptr; size_t cap = 0;
+    SymBuf() = default; SymBuf(const SymBuf &) = delete; SymBuf &operator=(const SymBuf &) = delete;
+    ~SymBuf() { free(p); }
+    size_t size() const { return cap; }
+    uint16_t *data() { return p; }
+    const uint16_t *data() const { return p; }
+    uint16_t &operator[](size_t i) { return p[i]; }
+    void resize(size_t n) { if (n <= cap) return; void *q = realloc(p, n * sizeof(uint16_t)); if (!q) throw std::bad_alloc(); p = (uint16_t *)q; cap = n; }
+};
+
 struct ParChunk {
     uint64_t start_bit = 0, stop_bit = ~0ull;     // decode from a block head at start_bit up to the first block head at or after stop_bit
     bool exact = false;                            // the window in front is real text (sym[0 .. PAR_WIN) hold bytes where known)
-    std::vector<uint16_t> sym;                     // PAR_WIN window entries, then the chunk's text as symbols
+    SymBuf sym;                                    // PAR_WIN window entries, then the chunk's text as symbols
     size_t n = 0;                                  // symbols of text (sym[PAR_WIN .. PAR_WIN + n))
     uint64_t end_bit = 0; bool hit_final = false, ok = false; const char *err = nullptr;
 };

@@ -65,6 +65,44 @@ def test_corner_cases(tmp_path):
             assert hash_pattern(dense.astype(np.int64)) == hash_pattern(np.asarray(k))
 
 
+def test_tokens_of_every_length_against_the_python_parser(tmp_path):
+    """The parser's 16-byte steps (token ends, 16-byte name keys; longer names through the string compare): sample names of 1 to 40
+    characters, names that agree in their first 16 bytes, a name that is a prefix of another, tokens with and without `:value`, with
+    several colons, unknown names of every length, tabs / CR / runs of blanks, the last token right at the end of a file without a
+    newline -- the presence vectors of read_variant (pyseer/input.py:377-388, restated in pyseer_amd/input.py)."""
+    rng = np.random.default_rng(11)
+    samples = []
+    for n in range(1, 41):
+        samples.append("".join(rng.choice(list("abcdefgh0123_."), n)))
+    samples += ["sample_0123456789", "sample_0123456789x", "sample_0123456789xy", "sample_012345678", "sample_01234567", "p", "pp", "ppp"]
+    samples = list(dict.fromkeys(samples))
+    unknown = ["".join(rng.choice(list("QRSTUV"), n)) for n in (1, 7, 8, 9, 15, 16, 17, 31, 32, 33)] + [samples[20] + "Z", samples[30][:-1]]
+    seps = [" ", "  ", "\t", " \t ", "   "]
+    lines = []
+    for v in range(300):
+        toks = []
+        for name in rng.permutation(samples + unknown)[:rng.integers(0, len(samples) + len(unknown) + 1)]:
+            form = rng.integers(0, 4)
+            toks.append(name if form == 0 else name + ":1" if form == 1 else name + ":17:3" if form == 2 else name + ":")
+        body = "".join(rng.choice(seps) + t for t in toks)
+        lines.append("K%04d |%s%s" % (v, body, rng.choice(["", " ", "\r", " \r"])))
+    p = pd.Series(np.arange(len(samples), dtype=float), index=samples)
+    for name, opener in (("t.txt", open), ("t.gz", gzip.open)):
+        path = str(tmp_path / name)
+        with opener(path, "wt", newline="") as fh:
+            fh.write("\n".join(lines))                           # no trailing newline
+        got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples, 64)]
+        names = sum((g[0] for g in got), [])
+        bits = np.concatenate([g[1] for g in got]); counts = np.concatenate([g[2] for g in got])
+        assert names == ["K%04d" % v for v in range(300)]
+        fh = open(path, newline="") if name.endswith(".txt") else gzip.open(path, "r")
+        for v in range(300):
+            eof, k, var_name, ks, nks, af, missing = read_variant(fh, p, "kmers", False, None, name.endswith(".txt"), set(samples), [])
+            dense = np.unpackbits(bits[v], bitorder="little")[:len(samples)]
+            assert var_name == names[v] and np.array_equal(dense, k), (v, lines[v])
+            assert counts[v] == int(np.sum(k))
+
+
 def test_packed_cache_round_trip(tmp_path):
     """--save-packed / --load-packed: the cache reproduces the native reader's blocks (names, AFs, kept rows, order), also when
     stored blocks are merged into larger ones, and refuses another sample list."""
