@@ -1456,6 +1456,7 @@ __global__ __launch_bounds__(256) void k_bitdot_build_tab(const double *__restri
     }
 }
 
+extern "C" hipError_t shk_bitdot_i8(hipStream_t st, const uint64_t *T, int64_t Vpad, int NB64, int NE, const void *atab, const double *scale, double *out);
 template <int Q>
 __global__ __launch_bounds__(256) void k_glm_bitdot(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P)
 {
@@ -3104,7 +3105,8 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
             hipLaunchKernelGGL((k_glm_fast<Q, true>), g256, b256, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
             int r0 = 0;
             if (P.bd_tab) {                                          // carrier sums: the first Newton step needs no pass, the finishing rounds use them too
-                hipLaunchKernelGGL(k_glm_bitdot<Q>, g256, b256, 0, st, T, Vpad, P);
+                if (P.bd_i8) (void)shk_bitdot_i8(st, T, Vpad, P.NB64, Q + 2, P.bd_i8, P.bd_scale, P.ch_bd);     // int8 matrix cores (bitdot_i8.hip)
+                else hipLaunchKernelGGL(k_glm_bitdot<Q>, g256, b256, 0, st, T, Vpad, P);
                 if (P.b1 && n32 > 1) hipLaunchKernelGGL(k_glm_first_step<Q>, g256, b256, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1);
                 else hipLaunchKernelGGL((k_glm_solve32<Q, true>), g256, b256, 0, st, Vpad, P, wk, P.ch_list[0], P.ch_cnt, P.ch_list[1], P.ch_cnt + 1,
                                         P.ch_list[2], cc, n32 == 1 ? 1 : 0);

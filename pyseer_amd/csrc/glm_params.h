@@ -55,6 +55,7 @@ struct GlmParams {
     float *ch_hf, *ch_rho;
     int *ch_list[6], *ch_cnt;
     const double *bd_tab;
+    const void *bd_i8; const double *bd_scale;   // bitdot_i8.hip: the same sums on the int8 matrix cores (digit table, column scales); null = k_glm_bitdot
     const float *wfp, *yf, *w0f;  // packed-fp32 passes (pass32_pk): wfp = per pair of samples a record of Q + 2 float2 (standardised covariates, y, w0;
                                   // each (even sample, odd sample)); yf, w0f = y and w0 as float arrays (the odd last sample); null = unpacked passes
     const double *rec;            // per sample a record of Q + 1 doubles (standardised covariates, then y): k_glm_score / k_glm_ll

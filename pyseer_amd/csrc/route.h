@@ -5,7 +5,8 @@
 //   chord=0          [1]  logistic: fp64-score Newton passes instead of the chord rounds (the form a run without covariates takes)
 //   chord_n32=K      [5]  single-precision Newton rounds before the chord rounds (1..8); stragglers restart in fp64
 //   chord_enter=X    [5e-3] step below which a variant enters the chord rounds
-//   bitdot=0         [1]  first Newton step by a sample pass, k_glm_final instead of the finishing kernels
+//   bitdot=0         [1]  first Newton step by a sample pass, k_glm_final instead of the finishing kernels;  2: carrier sums by the nibble-table
+//                    kernel on the vector ALU (k_glm_bitdot) instead of the int8 matrix cores (bitdot_i8.hip)
 //   first_bordered=0 [1]  first Newton step through the general (Q+2)^2 solve
 //   pk=0             [1]  the passes without the packed single-precision records
 //   warm=0           [1]  no null-model warm start (the reference's start vector)

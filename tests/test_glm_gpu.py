@@ -664,6 +664,7 @@ def test_logistic_fit_paths_agree(N, q, monkeypatch):
               dict(chord_enter="5e-2"),                              # early hand-over: several chord rounds per variant
               dict(chord_n32="2"),                                   # stragglers of the Newton rounds restarted in fp64 (workgroup kernel)
               dict(bitdot="0"),                                      # first step by a pass, k_glm_final instead of the finishing kernels
+              dict(bitdot="2"),                                      # carrier sums by round 3's nibble-table kernel (product: int8 matrix cores)
               dict(fin_rounds="0"), dict(pk="0"), dict(warm="0"), dict(newton="1"),
               dict(ll_first="0"),                                    # score pass first, likelihood pass last (one more fp64 pass per variant)
               dict(ll_first="0", chord_enter="5e-2"),
