@@ -298,6 +298,7 @@ static void produce_gzip_parallel(sh_reader *r)
     std::mutex mu; std::condition_variable cv_w, cv_a;
     int64_t next_id = 0, consumed = 0;                                // regions handed out / regions the acceptor is through with
     size_t next_from = 0, ch_cur = std::min<size_t>(CHMAX, std::max<size_t>(CHMIN, 1u << 18));
+    int infl_cur = INFL;                                              // regions in flight now: fewer when the text of a region is large (ratio)
     bool exhausted = LEN == 0, quit = false;
     std::vector<std::thread> workers;
     for (int w = 0; w < W; ++w) workers.emplace_back([&] {
@@ -306,7 +307,7 @@ static void produce_gzip_parallel(sh_reader *r)
             Task *t;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_w.wait(lk, [&] { return quit || exhausted || next_id < consumed + INFL; });
+                cv_w.wait(lk, [&] { return quit || exhausted || next_id < consumed + infl_cur; });
                 if (quit || exhausted) return;
                 t = &slots[(size_t)(next_id % INFL)];
                 t->id = next_id++; t->done = false;
@@ -417,7 +418,11 @@ static void produce_gzip_parallel(sh_reader *r)
         if (c->n > 0 && c->end_bit > c->start_bit) {                  // the next regions sized for ~3 MB of text each
             const double ratio = (double)c->n / ((double)(c->end_bit - c->start_bit) / 8.0);
             const size_t want = (size_t)std::min<double>((double)CHMAX, std::max<double>((double)CHMIN, 3.0e6 / std::max(1.0, ratio)));
-            std::lock_guard<std::mutex> lk(mu); ch_cur = want;
+            // at most ~768 MB of symbols in flight (a text that compresses 1000 : 1 would otherwise hold 64 regions of 128 MB)
+            const double per = std::max(1.0, ratio) * (double)want * 2.0;
+            const int infl = (int)std::min<double>((double)INFL, std::max<double>(2.0, 768.0e6 / per));
+            { std::lock_guard<std::mutex> lk(mu); ch_cur = want; infl_cur = infl; }
+            cv_w.notify_all();
         }
         if (c->hit_final) {
             // the trailer: CRC-32 (checked by the consumer over whole slabs), ISIZE; then the next member's header, or the end
