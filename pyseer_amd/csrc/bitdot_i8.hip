@@ -159,6 +159,7 @@ extern "C" hipError_t shk_bitdot_i8(hipStream_t st, const uint64_t *T, int64_t V
     if (NT == 1) hipLaunchKernelGGL(k_bitdot_i8<1>, grid, blk, 0, st, T, Vpad, NB64, NE, (const v4i *)atab, scale, out);
     else if (NT == 2) hipLaunchKernelGGL(k_bitdot_i8<2>, grid, blk, 0, st, T, Vpad, NB64, NE, (const v4i *)atab, scale, out);
     else if (NT == 3) hipLaunchKernelGGL(k_bitdot_i8<3>, grid, blk, 0, st, T, Vpad, NB64, NE, (const v4i *)atab, scale, out);
+    else if (NT == 4) hipLaunchKernelGGL(k_bitdot_i8<4>, grid, blk, 0, st, T, Vpad, NB64, NE, (const v4i *)atab, scale, out);   // Q = 11 .. 14 (GLM_MAXQ)
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

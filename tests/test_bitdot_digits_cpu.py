@@ -12,7 +12,7 @@ from test_bitdot_i8_gpu import _exact_sums
 LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyseer_amd", "libseerhip.so")
 
 
-@pytest.mark.parametrize("N,NE", [(130, 9), (64, 2), (257, 12)])
+@pytest.mark.parametrize("N,NE", [(130, 9), (64, 2), (257, 12), (100, 16)])
 def test_digit_table_walked_like_the_kernel_gives_the_exact_sums(N, NE):
     lib = C.CDLL(LIB)
     lib.shk_bitdot_i8_table_bytes.restype = C.c_int64

@@ -30,7 +30,7 @@ def _exact_sums(K, vals):
     return S, np.ldexp(1.0, ex - 62)
 
 
-@pytest.mark.parametrize("N,NE", [(777, 12), (64, 2), (5000, 12), (1000, 5), (130, 9)])
+@pytest.mark.parametrize("N,NE", [(777, 12), (64, 2), (5000, 12), (1000, 5), (130, 9), (250, 16), (333, 13)])
 def test_carrier_sums_equal_the_exactly_rounded_integer_sums(N, NE):
     import torch
     from pyseer_amd import _abi
