@@ -174,25 +174,6 @@ __device__ __forceinline__ double exp_neg(double x)
     return ldexp(p, (int)kf);
 }
 
-// e^-x for x >= 0 through a 64-entry table of 2^(j/64) (exp_tab64.h) and a degree-5 polynomial on
-// |r| <= ln 2 / 128 (remainder r^6 / 720 = 3.5e-17): 16 vector instructions + two lane permutes against exp_neg's 20
-// (tools/ubench/exp_rcp_acc.hip: both within 1 ulp of the long-double value).
-// (the table: lane j of the wavefront holds 2^(j/64) in `tlane`, looked up with two ds_bpermute_b32 -- no LDS memory, no LDS stores:
-// a kernel that stores to LDS loses the scalar loads of its wave-uniform records)
-__device__ __forceinline__ double exp_neg_tab(double x, double tlane)
-{
-    const double u = -fmin(x, 800.0);
-    const double mf = rint(u * 92.332482616893656758);                       // 64 / ln 2
-    double r = fma(mf, -6.93147180369123816490e-01 / 64.0, u);               // (the hi part has 21 trailing zero bits: m * hi / 64 is exact)
-    r = fma(mf, -1.90821492927058770002e-10 / 64.0, r);
-    const int m = (int)mf;
-    const int ja = (m & 63) << 2;
-    const double T = __hiloint2double(__builtin_amdgcn_ds_bpermute(ja, __double2hiint(tlane)), __builtin_amdgcn_ds_bpermute(ja, __double2loint(tlane)));
-    double c = fma(r, 1.0 / 120.0, 1.0 / 24.0); c = fma(c, r, 1.0 / 6.0); c = fma(c, r, 0.5);
-    const double q = fma(c, r * r, r);
-    return ldexp(fma(T, q, T), m >> 6);
-}
-
 // wave-aggregated append: one atomic per wavefront; callable from divergent code (the leader is one of the active lanes)
 __device__ __forceinline__ void list_push(bool p, int *__restrict__ list, int *__restrict__ count, int v)
 {

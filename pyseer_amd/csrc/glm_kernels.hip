@@ -21,7 +21,6 @@
 #endif
 
 #include "glm_common.h"
-#include "exp_tab64.h"
 #include "glm_device.h"
 
 // ---- one pass over the samples at beta: X^T W X (packed), optional score, log-likelihood, max |mu - y| --------------
@@ -1732,10 +1731,6 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
     if (!__any(on)) return;
     const int N = P.N, NB64 = P.NB64;
     const double *__restrict__ R = P.rec;
-#ifdef LL_EXPTAB
-    static __device__ const double tab64[64] = EXP_TAB64;
-    const double etab = tab64[threadIdx.x & 63];                       // lane j holds 2^(j/64): exp_neg_tab
-#endif
     double beta[PC], g[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
@@ -1751,16 +1746,10 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
         const double yi = rc[Q];
-#ifdef LL_EXPTAB
-        const double t = exp_neg_tab(fabs(eta), etab), u = 1.0 + t;
-#else
         const double t = exp_neg(fabs(eta)), u = 1.0 + t;
-#endif
         double inv = __builtin_amdgcn_rcp(u);                                      // two Newton steps: 1 / u to the last bit or two
         inv = fma(fma(-u, inv, 1.0), inv, inv);
-#ifndef LL_RCP1
         inv = fma(fma(-u, inv, 1.0), inv, inv);
-#endif
         const double mu = (eta >= 0.0) ? inv : t * inv;
         const double r = yi - mu;
         apos += fmax(fma(-2.0 * yi, eta, eta), 0.0);                              // a = (1 - 2 y) eta

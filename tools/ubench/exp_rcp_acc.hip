@@ -1,4 +1,4 @@
-// Accuracy of the pieces a leaner k_glm_ll would be made of (gfx950): v_rcp_f64 raw / after one / after two Newton steps on u in (1, 2];
+// Accuracy of the pieces a leaner k_glm_ll would be made of (gfx950; measured and NOT adopted -- DESIGN.md section 9): v_rcp_f64 raw / after one / after two Newton steps on u in (1, 2];
 // e^-x by the degree-13 polynomial (glm_device.h: exp_neg) against a 64-entry table + degree-5 polynomial.  Reference: long double on the host.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off exp_rcp_acc.hip -o exp_rcp_acc ; run: ./exp_rcp_acc
 #include <hip/hip_runtime.h>
