@@ -351,6 +351,68 @@ def glm_workload(cfg, Vs, N, q):
             "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"}
 
 
+def glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, contexts=3, steps=9, warmup=None, check=None):
+    """The same fixed-effects steps on `contexts` engine contexts of ONE device at once, each with its own stream, workspaces and host thread
+    (what `python -m pyseer_amd --gpus 0,0,0` does for a job; the counterpart of the reference's --cpu N, pyseer/__main__.py:541-568): a step
+    is still one batch through one sh_glm_batch_dev call; the timed region runs exactly `steps` of them, handed to the contexts in turn.  One
+    stream leaves the device idle between its per-variant kernels, its list-length round trips to the host and the tails of its restart /
+    Firth kernels (valu_issue_frac 0.45 at N = 1000); the other streams fill that.  (Cutting ONE batch into slices inside the library was
+    measured too: the per-call join and the smaller launches give most of it back -- DESIGN.md section 5.2.)
+    check = (bits, out, fl) of the one-context run: a context repeats that batch after the timed region and must return the same bytes."""
+    import threading
+    import torch
+    from pyseer_amd.engine import Engine
+    steps = (steps + contexts - 1) // contexts * contexts
+    warmup = contexts if warmup is None else warmup
+    ctxs = []
+    for c in range(contexts):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            eng = Engine(N, device=local); eng.use_torch_stream(); eng.set_af_filter(0.01, 0.99)
+            eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=(cfg == "C4"))
+            bits = [synth_bits(Vs, N, rb, 5151 + 10 * c + i, dev) for i in range(2)]
+            out = torch.empty((5 + q, Vs), dtype=torch.float64, device=dev); fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
+        ctxs.append((st, eng, bits, out, fl))
+    torch.cuda.synchronize()
+
+    def work(c, n):
+        st, eng, bits, out, fl = ctxs[c]
+        with torch.cuda.stream(st):
+            for i in range(n):
+                eng.glm_batch_dev(bits[i % 2], out, fl)
+            st.synchronize()
+
+    def timed(n_each):
+        th = [threading.Thread(target=work, args=(c, n_each)) for c in range(contexts)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    timed(max(1, warmup // contexts))
+    dt = timed(steps // contexts)
+    res = {"contexts": contexts, "value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "what": "%d engine contexts on one device, each with its own stream and host thread, batches handed to them in turn "
+                   "(the job path of --gpus 0,0,0; the reference's --cpu N); one step = one batch through one sh_glm_batch_dev call" % contexts}
+    if check is not None:
+        st, eng, _, out, fl = ctxs[0]
+        with torch.cuda.stream(st):
+            eng.glm_batch_dev(check[0], out, fl); st.synchronize()
+        same = bool(torch.equal(out.view(torch.int64), check[1].view(torch.int64))) and bool(torch.equal(fl, check[2]))
+        res["identical_to_one_context"] = same
+        if not same:                                                  # (never seen; reported rather than fatal: flags and the worst relative deviation)
+            a, b = out.double(), check[1].double()
+            okm = torch.isfinite(a) & torch.isfinite(b)
+            res["flags_identical"] = bool(torch.equal(fl, check[2]))
+            res["max_rel_dev_from_one_context"] = float(((a - b).abs() / b.abs().clamp_min(1e-300))[okm].max().item()) if bool(okm.any()) else None
+    for c in ctxs:
+        c[1].close()
+    return res
+
+
 def fixed_effects_line(cfg, dev, local, steps=5, warmup=1, Vs=None, cpu=True, parity=True, env=None):
     """One fixed-effects configuration measured the way the main line is (HIP events on the launch stream, inputs resident, oracle re-check
     of the timed output, CPU baseline): the `extra` entries of the default (C3) line, so that the driver's run of `bench.py --gpus 1`
@@ -400,6 +462,11 @@ def fixed_effects_line(cfg, dev, local, steps=5, warmup=1, Vs=None, cpu=True, pa
         n, devs = parity_glm(y, W, nl, nf, cfg == "C4", bits[(warmup + steps - 1) % nb], out, fl, N)
         res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
     eng.close()
+    if not env:
+        try:
+            res["three_contexts"] = glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, check=(bits[(warmup + steps - 1) % nb], out, fl))
+        except Exception as e:                                        # a secondary measurement must not take the line down
+            res["three_contexts"] = {"error": repr(e)}
     del bits, out, fl
     if cpu:
         res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, cfg == "C4")
@@ -680,6 +747,11 @@ def main():
             if not args.no_parity:
                 n, devs = parity_glm(y, W, nl, nf, force, last, out, fl, N)
                 res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
+            if world == 1 and not args.no_extra:
+                try:
+                    res["three_contexts"] = glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, check=(last, out, fl))
+                except Exception as e:
+                    res["three_contexts"] = {"error": repr(e)}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, force)
         print(json.dumps(res))

@@ -750,3 +750,57 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     close(b["kbeta"][ok], a["kbeta"][ok], rtol=1e-6, atol=2e-8, what="kbeta")
     close(b["intercept"][ok], a["intercept"][ok], rtol=1e-6, atol=2e-8, what="intercept")
     close(b["betas"][ok], a["betas"][ok], rtol=1e-6, atol=2e-8, what="betas")
+
+
+def test_contexts_on_one_device_run_concurrently_and_agree_bit_for_bit():
+    """Several engine contexts of ONE device driven from their own host threads at once (the job path of `--gpus 0,0,0`; bench.py's
+    three_contexts line; the counterpart of the reference's --cpu N, pyseer/__main__.py:541-568): every context returns the bytes the
+    single context returns for the same rows -- ordinary fits, Firth-routed rows, AF-filtered rows."""
+    import threading
+    import torch
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    N, q, V = 700, 5, 40000
+    rng = np.random.default_rng(31)
+    W = rng.standard_normal((N, q))
+    y = (rng.random(N) < 1 / (1 + np.exp(-(-0.3 + 0.9 * W[:, 0])))).astype(float)
+    af = np.concatenate([rng.uniform(0.02, 0.98, V - V // 5), rng.uniform(0.0, 0.02, V // 5)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K[:300] = (rng.random((300, N)) < (0.1 + 0.8 * y)[None, :]).astype(np.uint8)
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    rows = [torch.from_numpy(pack_variants(K[s::3])).cuda() for s in range(3)]          # three different batches
+    dev = torch.device("cuda:0")
+
+    def make():
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
+            e.glm_setup(y, W, False, nl, nf, 1.0, 1.0)
+        return st, e
+    st0, e0_ = make()
+    want = []
+    with torch.cuda.stream(st0):
+        for r in rows:
+            o, f = e0_.glm_batch_dev(r); st0.synchronize()
+            want.append((o.cpu().numpy().copy(), f.cpu().numpy().copy()))
+    ctxs = [(st0, e0_)] + [make() for _ in range(2)]
+    torch.cuda.synchronize()
+    got = [[None] * 6 for _ in range(3)]
+
+    def work(c):
+        st, e = ctxs[c]
+        with torch.cuda.stream(st):
+            for it in range(6):                                       # every context sees every batch, in another order than its neighbours
+                k = (it + c) % 3
+                o, f = e.glm_batch_dev(rows[k]); st.synchronize()
+                got[c][it] = (k, o.cpu().numpy().copy(), f.cpu().numpy().copy())
+    th = [threading.Thread(target=work, args=(c,)) for c in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for c in range(3):
+        for k, o, f in got[c]:
+            assert np.array_equal(o.view(np.uint8), want[k][0].view(np.uint8)) and np.array_equal(f, want[k][1]), (c, k)
+    assert (np.bitwise_and(want[0][1], 0x7C) != 0).sum() > 10         # Firth-routed rows were among them
+    for _, e in ctxs:
+        e.close()
