@@ -18,6 +18,7 @@
 #include <emmintrin.h>
 #include "route.h"
 #include "inflate_par.h"
+#include "crc32_clmul.h"
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -215,12 +216,12 @@ static void release_slab(sh_reader *r, Slab &sl)
 static uint32_t crc_parallel(ParPool *pool, uint32_t crc, const uint8_t *p, size_t n)
 {
     const size_t CH = 1u << 20;
-    if (n <= 2 * CH || !pool) return (uint32_t)crc32(crc, p, (uInt)n);
+    if (n <= 2 * CH || !pool) return shcrc::crc32(crc, p, n);
     const int64_t nch = (int64_t)((n + CH - 1) / CH);
     std::vector<uint32_t> part((size_t)nch);
     pool->run(nch, 1, [&](int64_t i) {
         const size_t lo = (size_t)i * CH, len = std::min(CH, n - lo);
-        part[(size_t)i] = (uint32_t)crc32(0L, p + lo, (uInt)len);
+        part[(size_t)i] = shcrc::crc32(0u, p + lo, len);
     });
     for (int64_t i = 0; i < nch; ++i) {
         const size_t lo = (size_t)i * CH, len = std::min(CH, n - lo);
@@ -484,7 +485,7 @@ static void produce_bgzf(sh_reader *r)
             const Mem &m = mem[(size_t)i];
             d.begin(m.cdata, m.cdata + m.clen, true);
             uint8_t *o = d.run(tmp.data(), tmp.data() + tmp.size(), tmp.data());
-            if (d.state != shinf::Decoder::DONE || (size_t)(o - tmp.data()) != m.isize || (uint32_t)crc32(0L, tmp.data(), m.isize) != m.crc) ++bad;
+            if (d.state != shinf::Decoder::DONE || (size_t)(o - tmp.data()) != m.isize || shcrc::crc32(0u, tmp.data(), m.isize) != m.crc) ++bad;
             else memcpy(buf + PAD + m.off, tmp.data(), m.isize);
         });
         if (bad && err.empty()) err = "BGZF: a member failed to decode or its CRC-32 check";
@@ -765,6 +766,7 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     return nv;
 }
 
+uint32_t shk_crc32(uint32_t crc, const uint8_t *p, int64_t n) { return shcrc::crc32(crc, p, (size_t)n); }   // (internal: tests/test_reader_cpu.py)
 int64_t sh_reader_names_needed(sh_reader *r) { return r ? r->names_needed : 0; }
 int64_t sh_reader_par_chunks(sh_reader *r) { return r ? r->par_accepted.load() : 0; }
 int64_t sh_reader_buffered(sh_reader *r)

@@ -294,6 +294,23 @@ def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
             read(path, "reader_slab=300000,reader_chunk=8192", None, "8")
 
 
+def test_clmul_crc32_equals_zlib():
+    """csrc/crc32_clmul.h (carry-less-multiplication folding of the gzip CRC-32; zlib's routine cost as much host time as inflating):
+    the value of zlib.crc32 for every length around the 16- and 64-byte block sizes, random starts and initial values."""
+    import ctypes as C
+    import zlib
+    from pyseer_amd import _abi
+    lib = C.CDLL(_abi.LIB_PATH)
+    lib.shk_crc32.restype = C.c_uint32
+    lib.shk_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_int64]
+    rng = np.random.default_rng(8)
+    data = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    for n in list(range(0, 300)) + [4095, 4096, 4097, 65535, 65536, 65537, 1 << 20] + [int(x) for x in rng.integers(300, 1 << 20, 200)]:
+        off = int(rng.integers(0, len(data) - n + 1))
+        init = int(rng.integers(0, 1 << 32)) if n % 3 else 0
+        assert lib.shk_crc32(init, data[off:off + n], n) == zlib.crc32(data[off:off + n], init), n
+
+
 def test_corrupt_gzip_is_reported(tmp_path):
     """A flipped bit inside the deflate data: the stream either stops decoding or fails its CRC-32 -- never a silent wrong block."""
     import pytest

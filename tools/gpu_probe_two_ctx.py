@@ -49,6 +49,10 @@ def run(cfg, nctx, steps=6, warmup=2):
 
 res = {}
 for cfg in (sys.argv[1:] or ["C2", "C2N5000", "C4"]):
-    r = {"one": run(cfg, 1), "two": run(cfg, 2), "three": run(cfg, 3), "one_again": run(cfg, 1)}
+    counts = [int(x) for x in os.environ.get("CONTEXTS", "1,2,3,1").split(",")]
+    names = {1: "one", 2: "two", 3: "three", 4: "four", 5: "five", 6: "six", 8: "eight"}
+    r = {}
+    for k in counts:
+        r[names.get(k, str(k)) + ("_again" if names.get(k, str(k)) in r else "")] = run(cfg, k, steps=6 if k < 4 else 4)
     res[cfg] = r
     print(json.dumps({cfg: {k: round(v / 1e6, 2) for k, v in r.items()}}), flush=True)
