@@ -158,37 +158,41 @@ static bool par_decode(Decoder &d, const uint8_t *base, const uint8_t *end, ParC
     return true;
 }
 
+// Kraft sums of four 3-bit code lengths at a time: low 16 bits = sum of 128 >> l over the non-zero lengths, high 16 = how many are non-zero
+struct Kraft4 { uint32_t t[4096]; Kraft4() { for (int v = 0; v < 4096; ++v) { uint32_t sum = 0, cnt = 0; for (int k = 0; k < 4; ++k) { const int l = (v >> (3 * k)) & 7; if (l) { sum += 128u >> l; ++cnt; } } t[v] = sum | (cnt << 16); } } };
+
 // The first bit offset in [from, to) at which a dynamic block head stands the tests of step 1, or ~0.
 static uint64_t par_find_block(const uint8_t *base, const uint8_t *end, uint64_t from, uint64_t to, Decoder &d, ParChunk &scratch)
 {
+    static const Kraft4 K4;
     const uint64_t total_bits = (uint64_t)(end - base) * 8;
     if (to > total_bits - 64 * 8) to = total_bits > 64 * 8 ? total_bits - 64 * 8 : 0;       // (the quick test reads 16 bytes ahead)
-    for (uint64_t bit = from; bit < to; ++bit) {
-        const uint8_t *p = base + (bit >> 3);
-        const int sh = (int)(bit & 7);
-        uint64_t w = load64(p) >> sh;                                   // >= 57 bits
-        // BFINAL (either), BTYPE = 2 (bits 1-2 = 0b10, LSB first: bit1 = 0, bit2 = 1), HLIT <= 29, HDIST <= 29
-        if (((w >> 1) & 3) != 2) continue;
-        const uint32_t hlit = (uint32_t)(w >> 3) & 31, hdist = (uint32_t)(w >> 8) & 31, hclen = (uint32_t)(w >> 13) & 15;
-        if (hlit > 29 || hdist > 29) continue;
-        // the code-length code: (hclen + 4) x 3 bits, must be complete
-        const int nc = (int)hclen + 4;
-        w >>= 17;                                                       // 40+ bits left: 13 lengths; the rest from a second load
-        int count[8] = {0};
-        uint64_t w2 = load64(p + 7) >> sh;                              // bits 56.. of the stream at this offset
-        for (int i = 0; i < nc; ++i) {
-            uint32_t l;
-            if (i < 13) { l = (uint32_t)(w & 7); w >>= 3; }
-            else { const int off = 17 + 3 * i - 56; l = (uint32_t)(w2 >> off) & 7; }
-            count[l]++;                                             // (the order the lengths are stored in does not matter to completeness)
+    for (uint64_t byte = from >> 3; byte * 8 < to; ++byte) {
+        const uint8_t *p = base + byte;
+        const uint64_t A0 = load64(p), B0 = load64(p + 7);              // stream bits 0 .. 63 and 56 .. 119 from this byte
+        // BTYPE = 2 at bit offset sh: bits sh + 1, sh + 2 of the byte pair = 0, 1.  All eight offsets at once: m bit sh set <=> a candidate
+        const uint32_t lo = (uint32_t)A0 & 0x3FFu;
+        uint32_t m = (~(lo >> 1) & (lo >> 2)) & 0xFFu;
+        if (byte * 8 < from) m &= 0xFFu << (from & 7);
+        while (m) {
+            const int sh = __builtin_ctz(m); m &= m - 1;
+            const uint64_t bit = byte * 8 + (uint64_t)sh;
+            if (bit >= to) break;
+            const uint64_t A = A0 >> sh;                                // >= 57 bits of the stream from `bit`
+            // BFINAL (either), BTYPE = 2, HLIT <= 29, HDIST <= 29
+            const uint32_t hlit = (uint32_t)(A >> 3) & 31, hdist = (uint32_t)(A >> 8) & 31, hclen = (uint32_t)(A >> 13) & 15;
+            if (hlit > 29 || hdist > 29) continue;
+            // the code-length code: (hclen + 4) x 3 bits from stream bit 17, must be complete (Kraft sum 128 / 128) or a single code
+            const int nc = (int)hclen + 4;
+            uint64_t L = ((A >> 17) & ((1ull << 39) - 1)) | ((B0 >> sh) << 39);       // stream bits 17 .. 80
+            L &= (1ull << (3 * nc)) - 1;                                 // (nc <= 19: 57 bits)
+            const uint32_t k = K4.t[L & 4095] + K4.t[(L >> 12) & 4095] + K4.t[(L >> 24) & 4095] + K4.t[(L >> 36) & 4095] + K4.t[(L >> 48) & 4095];
+            if ((k & 0xFFFFu) != 128u && (k >> 16) != 1u) continue;
+            if ((k & 0xFFFFu) > 128u) continue;
+            // the full tests: both codes complete, a first stretch of printable text
+            scratch.start_bit = bit; scratch.ok = false; scratch.err = nullptr; scratch.hit_final = false;
+            if (par_decode(d, base, end, scratch, true, 4096) && scratch.ok) return bit;
         }
-        int left = 1, used = 0;
-        bool bad = false;
-        for (int l = 1; l <= 7; ++l) { left <<= 1; left -= count[l]; used += count[l]; if (left < 0) { bad = true; break; } }
-        if (bad || (left > 0 && used != 1)) continue;
-        // the full tests: both codes complete, a first stretch of printable text
-        scratch.start_bit = bit; scratch.ok = false; scratch.err = nullptr; scratch.hit_final = false;
-        if (par_decode(d, base, end, scratch, true, 4096) && scratch.ok) return bit;
     }
     return ~0ull;
 }

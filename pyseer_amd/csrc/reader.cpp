@@ -154,7 +154,9 @@ struct sh_reader {
     std::thread producer;
     std::mutex mu; std::condition_variable cv_put, cv_get, cv_free;
     std::deque<Slab> queue; std::vector<char *> free_bufs; std::vector<char *> all_bufs; bool stop = false;
-    size_t slab_bytes = 16u << 20, pad_bytes = 1u << 20, depth = 3;
+    size_t slab_bytes = 16u << 20, pad_bytes = 1u << 20;
+    size_t depth = 10;                   // slabs decoded ahead of the parser: a 4 096-line block at N = 5000 is 9 slabs of text, and with 3 the decoder stood
+                                         // still while the block before it was parsed (gzip 122 k k-mers/s, decode and parse taking turns)
     std::atomic<int64_t> par_accepted{0}; // chunks accepted from a searched block head (sh_reader_par_chunks)
     size_t par_chunk = 1u << 20;         // most compressed bytes per region of the parallel gzip decoder (inflate_par.h)
     int par_workers = 0;                 //   its decoding threads
@@ -552,6 +554,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
     if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
     // one gzip member on several threads (inflate_par.h) unless SEERHIP_READER=serial, or there is nothing to share out
+    if (const char *cd = sh_route("reader_depth")) r->depth = std::max<size_t>(1, (size_t)std::atoll(cd));
     size_t par_min = 1u << 20;
     if (const char *cb = sh_route("reader_chunk")) { r->par_chunk = std::max<size_t>(4096, (size_t)std::atoll(cb)); par_min = 2 * r->par_chunk; }
     const bool par = r->mode == 1 && nt >= 3 && !(sel && std::string(sel) == "serial") && r->map_len >= par_min;

@@ -133,7 +133,7 @@ def test_packed_cache_round_trip(tmp_path):
 
 def test_buffer_stays_bounded_over_many_blocks(tmp_path, monkeypatch):
     """The reader holds a fixed number of recycled slab buffers whatever the file size (round 1 kept the whole inflated file; the
-    reference streams line by line, pyseer/input.py:301-454): ~50 MB of text through 1 MB slabs never allocates more than 8 of them."""
+    reference streams line by line, pyseer/input.py:301-454): ~50 MB of text through 1 MB slabs never allocates more than 16 of them."""
     samples = ["sample%04d" % i for i in range(400)]
     rng = np.random.default_rng(3)
     nlines = 24000
@@ -153,7 +153,7 @@ def test_buffer_stays_bounded_over_many_blocks(tmp_path, monkeypatch):
             total += counts.shape[0]
             peak = max(peak, int(r._lib.sh_reader_buffered(r._h)))
         assert total == nlines
-        assert peak <= 8 * ((1 << 20) + (1 << 18)), (name, peak)
+        assert peak <= 16 * ((1 << 20) + (1 << 18)), (name, peak)         # look-ahead of 10 slabs + the block in hand + the one being filled
 
 
 def test_long_variant_names_grow_the_names_buffer(tmp_path):
