@@ -158,8 +158,10 @@ struct sh_reader {
     size_t depth = 10;                   // slabs decoded ahead of the parser: a 4 096-line block at N = 5000 is 9 slabs of text, and with 3 the decoder stood
                                          // still while the block before it was parsed (gzip 122 k k-mers/s, decode and parse taking turns)
     std::atomic<int64_t> par_accepted{0}; // chunks accepted from a searched block head (sh_reader_par_chunks)
-    size_t par_chunk = 1u << 20;         // most compressed bytes per region of the parallel gzip decoder (inflate_par.h)
+    size_t par_chunk = 4u << 20;         // most compressed bytes per region of the parallel gzip decoder (inflate_par.h)
     int par_workers = 0;                 //   its decoding threads
+    double par_target = 12.0e6;          //   text bytes a region is sized for (the producer hands a region's text on in one fork-join of its helpers:
+                                         //   3 MB regions spent the whole run there, profiles/r04/bench_reader_sweep.jsonl)
     int mode = 0;                        // 0 plain, 1 gzip, 2 BGZF
     std::unique_ptr<ParPool> pool, pool_bgzf;   // parser / CRC workers; member-parallel BGZF decoding (the producer's)
     // consumer
@@ -303,11 +305,18 @@ static void produce_gzip_parallel(sh_reader *r)
     size_t next_from = 0, ch_cur = std::min<size_t>(CHMAX, std::max<size_t>(CHMIN, 1u << 18));
     int infl_cur = INFL;                                              // regions in flight now: fewer when the text of a region is large (ratio)
     bool exhausted = LEN == 0, quit = false;
+    // where the time goes (SEERHIP_HOST_DEBUG: one line on stderr when the stream ends), seconds summed over the threads of a kind
+    const bool dbg = std::getenv("SEERHIP_HOST_DEBUG") != nullptr;
+    std::atomic<int64_t> ns_wslot{0}, ns_find{0}, ns_dec{0}, n_redo{0}, n_acc{0};
+    int64_t ns_await = 0, ns_redo = 0, ns_trans = 0, ns_put = 0;
+    auto now_ns = [] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int64_t t_begin = now_ns();
     std::vector<std::thread> workers;
     for (int w = 0; w < W; ++w) workers.emplace_back([&] {
         std::unique_ptr<Decoder> dec(new Decoder);
         for (;;) {
             Task *t;
+            const int64_t tw0 = dbg ? now_ns() : 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_w.wait(lk, [&] { return quit || exhausted || next_id < consumed + infl_cur; });
@@ -323,9 +332,12 @@ static void produce_gzip_parallel(sh_reader *r)
             if (c.sym.size() < PAR_WIN + 65536) c.sym.resize(PAR_WIN + 65536);
             for (uint32_t k = 0; k < PAR_WIN; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
             c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0; c.exact = false;
+            const int64_t tf0 = dbg ? now_ns() : 0;
             const uint64_t start = par_find_block(base, end, t->from_bit, t->to_bit == ~0ull ? (uint64_t)LEN * 8 : t->to_bit, *dec, c);
+            const int64_t tf1 = dbg ? now_ns() : 0;
             c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0;
             if (start != ~0ull) { c.start_bit = start; c.stop_bit = t->to_bit; par_decode(*dec, base, end, c); }
+            if (dbg) { const int64_t tf2 = now_ns(); ns_wslot += tf0 - tw0; ns_find += tf1 - tf0; ns_dec += tf2 - tf1; }
             { std::lock_guard<std::mutex> lk(mu); t->done = true; }
             cv_a.notify_all();
         }
@@ -359,6 +371,13 @@ static void produce_gzip_parallel(sh_reader *r)
         if (!in_member) {
             hd.state = Decoder::HEADER;
             if (!hd.read_gzip_header()) {
+                if (dbg) {
+                    const double wall = (double)(now_ns() - t_begin) * 1e-9;
+                    fprintf(stderr, "[reader debug] parallel gzip: wall %.3f s, %d decoding threads: waiting for a slot %.3f, searching %.3f, decoding %.3f s (summed); "
+                                    "acceptor: waiting for a region %.3f, decoding again %.3f (%lld of %lld regions), translating + handing on %.3f (of it blocked on the parser %.3f) s\n",
+                            wall, W, (double)ns_wslot * 1e-9, (double)ns_find * 1e-9, (double)ns_dec * 1e-9, (double)ns_await * 1e-9, (double)ns_redo * 1e-9,
+                            (long long)n_redo.load(), (long long)(n_redo.load() + n_acc.load()), (double)ns_trans * 1e-9, (double)ns_put * 1e-9);
+                }
                 if (hd.state == Decoder::DONE) flush(true, std::string());
                 else flush(true, std::string("gzip: ") + (hd.err ? hd.err : "error"));
                 return;
@@ -367,6 +386,7 @@ static void produce_gzip_parallel(sh_reader *r)
         }
         // ---- the region the position lies in --------------------------------------------------------------------------------------------
         Task *t = nullptr;
+        const int64_t ta0 = dbg ? now_ns() : 0;
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
             if (exhausted && j >= next_id) break;                      // (cannot happen: the last region runs to the end of the file)
@@ -377,8 +397,11 @@ static void produce_gzip_parallel(sh_reader *r)
         }
         if (!t) { flush(true, "gzip: internal error (no region for the position)"); return; }
         ParChunk *c = &t->c;
-        if (c->ok && c->start_bit == pos_bit) ++r->par_accepted;
+        const int64_t ta1 = dbg ? now_ns() : 0;
+        ns_await += ta1 - ta0;
+        if (c->ok && c->start_bit == pos_bit) { ++r->par_accepted; ++n_acc; }
         else {
+            ++n_redo;
             redo.start_bit = pos_bit; redo.stop_bit = t->to_bit;
             if (redo.sym.size() < PAR_WIN + 65536) redo.sym.resize(PAR_WIN + 65536);
             for (uint32_t k = 0; k < PAR_WIN; ++k) redo.sym[k] = (uint16_t)(0x8000u | k);
@@ -387,6 +410,8 @@ static void produce_gzip_parallel(sh_reader *r)
             if (!redo.ok) { flush(true, std::string("gzip: ") + (redo.err ? redo.err : "error")); return; }
             c = &redo;
         }
+        const int64_t ta2 = dbg ? now_ns() : 0;
+        ns_redo += ta2 - ta1;
         // ---- its text: the next window first (in order, 32 K symbols), then everything into slabs by the helpers ---------------------------
         const uint16_t *sym = c->sym.data() + PAR_WIN;
         bool refs_ok = true;
@@ -411,8 +436,9 @@ static void produce_gzip_parallel(sh_reader *r)
             if (bad) refs_ok = false;
             fill += cnt; off += cnt;
             if (fill == SB && !refs_ok) break;
-            if (fill == SB) { if (!flush(false, std::string())) return; }
+            if (fill == SB) { const int64_t tp0 = dbg ? now_ns() : 0; const bool okp = flush(false, std::string()); if (dbg) ns_put += now_ns() - tp0; if (!okp) return; }
         }
+        if (dbg) ns_trans += now_ns() - ta2;
         if (!refs_ok) { flush(true, "gzip: distance too far back"); return; }
         hist.swap(hist2);
         avail = (uint32_t)std::min<uint64_t>(PAR_WIN, (uint64_t)avail + c->n);
@@ -420,7 +446,7 @@ static void produce_gzip_parallel(sh_reader *r)
         pos_bit = c->end_bit;
         if (c->n > 0 && c->end_bit > c->start_bit) {                  // the next regions sized for ~3 MB of text each
             const double ratio = (double)c->n / ((double)(c->end_bit - c->start_bit) / 8.0);
-            const size_t want = (size_t)std::min<double>((double)CHMAX, std::max<double>((double)CHMIN, 3.0e6 / std::max(1.0, ratio)));
+            const size_t want = (size_t)std::min<double>((double)CHMAX, std::max<double>((double)CHMIN, r->par_target / std::max(1.0, ratio)));
             // at most ~768 MB of symbols in flight (a text that compresses 1000 : 1 would otherwise hold 64 regions of 128 MB)
             const double per = std::max(1.0, ratio) * (double)want * 2.0;
             const int infl = (int)std::min<double>((double)INFL, std::max<double>(2.0, 768.0e6 / per));
@@ -555,13 +581,16 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
     // one gzip member on several threads (inflate_par.h) unless SEERHIP_READER=serial, or there is nothing to share out
     if (const char *cd = sh_route("reader_depth")) r->depth = std::max<size_t>(1, (size_t)std::atoll(cd));
-    size_t par_min = 1u << 20;
+    size_t par_min = 1u << 20;                                      // files below this go through the one-thread decoder
     if (const char *cb = sh_route("reader_chunk")) { r->par_chunk = std::max<size_t>(4096, (size_t)std::atoll(cb)); par_min = 2 * r->par_chunk; }
     const bool par = r->mode == 1 && nt >= 3 && !(sel && std::string(sel) == "serial") && r->map_len >= par_min;
     if (par) {
         r->par_workers = std::max(2, std::min(32, nt * 2 / 3));
         if (const char *cw = sh_route("reader_workers")) r->par_workers = std::max(1, std::atoi(cw));
-        r->pool_bgzf.reset(new ParPool(std::max(1, std::min(8, nt / 4))));
+        int helpers = std::max(2, std::min(8, nt / 2));
+        if (const char *ch = sh_route("reader_helpers")) helpers = std::max(1, std::atoi(ch));
+        if (const char *ct = sh_route("reader_target")) r->par_target = std::max(65536.0, std::atof(ct));
+        r->pool_bgzf.reset(new ParPool(helpers));
     }
     r->producer = std::thread([r, par] {
         if (r->mode == 0) produce_plain(r); else if (r->mode == 1) { if (par) produce_gzip_parallel(r); else produce_gzip(r); } else produce_bgzf(r);

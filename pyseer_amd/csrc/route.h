@@ -18,8 +18,9 @@
 //   afcompact=M      [1]  0: never compact AF / prefilter-rejected rows before the kernels, 2: always
 //   complement=0     [1]  LMM: rows with more than N/2 carriers stored as given
 //   reader_slab=B, reader_pad=B   reader: bytes per decoded slab / carried over between slabs
-//   reader_depth=D   [10] slabs decoded ahead of the parser
-//   reader_chunk=B   [1 MB] most compressed bytes per region of the parallel gzip decoder (regions are sized for ~3 MB of text; small values:
+//   reader_depth=D   [10] slabs decoded ahead of the parser;  reader_helpers=H  translating threads beside the producer [reader threads / 2, <= 8];
+//                    reader_target=B  text bytes a region is sized for [12e6]
+//   reader_chunk=B   [4 MB] most compressed bytes per region of the parallel gzip decoder (regions are sized for ~12 MB of text; small values:
 //                    many regions in a small file);  reader_workers=W  its decoding threads [2/3 of the reader's threads, at most 32]
 #pragma once
 #include <cstdlib>
@@ -29,7 +30,7 @@
 static inline const char *const *sh_route_keys()
 {
     static const char *const keys[] = {"chord", "chord_n32", "chord_enter", "bitdot", "first_bordered", "pk", "warm", "fin_rounds", "ll_first", "newton",
-                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", "reader_chunk", "reader_workers", "reader_depth", nullptr};
+                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", "reader_chunk", "reader_workers", "reader_depth", "reader_helpers", "reader_target", nullptr};
     return keys;
 }
 // the value of `key` in SEERHIP_ROUTE, or nullptr (the returned string lives until the calling thread's next sh_route)
