@@ -336,7 +336,10 @@ static void produce_gzip_parallel(sh_reader *r)
             const uint64_t start = par_find_block(base, end, t->from_bit, t->to_bit == ~0ull ? (uint64_t)LEN * 8 : t->to_bit, *dec, c);
             const int64_t tf1 = dbg ? now_ns() : 0;
             c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0;
-            if (start != ~0ull) { c.start_bit = start; c.stop_bit = t->to_bit; par_decode(*dec, base, end, c); }
+            if (start != ~0ull) {
+                c.start_bit = start; c.stop_bit = t->to_bit;
+                try { par_decode(*dec, base, end, c); } catch (const std::bad_alloc &) { c.ok = false; c.err = "out of memory"; }   // (the producer decides: it decodes the region again)
+            }
             if (dbg) { const int64_t tf2 = now_ns(); ns_wslot += tf0 - tw0; ns_find += tf1 - tf0; ns_dec += tf2 - tf1; }
             { std::lock_guard<std::mutex> lk(mu); t->done = true; }
             cv_a.notify_all();
@@ -406,7 +409,7 @@ static void produce_gzip_parallel(sh_reader *r)
             if (redo.sym.size() < PAR_WIN + 65536) redo.sym.resize(PAR_WIN + 65536);
             for (uint32_t k = 0; k < PAR_WIN; ++k) redo.sym[k] = (uint16_t)(0x8000u | k);
             redo.ok = false; redo.hit_final = false; redo.err = nullptr; redo.n = 0;
-            par_decode(*redo_dec, base, end, redo);
+            try { par_decode(*redo_dec, base, end, redo); } catch (const std::bad_alloc &) { redo.ok = false; redo.err = "out of memory decoding a region"; }
             if (!redo.ok) { flush(true, std::string("gzip: ") + (redo.err ? redo.err : "error")); return; }
             c = &redo;
         }
@@ -574,7 +577,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
         r->map = (const uint8_t *)m;
         madvise(m, r->map_len, MADV_SEQUENTIAL);
     }
-    if (const char *sb = sh_route("reader_slab")) r->slab_bytes = std::max<size_t>(70000, (size_t)std::atoll(sb));
+    if (const char *sb = sh_route("reader_slab")) r->slab_bytes = std::min<size_t>(2047u << 20, std::max<size_t>(70000, (size_t)std::atoll(sb)));   // (newline offsets are 32-bit)
     if (const char *pb = sh_route("reader_pad")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
