@@ -467,6 +467,9 @@ def fixed_effects_line(cfg, dev, local, steps=5, warmup=1, Vs=None, cpu=True, pa
             res["three_contexts"] = glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, check=(bits[(warmup + steps - 1) % nb], out, fl))
         except Exception as e:                                        # a secondary measurement must not take the line down
             res["three_contexts"] = {"error": repr(e)}
+        vf = res["roofline"].get("valu_issue_frac")
+        if vf and "value" in res["three_contexts"]:                   # the same instructions per variant, issued in less time
+            res["three_contexts"]["valu_issue_frac"] = vf * res["three_contexts"]["value"] / res["value"]
     del bits, out, fl
     if cpu:
         res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, cfg == "C4")
@@ -752,6 +755,9 @@ def main():
                     res["three_contexts"] = glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, check=(last, out, fl))
                 except Exception as e:
                     res["three_contexts"] = {"error": repr(e)}
+                vf = res["roofline"].get("valu_issue_frac")
+                if vf and "value" in res["three_contexts"]:
+                    res["three_contexts"]["valu_issue_frac"] = vf * res["three_contexts"]["value"] / res["value"]
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, force)
         print(json.dumps(res))
