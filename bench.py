@@ -351,7 +351,7 @@ def glm_workload(cfg, Vs, N, q):
             "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"}
 
 
-def glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, contexts=3, steps=9, warmup=None, check=None):
+def glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, contexts=3, steps=15, warmup=None, check=None):
     """The same fixed-effects steps on `contexts` engine contexts of ONE device at once, each with its own stream, workspaces and host thread
     (what `python -m pyseer_amd --gpus 0,0,0` does for a job; the counterpart of the reference's --cpu N, pyseer/__main__.py:541-568): a step
     is still one batch through one sh_glm_batch_dev call; the timed region runs exactly `steps` of them, handed to the contexts in turn.  One
