@@ -8,6 +8,16 @@
     part firth   pyseer/model.py:414 fit_firth on the rows tools/gpu_dump_disputed_firth.py dumped from the C4 workload
                  (every row on which the library's three step-halving modes or the C restatement disagree, and 24 controls)
                  -> n5000_firth.npz; `--slice i/n` does rows i::n (one process per slice, merged by `--merge`)
+  round 5 (VERDICT r04 "next" 4):
+    part firth_random  pyseer/model.py:414 fit_firth and :202 fixed_effects_regression on the FIRST 256 rows of the bench's C4 / C2N5000
+                 batch (tools/gpu_dump_c4_rows.py: synth_bits(2^18, 5000, rb, 4242), nobody chose them)       -> n5000_random.npz
+                 (`firth_random i/n` per slice, `merge_random n`)
+    part ols     pyseer/model.py:299-312 (continuous phenotype, OLS) on 64 rows                          -> n5000_ols.npz
+    part lineage pyseer/model.py:151-199 fit_lineage_effect on 32 rows: 10 MDS-like columns + 2 covariates; 12 cluster indicators  -> n5000_lineage.npz
+    part lmm_d3  pyseer/lmm.py:26,95-99,228: D = 3 covariates (fresh decomposition of the projected kernel) and the cache-mismatch case
+                 (U, S, h2 of the D = 1 cache with the D = 3 covariates, run_test.sh:47)                  -> n5000_lmm_d3.npz
+    part cap35   pyseer/model.py:316-330 on a design with a quasi-separating covariate: statsmodels' Newton stops at its 35-iteration cap
+                 (SM:base/optimizer.py:407-427) without failing                                          -> n5000_cap35.npz
 
 Runs ONLY in the build container:
     cd /root/repo/tests/golden && PYTHONPATH=_harness:_harness/stubs:/root/reference PYTHONDONTWRITEBYTECODE=1 \
@@ -25,7 +35,7 @@ import pandas as pd
 
 warnings.simplefilter("ignore")
 import statsmodels.formula.api as smf
-from pyseer.model import fit_null, fit_firth, fixed_effects_regression
+from pyseer.model import fit_null, fit_firth, fixed_effects_regression, fit_lineage_effect
 from pyseer.lmm import initialise_lmm, fit_lmm, fit_lmm_block
 from pyseer.classes import LMM
 
@@ -224,8 +234,239 @@ def merge_firth(n):
                                                                           (out[:, -1] == -1).sum()))
 
 
+RANDOM_DUMP = "/root/repo/gpurun_out/r05/c4_random_rows.npz"
+
+
+def part_firth_random(sl):
+    """The reference on rows nobody picked: fit_firth (C4's mode) and fixed_effects_regression (C2N5000's) on the first rows of the bench batch."""
+    i0, n = (int(x) for x in sl.split("/"))
+    d = np.load(RANDOM_DUMP)
+    y, W = glm_design()
+    assert np.array_equal(y, d["y"].astype(float)) and np.array_equal(W, d["W"]), "the dump was made on another design"
+    rows = unpack(d["bits"], N); q = W.shape[1]
+    nl = float(fit_null(y, W, E0, False, firth=False).llf); nf = float(fit_null(y, W, E0, False, firth=True))
+    assert abs(nl - float(d["null_llf"])) < 1e-9 * abs(nl) and abs(nf - float(d["null_firth"])) < 1e-9 * abs(nf)
+    out = np.full((rows.shape[0], 4 + q + 1), np.nan)            # intercept, kbeta, bse, fitll, betas[q], status
+    glm = np.full((rows.shape[0], 5 + q + 3), np.nan)            # prep, pvalue, kbeta, bse, intercept, betas[q], notes, prefilter, filter
+    t0 = time.time()
+    for v in np.arange(rows.shape[0])[i0::n]:
+        af = float(rows[v].mean())
+        if 0.01 <= af <= 0.99:
+            X = np.concatenate((np.ones((N, 1)), rows[v].reshape(-1, 1), W), axis=1)
+            sv = np.zeros(X.shape[1]); sv[0] = np.log(np.mean(y) / (1 - np.mean(y)))
+            try:
+                res = fit_firth(smf.Logit(y, X), sv, X, y); st = 1 if res is not None else 0
+            except Exception:
+                res, st = None, -1
+            if res is not None:
+                ic, kb, be, bse, fitll = res
+                out[v, :4] = [ic, kb, bse, fitll]; out[v, 4:4 + q] = np.asarray(be, dtype=float)
+            out[v, -1] = st
+        else:
+            out[v, -1] = 2                                        # af-filtered upstream: fit_firth never sees it
+        s = fixed_effects_regression("v%d" % v, y if 0.01 <= af <= 0.99 else None, rows[v], W, E0.values, af, b"x", False, None, 1.0, 1.0,
+                                     nl, nf, [], [], False)
+        glm[v, :5] = [nn(s.prep), nn(s.pvalue), nn(s.kbeta), nn(s.bse), nn(s.intercept)]
+        b = np.asarray(s.betas, dtype=float) if s.betas is not None else np.array([])
+        if b.shape == (q,):
+            glm[v, 5:5 + q] = b
+        glm[v, 5 + q:] = [notes_mask(s.notes), int(bool(s.prefilter)), int(bool(s.filter))]
+        print(v, int(out[v, -1]), sorted(s.notes), "%.1f s" % (time.time() - t0), flush=True)
+    np.save("/tmp/n5000_random_part_%d_of_%d.npy" % (i0, n), np.concatenate([out, glm], axis=1))
+
+
+def merge_random(n):
+    d = np.load(RANDOM_DUMP)
+    parts = [np.load("/tmp/n5000_random_part_%d_of_%d.npy" % (i, n)) for i in range(n)]
+    al = parts[0].copy()
+    for i in range(n):
+        al[i::n] = parts[i][i::n]
+    y, W = glm_design(); q = W.shape[1]
+    out, glm = al[:, :4 + q + 1], al[:, 4 + q + 1:]
+    assert np.isfinite(out[:, -1]).all()
+    nf = float(fit_null(y, W, E0, False, firth=True)); nl = float(fit_null(y, W, E0, False, firth=False).llf)
+    np.savez_compressed(os.path.join(OUT, "n5000_random.npz"), N=N, q=q, seed=1002, seed_bits=int(d["seed_bits"]), bits=d["bits"], y=y.astype(np.uint8), W=W,
+                        null_llf=nl, null_firth=nf, firth_main=out[:, :4], firth_betas=out[:, 4:4 + q], firth_ok=out[:, -1].astype(np.int64),
+                        main=glm[:, :5], betas=glm[:, 5:5 + q], notes=glm[:, 5 + q].astype(np.int64), prefilter=glm[:, 6 + q].astype(np.int64),
+                        filter=glm[:, 7 + q].astype(np.int64))
+    print("n5000_random: %d rows; fit_firth fit %d, None %d, exception %d, af-filtered %d; notes %s" % (
+        out.shape[0], (out[:, -1] == 1).sum(), (out[:, -1] == 0).sum(), (out[:, -1] == -1).sum(), (out[:, -1] == 2).sum(),
+        {NOTE_ORDER[i]: int(((glm[:, 5 + q].astype(np.int64) >> i) & 1).sum()) for i in range(9)}))
+
+
+def variant_rows(rng, y01, W, n_rows):
+    """A spread of rows for the OLS / lineage parts: AF grid, random AF, rows tied to the phenotype and to covariates, rare / common rows."""
+    rows = []
+    for af in np.r_[np.linspace(0.02, 0.98, n_rows // 2), rng.uniform(0.02, 0.98, n_rows // 8)]:
+        rows.append((rng.random(N) < af).astype(float))
+    for s_ in (0.1, 0.25, 0.4, -0.2, -0.35):
+        rows.append((rng.random(N) < np.clip(0.3 + s_ * (y01 - 0.5), 0, 1)).astype(float))
+    for j in (0, 1, 7):
+        rows.append((W[:, j] + 0.3 * rng.standard_normal(N) > 0.2).astype(float))
+    for c in (51, 75, 4940):
+        r = np.zeros(N); r[rng.choice(N, c, replace=False)] = 1; rows.append(r)
+    r = np.zeros(N); r[rng.choice(N, 30, replace=False)] = 1; rows.append(r)             # AF 0.006: af-filtered
+    while len(rows) < n_rows:
+        rows.append((rng.random(N) < rng.uniform(0.02, 0.98)).astype(float))
+    return np.array(rows[:n_rows])
+
+
+def part_ols():
+    t0 = time.time()
+    _, W = glm_design()
+    rng = np.random.default_rng(55012)
+    yc = 0.4 - 1.2 * W[:, 0] + 0.8 * W[:, 2] + 0.9 * rng.standard_normal(N)              # continuous phenotype
+    Kv = variant_rows(rng, (yc > np.median(yc)).astype(float), W, 64)
+    Kv[40] = (rng.random(N) < np.clip(0.3 + 0.15 * np.tanh(yc - np.median(yc)), 0, 1)).astype(float)   # causal for the continuous trait
+    Kv[41] = (rng.random(N) < np.clip(0.5 - 0.3 * np.tanh(yc - np.median(yc)), 0, 1)).astype(float)
+    nr = fit_null(yc, W, E0, True)
+    V = Kv.shape[0]; q = W.shape[1]
+    main = np.zeros((V, 5)); betas = np.full((V, q), np.nan); notes = np.zeros(V, dtype=np.int64)
+    pf = np.zeros(V, dtype=np.int64); fl = np.zeros(V, dtype=np.int64)
+    for thr, tag in (((1.0, 1.0), ""), ((0.05, 0.01), "_thr")):
+        for v in range(V):
+            af = float(Kv[v].mean())
+            s = fixed_effects_regression("v%d" % v, yc if 0.01 <= af <= 0.99 else None, Kv[v], W, E0.values, af, b"x", False, None, thr[0], thr[1],
+                                         nr, None, [], [], True)
+            main[v] = [nn(s.prep), nn(s.pvalue), nn(s.kbeta), nn(s.bse), nn(s.intercept)]
+            b = np.asarray(s.betas, dtype=float) if s.betas is not None else np.array([])
+            betas[v] = b if b.shape == (q,) else np.nan
+            notes[v] = notes_mask(s.notes); pf[v] = int(bool(s.prefilter)); fl[v] = int(bool(s.filter))
+        if tag == "":
+            keep = dict(main=main.copy(), betas=betas.copy(), notes=notes.copy(), prefilter=pf.copy(), filter=fl.copy())
+        else:
+            keep.update({"main_thr": main.copy(), "betas_thr": betas.copy(), "notes_thr": notes.copy(), "prefilter_thr": pf.copy(), "filter_thr": fl.copy()})
+    np.savez_compressed(os.path.join(OUT, "n5000_ols.npz"), N=N, q=q, seed=1002, y=yc, W=W, bits=pack(Kv), pret_thr=0.05, lrtt_thr=0.01, **keep)
+    print("n5000_ols: %d rows, %.0f s; notes %s; with thresholds %s" % (V, time.time() - t0, {NOTE_ORDER[i]: int(((keep["notes"] >> i) & 1).sum()) for i in range(9)},
+          {NOTE_ORDER[i]: int(((keep["notes_thr"] >> i) & 1).sum()) for i in range(9)}))
+
+
+def part_lineage():
+    t0 = time.time()
+    y, W = glm_design()
+    rng = np.random.default_rng(55022)
+    lab = rng.integers(0, 12, N)
+    Kv = variant_rows(rng, y, W, 32)
+    for j, l_ in enumerate((0, 3, 7)):                                                    # rows that follow a cluster / an MDS axis
+        Kv[20 + j] = ((lab == l_) ^ (rng.random(N) < 0.03)).astype(float)
+    Kv[23] = (W[:, 4] > 0.1).astype(float); Kv[24] = (W[:, 9] + 0.05 * rng.standard_normal(N) > 0).astype(float)
+    Kv[25] = (lab == 5).astype(float)                                                     # a cluster indicator itself: separation -> None
+    cov = np.c_[(rng.random(N) < 0.4).astype(float), rng.standard_normal(N)]
+    cl = np.zeros((N, 12)); cl[np.arange(N), lab] = 1.0; cl = cl[:, 1:]                   # indicators, one dropped as __main__.py:417-432 does
+    out = {}
+    for tag, lin, c in (("mds", W, cov), ("mds_nocov", W, E0.values), ("clusters", cl, E0.values)):
+        ml = []
+        for v in range(Kv.shape[0]):
+            r = fit_lineage_effect(lin, c, Kv[v])
+            ml.append(-1 if r is None else int(r))
+        out["max_lineage_" + tag] = np.array(ml, dtype=np.int64)
+        print(tag, ml, "%.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "n5000_lineage.npz"), N=N, bits=pack(Kv), W=W, cov=cov, clusters=cl, **out)
+
+
+def part_lmm_d3():
+    t0 = time.time()
+    lin, G, K, y = lmm_design()
+    names = ["s%04d" % i for i in range(N)]
+    tsv = "/tmp/n5000_similarity.tsv"
+    if not os.path.exists(tsv):
+        pd.DataFrame(K, index=names, columns=names).to_csv(tsv, sep="\t")
+    p = pd.Series(y, index=names)
+    rng = np.random.default_rng(55033)
+    cv = np.c_[(rng.random(N) < 0.35).astype(float) + 0.2 * (lin % 3 == 0), rng.standard_normal(N) + 0.5 * y]
+    cov = pd.DataFrame(cv, index=names, columns=["c1", "c2"])
+    cache1 = "/tmp/n5000_lmm_cache_D1.npz"
+    if os.path.exists(cache1):
+        os.remove(cache1)
+    _, lmm1, h2_1 = initialise_lmm(p, E0, tsv, lmm_cache_in=None, lmm_cache_out=cache1)   # D = 1: writes the cache (arr_0 U, arr_1 S, arr_2 [h2])
+    print("D=1 h2 = %.12g (%.0f s)" % (float(h2_1), time.time() - t0), flush=True)
+    _, lmm3, h2_3 = initialise_lmm(p, cov, tsv, lmm_cache_in=None, lmm_cache_out=None)    # D = 3, fresh: eigh of the projected kernel
+    nll3 = float(lmm3.findH2()["nLL"][0])
+    print("D=3 h2 = %.12g nLL = %.12g (%.0f s)" % (float(h2_3), nll3, time.time() - t0), flush=True)
+    _, lmmx, h2_x = initialise_lmm(p, cov, tsv, lmm_cache_in=cache1, lmm_cache_out=None)  # the cache of D = 1 under D = 3 covariates (lmm.py:57-76)
+    assert float(h2_x) == float(h2_1)
+    rows = []
+    for af in np.r_[np.linspace(0.0102, 0.05, 6), np.linspace(0.95, 0.9898, 6), np.linspace(0.06, 0.94, 20)]:
+        rows.append((rng.random(N) < af).astype(float))
+    for j in range(8):
+        rows.append(G[:, 150 + 41 * j].copy())
+    for l_ in (2, 11):
+        rows.append((lin == l_).astype(float))
+    for s_ in (0.15, 0.3, 0.5):
+        rows.append((rng.random(N) < np.clip(0.3 + s_ * (y - 0.5), 0, 1)).astype(float))
+    rows.append((cv[:, 0] > 0.5).astype(float))                                          # a function of a covariate (not in its span: c1 has 4 levels)
+    rows.append(np.ones(N)); rows.append(np.zeros(N))
+    while len(rows) < 64:
+        rows.append((rng.random(N) < rng.uniform(0.02, 0.98)).astype(float))
+    Kv = np.array(rows); X = Kv.T.copy()
+
+    def blk(l_, h):
+        r = fit_lmm_block(l_, float(h), X.copy())
+        return np.stack([r["beta"], r["bse"], r["frac_h2"], r["p_values"]], axis=1)
+    b3 = blk(lmm3, h2_3); bx = blk(lmmx, h2_x)
+    np.savez_compressed(os.path.join(OUT, "n5000_lmm_d3.npz"), N=N, seed=1003, y=y.astype(np.uint8), cov=cv, bits=pack(Kv),
+                        h2_D1=float(h2_1), h2_D3=float(h2_3), nLL_D3=nll3, blk_D3=b3, blk_mismatch=bx, K_trace=np.trace(K), K_sum=K.sum(),
+                        S_top_D3=np.sort(np.asarray(lmm3.S))[-8:], S_top_D1=np.sort(np.asarray(lmmx.S))[-8:])
+    print("n5000_lmm_d3: %d rows, %.0f s" % (Kv.shape[0], time.time() - t0))
+
+
+def part_cap35():
+    """A covariate that quasi-separates the phenotype (every sample with z > 0 has y = 1, every one with z < 0 has y = 0, a tied group at
+    z = 0 carries both): Newton's slope on it grows by about one per iteration and never meets the 1e-8 step tolerance; statsmodels stops at
+    maxiter = 35 with a ConvergenceWarning and returns what it has (SM:base/optimizer.py:407-427), and the reference uses that."""
+    t0 = time.time()
+    rng = np.random.default_rng(55035)
+    q = 3
+    W = rng.standard_normal((N, q))
+    tie = rng.random(N) < 0.04
+    W[tie, 0] = 0.0
+    W /= np.abs(W).max(axis=0)
+    y = (W[:, 0] > 0).astype(float)
+    y[tie] = (rng.random(int(tie.sum())) < 0.5).astype(float)
+    nl_res = fit_null(y, W, E0, False, firth=False)
+    nf = fit_null(y, W, E0, False, firth=True)
+    nl = float(nl_res.llf)
+    print("null: iterations %s converged %s llf %.12g firth %s" % (nl_res.mle_retvals.get("iterations"), nl_res.mle_retvals.get("converged"), nl,
+          nf), flush=True)
+    rows = []
+    for af in np.linspace(0.05, 0.95, 10):
+        rows.append((rng.random(N) < af).astype(float))
+    for s_ in (0.2, -0.3):
+        rows.append((rng.random(N) < np.clip(0.3 + s_ * (y - 0.5), 0, 1)).astype(float))
+    r = np.zeros(N); r[rng.choice(np.where(tie)[0], 60, replace=False)] = 1; rows.append(r)       # carried inside the tied group only
+    r = (rng.random(N) < 0.3).astype(float); rows.append(r * tie + (rng.random(N) < 0.02) * (~tie))
+    Kv = np.array(rows); V = Kv.shape[0]
+    main = np.zeros((V, 5)); betas = np.full((V, q), np.nan); notes = np.zeros(V, dtype=np.int64); its = np.zeros(V, dtype=np.int64); conv = np.zeros(V, dtype=np.int64)
+    pf = np.zeros(V, dtype=np.int64); fl = np.zeros(V, dtype=np.int64)
+    for v in range(V):
+        af = float(Kv[v].mean())
+        X = np.concatenate((np.ones((N, 1)), Kv[v].reshape(-1, 1), W), axis=1)
+        sv = np.zeros(X.shape[1]); sv[0] = np.log(np.mean(y) / (1 - np.mean(y)))
+        try:
+            rr = smf.Logit(y, X).fit(start_params=sv, method="newton", disp=False)
+            its[v] = int(rr.mle_retvals["iterations"]); conv[v] = int(bool(rr.mle_retvals["converged"]))
+        except Exception as e:
+            its[v] = -1
+        s = fixed_effects_regression("v%d" % v, y, Kv[v], W, E0.values, af, b"x", False, None, 1.0, 1.0, nl, nf, [], [], False)
+        main[v] = [nn(s.prep), nn(s.pvalue), nn(s.kbeta), nn(s.bse), nn(s.intercept)]
+        b = np.asarray(s.betas, dtype=float) if s.betas is not None else np.array([])
+        betas[v] = b if b.shape == (q,) else np.nan
+        notes[v] = notes_mask(s.notes); pf[v] = int(bool(s.prefilter)); fl[v] = int(bool(s.filter))
+        print(v, "iterations", its[v], "converged", conv[v], sorted(s.notes), main[v], "%.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "n5000_cap35.npz"), N=N, q=q, y=y.astype(np.uint8), W=W, bits=pack(Kv), null_llf=nl,
+                        null_firth=(np.nan if nf is None else float(nf)), main=main, betas=betas, notes=notes, prefilter=pf, filter=fl,
+                        newton_iterations=its, newton_converged=conv, null_iterations=int(nl_res.mle_retvals["iterations"]))
+    print("n5000_cap35: %d rows, %d at the 35-iteration cap without convergence" % (V, int(((its == 35) & (conv == 0)).sum())))
+
+
 if __name__ == "__main__":
     part = sys.argv[1]
+    if part == "firth_random":
+        part_firth_random(sys.argv[2]); sys.exit(0)
+    if part == "merge_random":
+        merge_random(int(sys.argv[2])); sys.exit(0)
+    if part in ("ols", "lineage", "lmm_d3", "cap35"):
+        {"ols": part_ols, "lineage": part_lineage, "lmm_d3": part_lmm_d3, "cap35": part_cap35}[part](); sys.exit(0)
     if part == "lmm":
         part_lmm()
     elif part == "glm":

@@ -4,7 +4,7 @@ the kinship decomposition of bench.py's C3 workload saved as the reference's --s
 bench's AF mix and written in the packed-cache format (no text involved: this measures the steady state a second run over a k-mer file sees).
 Reports rows/s end to end and the split of a block's time into engine call (H2D + GPU + D2H) / sink (masking, formatting) / write, measured
 with SEERHIP_CLI_TIMING=1; runs the default (overlapped) loop and --serial-sink, and compares their output bytes."""
-import json, os, subprocess, sys, time
+import json, os, resource, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -13,6 +13,7 @@ from pyseer_amd.input import PackedCacheWriter
 from pyseer_amd.packing import row_bytes_for
 
 N = 5000; V = int(os.environ.get("V", 10_000_000)); BLK = int(os.environ.get("BLOCK", 262144))
+LRT = ["--lrt-pvalue", os.environ["E2E_LRT"]] if os.environ.get("E2E_LRT") else []
 d = os.environ.get("E2E_DIR", "/tmp/e2e_c3"); os.makedirs(d, exist_ok=True)
 dev = torch.device("cuda", 0)
 names = ["sample_%05d" % i for i in range(N)]
@@ -48,18 +49,21 @@ for t in [x for x in os.environ.get("E2E_SINK_THREADS", "").split(",") if x]:   
 for name, extra, more_env in runs:
     out = d + "/out_%s.tsv" % name
     env = dict(env0); env.update(more_env)
-    t0 = time.time()
+    t0 = time.time(); ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv", "--lmm",
-                        "--load-lmm", d + "/lmm.npz", "--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + extra,
+                        "--load-lmm", d + "/lmm.npz", "--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + LRT + extra,
                        env=env, stdout=open(out, "w"), stderr=subprocess.PIPE)
-    dt = time.time() - t0
+    dt = time.time() - t0; ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     err = r.stderr.decode()
     tl = [l for l in err.splitlines() if l.startswith("[cli timing]")]
     print("%s: rc %d, %.1f s wall, %.3g rows/s end to end (start-up included), output %.2f GB" % (name, r.returncode, dt, V / dt, os.path.getsize(out) / 1e9))
     for l in tl[-9:]:
         print("   ", l)
     print("   ", err.strip().splitlines()[-4:])
-    res[name] = {"rc": r.returncode, "wall_s": dt, "rows_per_s_wall": V / dt, "output_GB": os.path.getsize(out) / 1e9, "timing": tl[-9:]}
+    res[name] = {"rc": r.returncode, "wall_s": dt, "rows_per_s_wall": V / dt, "output_GB": os.path.getsize(out) / 1e9, "timing": tl[-9:],
+                 "cpu_s_whole_process": cpu_s, "cpu_s_per_million_rows_whole_process": cpu_s / (V / 1e6)}
+    print("    whole process: %.2f CPU-s (user + sys, all threads, start-up included) = %.4f per million rows" % (cpu_s, cpu_s / (V / 1e6)))
 import hashlib
 def digest(p):
     h = hashlib.md5()
@@ -74,5 +78,5 @@ for name, extra, _ in runs[2:]:
         res[name]["identical_to_single_engine"] = digest(d + "/out_%s.tsv" % name) == digest(d + "/out_overlapped.tsv")
         res[name]["rows_per_s_vs_single_engine"] = res[name]["rows_per_s_wall"] / res["overlapped"]["rows_per_s_wall"]
         print(name, "identical to the single-engine output:", res[name]["identical_to_single_engine"], " wall ratio %.3f" % res[name]["rows_per_s_vs_single_engine"])
-o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "r04"); os.makedirs(o, exist_ok=True)
+o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", os.environ.get("E2E_ROUND", "r05")); os.makedirs(o, exist_ok=True)
 json.dump(res, open(o + "/e2e_c3.json", "w"), indent=1)
