@@ -43,6 +43,7 @@ int main(int argc, char **argv)
         fsync(fd); close(fd);
     }
     bool ok = true;
+    if (getenv("PROBE_BLOCKING_DEVICE")) { CK(hipSetDeviceFlags(hipDeviceScheduleBlockingSync)); printf("device flag hipDeviceScheduleBlockingSync set\n"); }
     uint8_t *d = nullptr, *pin[2] = {nullptr, nullptr};
     CK(hipSetDevice(0)); CK(hipMalloc((void **)&d, W)); CK(hipHostMalloc((void **)&pin[0], W, hipHostMallocDefault)); CK(hipHostMalloc((void **)&pin[1], W, hipHostMallocDefault));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -53,6 +54,16 @@ int main(int argc, char **argv)
                w, S / w / 1e9, c, c / (S / 632.0) * 1e9, c / (S / 632.0) * 1e6);
         fflush(stdout);
     };
+    // F: what a WAIT costs the waiting thread: 24 x 160 MB of copies queued, then one wait (CPU-s ~ wall = the wait spins)
+    for (int mode = 0; mode < 3; ++mode) {
+      ok = true; hipEvent_t e; CK(hipEventCreateWithFlags(&e, mode == 2 ? (hipEventBlockingSync | hipEventDisableTiming) : hipEventDisableTiming));
+      for (int k = 0; k < 24; ++k) CK(hipMemcpyAsync(d, pin[k & 1], W, hipMemcpyHostToDevice, st));
+      CK(hipEventRecord(e, st));
+      const double w0 = wall(), c0 = cpu();
+      if (mode == 0) CK(hipStreamSynchronize(st)); else CK(hipEventSynchronize(e));
+      printf("F%d  %s: waited %.4f s wall, %.4f CPU-s (%s)\n", mode, ok ? "ok  " : "FAIL", wall() - w0, cpu() - c0,
+             mode == 0 ? "hipStreamSynchronize" : mode == 1 ? "hipEventSynchronize, default event" : "hipEventSynchronize, hipEventBlockingSync event");
+      CK(hipEventDestroy(e)); }
     // E: PCIe alone
     { ok = true; const double w0 = wall(), c0 = cpu();
       for (size_t o = 0, k = 0; o < S; o += W, ++k) { CK(hipMemcpyAsync(d, pin[k & 1], W, hipMemcpyHostToDevice, st)); }
