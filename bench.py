@@ -579,6 +579,97 @@ def parity_glm(y, W, nl, nf, force_firth, bits_t, out_t, fl_t, N, n_check=64):
     return int(ok.sum()), dev
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# what goes on the ONE JSON line.  Round 4's line was 19 KB (prose in `what` / `ops` / `sample` / `workload`), and the driver keeps the parsed
+# line plus an 8 KB tail: the fixed-effects half of the metric fell off both.  The line now carries numbers; the prose goes to stderr
+# ("bench details ...", printed BEFORE the line) and to gpurun_out/bench_details.json.
+# ---------------------------------------------------------------------------------------------------------------
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "launches", "valu_issue_frac", "frac_at_measured_clock",
+             "sclk_mhz_mean", "power_w_mean", "fp64_equiv_tflops", "hbm_algorithmic_GBps", "mfma_f16_tflops", "int8_macs_per_variant", "algorithmic_bytes_per_launch")
+
+
+def max_dev(d):
+    v = [float(x) for x in d.values() if isinstance(x, (int, float)) and not isinstance(x, bool)]
+    return max(v) if v else None
+
+
+def rounded(o, sig=6):
+    """Floats of a JSON-able object to `sig` significant digits (the line is for reading; full precision is in the details)."""
+    if isinstance(o, float):
+        return float("%.*g" % (sig, o)) if o == o and abs(o) != float("inf") else o
+    if isinstance(o, dict):
+        return {k: rounded(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [rounded(v, sig) for v in o]
+    return o
+
+
+def slim(e):
+    """A secondary measurement reduced to its numbers."""
+    if not isinstance(e, dict):
+        return e
+    out = {k: e[k] for k in ("value", "unit", "steps", "ms_per_step", "n_limbs", "kernel_ms", "frac_of_int8_peak_main_pass", "refined_last_batch",
+                             "parity_checked", "bytes_per_variant_over_pcie", "identical_to_synchronous_call", "contexts", "identical_to_one_context",
+                             "valu_issue_frac", "env", "error") if k in e}
+    if isinstance(e.get("parity_max_rel_dev"), dict) and e["parity_max_rel_dev"]:
+        out["parity_max_rel_dev"] = max_dev(e["parity_max_rel_dev"])
+    if isinstance(e.get("roofline"), dict):
+        out["roofline"] = {k: e["roofline"][k] for k in ROOF_KEYS if k in e["roofline"] and k != "kernel"}
+    if isinstance(e.get("cpu_baseline"), dict):
+        out["cpu_baseline"] = {k: e["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind") if k in e["cpu_baseline"]}
+    for k in ("three_contexts", "pipelined"):
+        if isinstance(e.get(k), dict):
+            out[k] = slim(e[k])
+    if isinstance(e.get("config"), dict) and "workload" in e["config"]:
+        out["workload"] = e["config"]["workload"].split(":")[0]
+    return out
+
+
+def fixed_effects_summary(extra):
+    """BASELINE's metric is "LMM and fixed-effects at N = 5000": the fixed-effects half as top-level numbers of the line."""
+    def one(e):
+        if not isinstance(e, dict) or "value" not in e:
+            return None
+        r = e.get("roofline", {})
+        o = {"value": e["value"], "unit": e.get("unit"), "ms_per_step": e.get("ms_per_step"), "frac": r.get("frac"), "valu_issue_frac": r.get("valu_issue_frac"),
+             "bound": r.get("bound"), "traffic": r.get("traffic"), "contexts": 1}
+        if isinstance(e.get("parity_max_rel_dev"), dict) and e["parity_max_rel_dev"]:
+            o["parity_max_rel_dev"] = max_dev(e["parity_max_rel_dev"])
+        t = e.get("three_contexts")
+        if isinstance(t, dict) and "value" in t:
+            o["three_contexts_value"] = t["value"]
+        return o
+    return {"logistic": one(extra.get("C2N5000")), "firth": one(extra.get("C4")),
+            "workloads": "C2N5000 / C4: 2^18 synthetic k-mers x 5000 samples per step, 10 covariates, rows resident in HBM, ONE engine context"}
+
+
+def emit(res):
+    """Details to stderr and gpurun_out/, then the compact line (the last thing on stdout)."""
+    line = dict(res)
+    if isinstance(res.get("extra"), dict):
+        line["fixed_effects_n5000"] = fixed_effects_summary(res["extra"])
+        line["extra"] = {k: slim(v) for k, v in res["extra"].items()}
+    if isinstance(res.get("roofline"), dict):
+        line["roofline"] = {k: v for k, v in res["roofline"].items() if k not in ("ops", "traffic_source", "traffic_unit", "clock_source")}
+    if isinstance(res.get("cpu_baseline"), dict) and len(json.dumps(res["cpu_baseline"])) > 400:
+        cb = dict(res["cpu_baseline"]); cb["sample"] = str(cb.get("sample", ""))[:160]; line["cpu_baseline"] = cb
+    if isinstance(res.get("three_contexts"), dict):
+        line["three_contexts"] = slim(res["three_contexts"])
+    order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+             "fixed_effects_n5000", "roofline", "cpu_baseline"]
+    line = {**{k: line[k] for k in order if k in line}, **{k: v for k, v in line.items() if k not in order}}
+    details = json.dumps(res)
+    sys.stderr.write("bench details " + details + "\n"); sys.stderr.flush()
+    try:
+        o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(o, exist_ok=True)
+        with open(os.path.join(o, "bench_details.json"), "w") as f:
+            f.write(details + "\n")
+    except OSError:
+        pass
+    print(json.dumps(rounded(line))); sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -760,7 +851,7 @@ def main():
                     res["three_contexts"]["valu_issue_frac"] = vf * res["three_contexts"]["value"] / res["value"]
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, force)
-        print(json.dumps(res))
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

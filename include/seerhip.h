@@ -63,6 +63,12 @@ int         sh_device_count(void);
  * Optional: every other entry point initialises what it needs. */
 int         sh_warmup(int device);
 
+/* How host threads wait for the device: sleeping != 0 asks for waits that SLEEP (hipDeviceScheduleBlockingSync, offered to each device at its
+ * first sh_warmup / sh_create; a device that something else initialised first keeps its mode).  The runtime's default is to spin: one CPU per
+ * waiting stream -- fine for a benchmark, not for a job of several device streams under a CPU quota (the command line asks for sleeping
+ * waits).  Call before the first sh_warmup / sh_create.  Process-wide. */
+void        sh_set_wait_mode(int sleeping);
+
 /* one context per device; n_samples = len(p) of the reference */
 sh_ctx *sh_create(int device, int n_samples);
 void    sh_destroy(sh_ctx *ctx);
@@ -214,16 +220,67 @@ int sh_glm_info(sh_ctx *ctx, int64_t *firth_routed, int64_t *pinv_routed);
 
 /* ---------------------------------------------------------------------------------------------
  * Result sink: array-backed results -> the reference's TSV rows (pyseer/utils.py:39-105 format_output, the print loop of
- * pyseer/__main__.py:805-827).  CPU only (OpenMP).  For every selected row v = sel[r], in order:
+ * pyseer/__main__.py:805-827).  CPU only.  For every selected row v = sel[r], in order:
  *   name \t cols[0][v] \t ... \t cols[ncol-1][v] [\t betas[v*q .. v*q+q) if betas_valid[v]] [\t label | NA] \t notes \n
  * numbers as '%.2E', non-finite -> empty field; notes = names of flag bits 0..8 joined by ','.
  * names/name_off: concatenated variant names as sh_reader_next delivers them.  lineage may be NULL (no column).
  * Returns the number of bytes written, or -(needed+1) when cap is too small (nothing written), -1 on bad arguments.
+ * Formatting runs on the calling thread and the idle workers of the process-wide host pool; any number of threads may call at once
+ * (each owns its text buffers: no lock).
  * --------------------------------------------------------------------------------------------- */
 int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t *sel, int64_t nsel,
                        const double *const *cols, int ncol, const double *betas, int q, const uint8_t *betas_valid,
                        const int32_t *lineage, const char *const *lineage_labels, int n_labels,
                        const uint32_t *flags, char *out, int64_t cap);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Job stream (round 5): blocks of a variant stream in, the TSV text of the rows the run PRINTS and the run's counters out.
+ * Replaces, per block, the reference's print loops pyseer/__main__.py:571-593 (fixed effects) and :805-827 (LMM) over the tuples of
+ * fixed_effects_regression / fit_lmm, with format_output (pyseer/utils.py:39-105) on the rows that pass: rows that are not pre-filtered and
+ * not filtered (or every row with print_filtered, LMM blocks then listing their filtered rows first and NaN-masked as pyseer/lmm.py:160-217
+ * leaves them).  Selection, the counters and the compaction of the printed rows' statistics run on the device (csrc/job_kernels.hip); the host
+ * formats only printed rows.  The stream is pipelined three blocks deep: sh_job_submit queues the upload of block k and the kernels of block
+ * k-1 and returns; sh_job_collect waits (asleep between polls of the block's event) for the OLDEST uncollected block and returns its text, valid until the
+ * calling thread's next sh_job_collect / sh_format_* call.  At most 3 blocks may be submitted and not yet collected.
+ *   bits/row_bytes/V: as sh_lmm_batch;  counts[v]: carriers of variant v (af = counts / n_samples, pyseer/input.py:446);
+ *   names/name_off: concatenated variant names as sh_reader_next delivers them.  All four must stay valid until the block is collected.
+ *   rows_are_dma != 0: `bits` lies in pinned or registered host memory (sh_host_register) and is read by the device where it lies;
+ *   otherwise the rows are copied through a pinned slab by the calling thread and the process-wide host pool.
+ *   counters[0..2] of sh_job_collect: pre-filtered, tested, printed variants of the block (the reference's stderr summary, __main__.py:595-599).
+ * Lineage labels, sample lists and pattern output are not part of the stream (the caller keeps its per-variant path for those options).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct sh_job sh_job;
+sh_job *sh_job_open(sh_ctx *ctx, int lmm, int print_filtered);
+void    sh_job_close(sh_job *job);
+int     sh_job_submit(sh_job *job, const uint8_t *bits, int64_t row_bytes, int64_t V, const int32_t *counts,
+                      const char *names, const int64_t *name_off, int rows_are_dma);
+int     sh_job_collect(sh_job *job, const char **text, int64_t *nbytes, int64_t *counters);
+int64_t sh_job_pending(sh_job *job);
+/* the formatter behind sh_job_collect, callable on its own (tests): nsel compacted records -- idx[r] = the variant's index into names / counts,
+ * flags[r], cols[c][r] (c < ncol), slopes betas[j * betas_stride + r] printed where betas_valid[r] -- as
+ *   name \t counts[idx]/n_samples \t cols... [\t betas...] \t notes \n ; *text is owned by the calling thread (valid until its next call). */
+int64_t sh_format_records(const char *names, const int64_t *name_off, const int32_t *counts, int n_samples, const int32_t *idx, int64_t nsel,
+                          const double *const *cols, int ncol, const double *betas, int64_t betas_stride, int q, const uint8_t *betas_valid,
+                          const uint32_t *flags, const char **text);
+/* Make [p, p + nbytes) (e.g. a window of a read-only file mapping: the packed cache) readable by the device where it lies, so that the rows
+ * cross PCIe by DMA with no CPU copy (hipHostRegister on the enclosing pages; measured 4 ns of CPU per 632-byte row against 21 for the
+ * copy into pinned staging, profiles/r05/host_feed_probe.txt).  `device`: the device whose stream will read it (the registration itself is portable).
+ * Unregister with the same p once the rows have been collected. */
+int     sh_host_register(const void *p, int64_t nbytes, int device);
+int     sh_host_unregister(const void *p);
+/* The host CPU budget (csrc/host_pool.h): every host-side helper of this library -- readers, the stager of pageable rows, the formatter --
+ * draws on ONE persistent pool sized to the CPUs the process may use (affinity mask cut by the cgroup quota), the counterpart of the
+ * reference's `--cpu N`.  sh_set_host_threads overrides the detected number (0 = detect); sh_set_host_streams says how many device streams
+ * (or readers) the caller runs at once, so per-stream helpers take their share (generalises sh_reader_set_concurrency).
+ * sh_host_cpu_seconds: thread CPU seconds spent per host stage so far ("stage=seconds,..."); returns the length, or -(needed+1). */
+int     sh_host_cpus(void);
+void    sh_set_host_threads(int n);
+void    sh_set_host_streams(int n);
+int     sh_host_pool_workers(void);
+int     sh_host_cpu_seconds(char *buf, int cap);
+/* the largest number of threads that were inside sh_format_rows / sh_format_records at the same time (reset != 0 clears it): tests */
+int     sh_format_concurrency_max(int reset);
 
 #ifdef __cplusplus
 }

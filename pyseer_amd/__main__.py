@@ -58,7 +58,10 @@ def _warm_device():
             libc.dlopen.restype = ctypes.c_void_p
             libc.dlopen.argtypes = [ctypes.c_char_p, ctypes.c_int]
             libc.dlopen(_abi.LIB_PATH.encode(), os.RTLD_NOW)
-        _abi.load().sh_warmup(dev)
+        lib = _abi.load()
+        # a job's host threads wait for the device asleep (include/seerhip.h sh_set_wait_mode): the runtime's default spins a CPU per waiting stream
+        lib.sh_set_wait_mode(0 if os.environ.get("SEERHIP_WAIT") == "spin" else 1)
+        lib.sh_warmup(dev)
     except Exception:
         pass
 
@@ -286,6 +289,11 @@ def main(argv=None):
     def make_engines(n):
         """One context per listed device; the same device may be listed twice (two contexts on one GPU: the test of
         the multi-device job path on a one-GPU box)."""
+        wt = globals().get("_warm_thread")
+        if wt is not None:
+            wt.join()                                      # (the device's wait mode is chosen at its first use: by the warm-up, not by a context racing it)
+        from . import _abi as _abi_w
+        _abi_w.load().sh_set_wait_mode(0 if os.environ.get("SEERHIP_WAIT") == "spin" else 1)
         if options.gpus is None:
             return [Engine(n, device=options.gpu)]
         devs = [int(x) for x in options.gpus.split(",")] if "," in options.gpus else list(range(int(options.gpus)))
@@ -407,18 +415,26 @@ def main(argv=None):
                 cache_stamp = (side + ".stamp", stamp)
             else:
                 sys.stderr.write("Cannot write a packed cache next to %s; continuing without\n" % var_file)
+    # ---- the job stream (round 5; include/seerhip.h sh_job_*): when nothing per variant is asked of the host (no lineage fit, no sample lists,
+    # no pattern file, not the cross-check sinks) a block goes to the library as parsed and comes back as the text of its printed rows: the AF
+    # window, the NaN masks, the counters and the choice of rows run on the device, the host formats printed rows only.  Output without
+    # --print-filtered does not depend on where blocks end, so short blocks are coalesced (a 3000-row block is 90 us of GPU time).
+    job_path = ((native or bool(options.load_packed)) and not options.lineage and not options.print_samples and not options.output_patterns
+                and not options.python_sink and not options.serial_sink and os.environ.get("SEERHIP_JOB", "1") != "0")
+    job_block = options.block_size if (options.print_filtered or not job_path) else max(options.block_size, 1 << 16)
     if options.load_packed:
-        blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
-                                           want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
+        blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
+                                           want_patterns=bool(options.output_patterns), want_samples=options.print_samples,
+                                           raw=job_path, device=(engs[0].device if job_path else None))
     elif native and len(kmer_files) > 1:
-        blocks = iter_packed_blocks_native_multi(p, kmer_files, options.min_af, options.max_af, options.block_size,
-                                                 want_patterns=bool(options.output_patterns), want_samples=options.print_samples)
+        blocks = iter_packed_blocks_native_multi(p, kmer_files, options.min_af, options.max_af, job_block,
+                                                 want_patterns=bool(options.output_patterns), want_samples=options.print_samples, raw=job_path)
     elif native:
         if options.save_packed:
             cache_out = PackedCacheWriter(options.save_packed, [str(x) for x in p.index], stamp=cache_stamp)
-        blocks = iter_packed_blocks_native(p, var_file, options.min_af, options.max_af, options.block_size,
+        blocks = iter_packed_blocks_native(p, var_file, options.min_af, options.max_af, job_block,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples,
-                                           save_to=cache_out)
+                                           save_to=cache_out, raw=job_path)
     else:
         blocks = iter_packed_blocks(p, var_type, infile, all_strains, sample_order, options.min_af, options.max_af,
                                     options.max_missing, options.uncompressed, options.block_size)
@@ -429,12 +445,63 @@ def main(argv=None):
     NOTE_AF, NOTE_FIRTH_FAIL = 1, 1 << 6
     q_out = 0
 
+    import collections
     import time as _time
     cli_timing = os.environ.get("SEERHIP_CLI_TIMING") is not None
 
     def new_tm():
         return {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0,
                 "t0w": _time.time(), "rows": 0}
+
+    def run_stream_job(engs, blocks, write_text, tm, stop=None):
+        """One stream of RawBlocks through the library's job stream, block k on context k % len(engs) (each context pipelined three deep:
+        the rows of its next block cross PCIe while the block before runs its kernels and the one before that is written out here).
+        Returns (pre-filtered, tested, printed)."""
+        from .engine import Job
+        jobs = [Job(e_, options.lmm, options.print_filtered) for e_ in engs]
+        prefilter = tested = printed = 0
+        order = collections.deque()                           # the job each block in flight went to, in input order
+
+        def take():
+            nonlocal prefilter, tested, printed
+            jb = order.popleft()
+            t_c = _time.perf_counter()
+            text, cnt, release = jb.collect()
+            tm["engine"] += _time.perf_counter() - t_c
+            prefilter += cnt[0]; tested += cnt[1]; printed += cnt[2]
+            if len(text):
+                t_w = _time.perf_counter()
+                write_text(text)
+                tm["write"] += _time.perf_counter() - t_w
+            if release is not None:
+                release()
+        try:
+            blocks = iter(blocks)
+            k = 0
+            while True:
+                t_r = _time.perf_counter()
+                rb = next(blocks, None)                       # (waiting here = the reader is the slowest stage)
+                tm["reader"] += _time.perf_counter() - t_r
+                if rb is None or (stop is not None and stop.is_set()):
+                    break
+                jb = jobs[k % len(jobs)]
+                while jb.pending() >= Job.DEPTH:
+                    take()
+                t_e = _time.perf_counter()
+                jb.submit(rb.bits, rb.counts, rb.blob, rb.off, rows_are_dma=rb.dma, keep=rb.release)
+                tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
+                order.append(jb)
+                # two blocks stay in flight per context (one uploading, one computing); the third is collected, formatted and written
+                while len(order) > 2 * len(jobs):
+                    take()
+                k += 1
+            while order:
+                take()
+        finally:
+            for jb in jobs:
+                jb.close()
+        tm["rows"] = prefilter + tested; tm["loop"] = _time.perf_counter() - tm["t0"]; tm["overlap"] = True; tm["job"] = True
+        return prefilter, tested, printed
 
     def run_stream(engs, blocks, write_text, write_patterns, tm):
         """One stream of blocks, in order: reader (its own thread inside `blocks`) -> engine calls, block k on engs[k % len(engs)], each engine
@@ -731,25 +798,41 @@ def main(argv=None):
     # four counters summed at the end -- nothing crosses between devices while the job runs).  Input that is only readable front to back
     # (text, gzip) stays one stream whose blocks go to the contexts in turn.
     tms = [new_tm()]
+    import resource as _res
+    from . import _abi as _abi_mod
+    _lib = _abi_mod.load()
+    ru_loop0 = _res.getrusage(_res.RUSAGE_SELF); cpu_stage0 = _abi_mod.host_cpu_seconds(); t_loop0 = _time.perf_counter()
+    thread_cpu = {}                                        # CPU seconds of the Python threads of the block loop, by role (time.thread_time)
     if len(engs) > 1 and options.load_packed:
         import shutil
         import tempfile
         import threading as _th
         G = len(engs)
+        _lib.sh_set_host_streams(G)                        # per-stream helpers (stager, readers) take 1/G of the host CPU budget each
         tms = [new_tm() for _ in range(G)]
+        # part 0 goes straight to stdout, the others to temporary files ($TMPDIR) joined in order at the end: like the reference's and the
+        # single-device run's, the output of a run that fails is partial (what part 0 had printed); the first error stops the other streams
         outs = [None] + [tempfile.TemporaryFile() for _ in range(1, G)]
         pouts = [None] + [tempfile.TemporaryFile() if patterns is not None else None for _ in range(1, G)]
         counts = [None] * G
         errs = [None] * G
+        stop = _th.Event()
 
         def stream_worker(i):
             try:
-                blocks_i = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, options.block_size,
-                                                     want_patterns=bool(options.output_patterns), want_samples=options.print_samples, part=(i, G))
-                wp = None if patterns is None else (patterns.write if i == 0 else pouts[i].write)
-                counts[i] = run_stream([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, wp, tms[i])
+                t_th = _time.thread_time()
+                blocks_i = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
+                                                     want_patterns=bool(options.output_patterns), want_samples=options.print_samples, part=(i, G),
+                                                     raw=job_path, device=(engs[i].device if job_path else None))
+                if job_path:
+                    counts[i] = run_stream_job([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, tms[i], stop)
+                else:
+                    wp = None if patterns is None else (patterns.write if i == 0 else pouts[i].write)
+                    counts[i] = run_stream([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, wp, tms[i])
+                thread_cpu["stream %d loop thread" % i] = _time.thread_time() - t_th
             except BaseException as ex:                    # re-raised below, on the main thread
                 errs[i] = ex
+                stop.set()
         workers = [_th.Thread(target=stream_worker, args=(i,)) for i in range(G)]
         for w_ in workers:
             w_.start()
@@ -771,11 +854,33 @@ def main(argv=None):
                 shutil.copyfileobj(pouts[i], patterns, 1 << 22)
                 pouts[i].close()
         prefilter, tested, printed = (sum(c[j] for c in counts) for j in range(3))
+    elif job_path:
+        t_th = _time.thread_time()
+        prefilter, tested, printed = run_stream_job(engs, blocks, write_stdout, tms[0])
+        thread_cpu["stream 0 loop thread"] = _time.thread_time() - t_th
     else:
         prefilter, tested, printed = run_stream(engs, blocks, write_stdout, None if patterns is None else patterns.write, tms[0])
 
     if cli_timing:
+        # the host budget of the block loop (tools/gpu_e2e_job.py -> profiles/r05/host_budget.json): process CPU seconds (user + sys, every
+        # thread: getrusage) over the loop, the library's own per-stage thread CPU (csrc/host_pool.h), the loop threads' CPU (time.thread_time)
+        ru1 = _res.getrusage(_res.RUSAGE_SELF); st1 = _abi_mod.host_cpu_seconds()
+        rows_all = sum(tm_["rows"] for tm_ in tms)
+        budget = {"rows": int(rows_all), "wall_s": _time.perf_counter() - t_loop0, "streams": len(tms), "job_path": bool(job_path),
+                  "host_cpus": int(_lib.sh_host_cpus()), "pool_workers": int(_lib.sh_host_pool_workers()),
+                  "process_cpu_s": (ru1.ru_utime - ru_loop0.ru_utime) + (ru1.ru_stime - ru_loop0.ru_stime),
+                  "process_user_s": ru1.ru_utime - ru_loop0.ru_utime, "process_sys_s": ru1.ru_stime - ru_loop0.ru_stime,
+                  "library_stage_cpu_s": {k_: st1[k_] - cpu_stage0.get(k_, 0.0) for k_ in st1},
+                  "loop_thread_cpu_s": thread_cpu}
+        import json as _json
+        sys.stderr.write("[cli budget] " + _json.dumps(budget) + "\n")
+    if cli_timing:
         for i, tm in enumerate(tms):
+            if tm.get("job"):
+                sys.stderr.write("[cli timing] stream %d of %d (job stream): %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; in library calls (submit + "
+                                 "collect: launches, the wait for the oldest block, formatting of printed rows) %.2f s, write %.2f s; this thread waited %.2f s for the reader\n"
+                                 % (i, len(tms), tm["blocks"], tm["rows"], tm["loop"], tm["rows"] / max(tm["loop"], 1e-9), tm["engine"], tm["write"], tm["reader"]))
+                continue
             sys.stderr.write("[cli timing] stream %d of %d: %d blocks, %d rows in %.2f s of the block loop = %.3g rows/s; engine calls (H2D + GPU + D2H) %.2f s, sink (masking, "
                              "counters, formatting, write) %.2f s of which formatting %.2f s and write %.2f s; sink %s; this thread waited %.2f s for the reader and %.2f s for the sink's queue\n"
                              % (i, len(tms), tm["blocks"], tm["rows"], tm["loop"], tm["rows"] / max(tm["loop"], 1e-9), tm["engine"], tm["sink"], tm["format"], tm["write"],

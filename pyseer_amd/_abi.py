@@ -22,6 +22,7 @@ SIGNATURES = {
     "sh_last_error": (C.c_char_p, []),
     "sh_device_count": (C.c_int, []),
     "sh_warmup": (C.c_int, [C.c_int]),
+    "sh_set_wait_mode": (None, [C.c_int]),
     "sh_create": (C.c_void_p, [C.c_int, C.c_int]),
     "sh_destroy": (None, [C.c_void_p]),
     "sh_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -68,6 +69,22 @@ SIGNATURES = {
                                    C.c_int64]),
     "sh_glm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sh_glm_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    # the job stream (round 5): blocks in, the text of the printed rows + counters out
+    "sh_job_open": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "sh_job_close": (None, [C.c_void_p]),
+    "sh_job_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "sh_job_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sh_job_pending": (C.c_int64, [C.c_void_p]),
+    "sh_format_records": (C.c_int64, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int64, C.POINTER(c_dp),
+                                      C.c_int, c_dp, C.c_int64, C.c_int, c_u8p, c_u32p, C.POINTER(C.c_void_p)]),
+    "sh_host_register": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "sh_host_unregister": (C.c_int, [C.c_void_p]),
+    "sh_host_cpus": (C.c_int, []),
+    "sh_set_host_threads": (None, [C.c_int]),
+    "sh_set_host_streams": (None, [C.c_int]),
+    "sh_host_pool_workers": (C.c_int, []),
+    "sh_host_cpu_seconds": (C.c_int, [C.c_char_p, C.c_int]),
+    "sh_format_concurrency_max": (C.c_int, [C.c_int]),
 }
 
 _lib = None
@@ -102,6 +119,15 @@ def load():
             raise ImportError("libseerhip ABI version mismatch")
         _lib = lib
     return _lib
+
+
+def host_cpu_seconds():
+    """{stage: thread CPU seconds spent in it so far} for the host stages of the library (csrc/host_pool.h)."""
+    buf = C.create_string_buffer(1024)
+    n = load().sh_host_cpu_seconds(buf, len(buf))
+    if n < 0:
+        return {}
+    return {k: float(v) for k, v in (item.split("=") for item in buf.value.decode().split(","))}
 
 
 def check(rc):

@@ -2,6 +2,9 @@
 // One-off per-run setup is done here in plain C++ (it is O(N^2 D) at most); everything per-variant is a HIP kernel.
 #include "common.h"
 #include "route.h"
+#include "host_pool.h"
+#include <atomic>
+#include <functional>
 #include <string>
 #include <vector>
 #include <thread>
@@ -38,6 +41,10 @@ hipError_t shk_pf_rows(hipStream_t, const uint8_t *, int64_t, int64_t, int, cons
                        double, int, int *, int *, int *, int *, int *, int *, double *, uint32_t *);
 hipError_t shk_dd_gather(hipStream_t, const uint8_t *, int64_t, int64_t, const int *, const int *, uint8_t *);
 hipError_t shk_dd_scatter(hipStream_t, int64_t, int64_t, int, const int *, const int *, const double *, const uint32_t *, double *, uint32_t *);
+hipError_t shk_job_select(hipStream_t, const uint32_t *, const double *, int64_t, int, int, int, int *, long long *, long long *, int32_t *, uint32_t *, double *, int64_t);
+int64_t sh_format_records(const char *, const int64_t *, const int32_t *, int, const int32_t *, int64_t, const double *const *, int, const double *, int64_t, int,
+                          const uint8_t *, const uint32_t *, const char **);
+#define JOB_ROWS_PER_BLOCK_HOST 1024
 }
 #include "glm_api.inc"
 
@@ -148,19 +155,15 @@ static int ensure_staging(sh_ctx *c, int64_t bits_bytes, int64_t out_doubles, in
     return SH_OK;
 }
 
-// user rows -> pinned staging with several host threads: a single-threaded pageable hipMemcpy caps the whole path at ~10 GB/s
+// user rows -> pinned staging: the calling thread and the idle workers of the process-wide pool (host_pool.h), at most this stream's share of
+// the CPU budget.  (Round 4 started up to 16 std::threads per chunk per context, sized from hardware_concurrency(): 256 on the GPU boxes.)
 static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n)
 {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nt = (int)std::min<size_t>(std::min(16u, hw), n / ((size_t)4 << 20) + 1);
-    if (nt <= 1) { std::memcpy(dst, src, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = (n / nt + 63) & ~(size_t)63;
-    for (int t = 0; t < nt; ++t) {
-        const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
-        if (lo < hi) th.emplace_back([=] { std::memcpy(dst + lo, src + lo, hi - lo); });
-    }
-    for (auto &x : th) x.join();
+    shost::CpuScope cs(shost::ST_STAGE_COPY);
+    const size_t piece = (size_t)4 << 20, np = (n + piece - 1) / piece;
+    if (np <= 1) { std::memcpy(dst, src, n); return; }
+    const std::function<void(int64_t)> cp = [&](int64_t i) { const size_t lo = (size_t)i * piece, hi = std::min(n, lo + piece); std::memcpy(dst + lo, src + lo, hi - lo); };
+    shost::pool().run((int64_t)np, 1, cp, shost::ST_STAGE_COPY, shost::per_stream_cpus(2));
 }
 
 // Host-pointer batches, pipelined: the packed rows of chunk i+1 cross PCIe on a copy stream while chunk i runs its kernels
@@ -410,11 +413,28 @@ int sh_device_count(void)
 
 __global__ void k_noop() {}
 
+// How host threads wait for the device (sh_set_wait_mode): 1 = asleep.  The HIP runtime's waits (hipStreamSynchronize, hipEventSynchronize,
+// the device-wide wait inside hipHostUnregister) spin by default -- a CPU per waiting stream, whatever the event's flags; with
+// hipDeviceScheduleBlockingSync set on the device BEFORE its first use they sleep on an interrupt (tools/ubench/host_feed_probe.hip lines F:
+// 0.0705 -> 0.0008 CPU-s for a 70 ms wait).  A job of eight device streams on a 16-CPU quota cannot afford eight spinning threads; a
+// benchmark driven through torch (which initialises the device first) keeps the default.
+static std::atomic<int> g_wait_mode{0};
+static std::atomic<uint64_t> g_wait_applied{0};                     // bit d: the flag was offered to device d
+static void apply_wait_mode(int device)
+{
+    if (g_wait_mode.load() != 1 || device < 0 || device >= 64) return;
+    const uint64_t bit = 1ull << device;
+    if (g_wait_applied.fetch_or(bit) & bit) return;
+    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();   // (a device somebody initialised already keeps its mode)
+}
+void sh_set_wait_mode(int sleeping) { g_wait_mode.store(sleeping ? 1 : 0); }
+
 int sh_warmup(int device)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(SH_ENODEV, "no such HIP device");
     HIPCHK(hipSetDevice(device));
+    apply_wait_mode(device);
     hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -434,6 +454,7 @@ sh_ctx *sh_create(int device, int n_samples)
         g_err = std::string("device is ") + prop.gcnArchName + ", libseerhip is built for gfx950 only"; return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    apply_wait_mode(device);
     sh_ctx *c = new sh_ctx();
     c->device = device; c->N = n_samples;
     if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
@@ -1011,5 +1032,6 @@ int sh_sim_finish(sh_ctx *c, double *K)
 }
 
 #include "glm_api_impl.inc"
+#include "job_api.inc"
 
 }  // extern "C"

@@ -10,6 +10,11 @@ __host__ __device__ constexpr int sidx(int i, int j) { return i * (i + 1) / 2 + 
 // Firth step halving: the two noise rules of the default mode are GlmParams.firth_noise / firth_accept (glm_params.h)
 
 __device__ __forceinline__ double logit_cdf(double x) { return 1.0 / (1.0 + exp(-x)); }    // SM Logit.cdf
+// SM Logit.loglike of a sample with y = 0: log(cdf(-eta)).  cdf(-eta) = exp(-eta) cdf(eta), so it is log(mu) - eta with the logarithm the
+// y = 1 branch needs anyway -- except where mu = cdf(eta) has underflowed (eta < -700: a fit that diverges along a quasi-separating covariate,
+// tests/golden/n5000_cap35.npz row 10), where the identity reads -inf + |eta|; there 1 + exp(eta) == 1 and the reference's value is log(1) = 0.
+__device__ __forceinline__ double ll_y0(double lm, double eta) { return eta < -700.0 ? 0.0 : lm - eta; }
+
 
 // ---- a1 prefilter from the packed bits ------------------------------------------------------------------------------
 __device__ __forceinline__ double glm_prefilter(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int NB64, int N,

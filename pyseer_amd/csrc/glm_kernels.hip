@@ -62,7 +62,7 @@ __device__ __forceinline__ void info_pass(const uint64_t *__restrict__ T, int64_
                 // SM Logit.loglike: log(cdf(q*eta)), q = 2y-1.  y = 1: log(mu).  y = 0: cdf(-eta) = exp(-eta) * cdf(eta), so
                 // log(cdf(-eta)) = log(mu) - eta: one logarithm, no second reciprocal, and no cancellation when mu -> 1.
                 const double lm = log(mu);
-                ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                ll += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));
             }
             if (SCORE) {
                 g[0] += r; g[1] = fma(r, xd, g[1]);
@@ -409,7 +409,7 @@ __device__ __forceinline__ void final_pass_mfma(const uint64_t *__restrict__ T, 
         const double r = yi - mu;
         maxdev = fmax(maxdev, fabs(r));
         const double lm = log(mu);                                            // SM Logit.loglike, as info_pass
-        ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+        ll += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));
         g[0] += r; g[1] += xb ? r : 0.0;
         const double wgt = mu * (1.0 - mu), wx = xb ? wgt : 0.0;
         h00 += wgt; h10 += wx;
@@ -1540,6 +1540,7 @@ __global__ __launch_bounds__(256) void k_glm_slow_blk(const uint64_t *__restrict
     for (int idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t v = wk.slow_list[idx];
         int it = 0, status = 0, reps = 0;                            // thread-0 state
+        bool capped = false;                                         //   the Newton loop ended at its 35th step, still moving
         double llf = NAN, bse1 = NAN;
         __syncthreads();
         if (tid == 0) { for (int a = 0; a < PC; ++a) s_beta[a] = 0.0; s_beta[0] = P.ymean_logit; s_ctl = 0; }
@@ -1565,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_glm_slow_blk(const uint64_t *__restrict
                 mx = fmax(mx, fabs(r));
                 if (want_ll) {
                     const double lm = log(mu);                                                   // as info_pass
-                    acc[NH + PC] += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                    acc[NH + PC] += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));
                 }
 #pragma unroll
                 for (int a = 0; a < PC; ++a) {
@@ -1599,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_glm_slow_blk(const uint64_t *__restrict
 #pragma unroll
                             for (int a = 0; a < PC; ++a) { s_beta[a] = beta[a] + g[a]; moving = moving || (fabs(g[a]) > 1e-8); }
                             ++it;
-                            if (!moving || it >= 35) s_ctl = 1;
+                            if (!moving || it >= 35) { s_ctl = 1; capped = moving; }
                         }
                     }
                 } else {                                             // evaluation at the final beta (k_glm_final<Q, false>)
@@ -1618,7 +1619,9 @@ __global__ __launch_bounds__(256) void k_glm_slow_blk(const uint64_t *__restrict
 #pragma unroll
                             for (int a = 0; a < PC; ++a) { smax = fmax(smax, fabs(g[a])); finite = finite && isfinite(g[a]); }
                             s_ctl = 2;
-                            if (finite) {
+                            // (a fit that stopped at statsmodels' 35-iteration cap without converging -- SM:base/optimizer.py:407-427: a covariate
+                            // that quasi-separates the phenotype -- is reported where it stopped, as the reference does: no further step)
+                            if (finite && !capped) {
 #pragma unroll
                                 for (int a = 0; a < PC; ++a) s_beta[a] = beta[a] + g[a];
                                 if (smax > 5e-7 && ++reps < 6) s_ctl = 1;                      // llf and bse belong to a beta this far from the fixed point: again
@@ -2296,7 +2299,7 @@ __device__ __forceinline__ void blk_info_packed(const uint64_t *__restrict__ T, 
         for (int a = 0; a < PC; ++a) eta = fma(beta[a], x[a], eta);
         const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu);
         const double yi = y[i], lm = log(mu);
-        acc[NH] += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));   // as info_pass
+        acc[NH] += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));   // as info_pass
 #pragma unroll
         for (int a = 0; a < PC; ++a) {
             const double wa = wgt * x[a];

@@ -140,7 +140,7 @@ __device__ __noinline__ void w_info(const uint64_t *__restrict__ T, int64_t Vpad
             const double mu = logit_cdf(eta), wgt = mu * (1.0 - mu), yi = y[i], r = yi - mu;
             maxdev = fmax(maxdev, fabs(r));
             const double lm = log(mu);
-            ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+            ll += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));
 #pragma unroll 1
             for (int a = 0; a < pc; ++a) {
                 if (g) g[a] = fma(r, x[a], g[a]);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_newton_blk(const uint64_t *__r
                         wch[tid] = mu * (1.0 - mu); rch[tid] = r;
                         sc[1] = fmax(sc[1], fabs(r));
                         const double lm = log(mu);
-                        sc[0] += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                        sc[0] += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));
                     } else {
 #pragma unroll 1
                         for (int a = 0; a < 3 * NT; ++a) row[a] = 0.0;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_firth_blk(const uint64_t *__re
                     const double mu = logit_cdf(eta), yi = y[i];
                     wch[tid] = mu * (1.0 - mu);
                     const double lm = log(mu);
-                    ll += (yi == 1.0) ? lm : ((yi == 0.0) ? lm - eta : log(logit_cdf((2.0 * yi - 1.0) * eta)));
+                    ll += (yi == 1.0) ? lm : ((yi == 0.0) ? ll_y0(lm, eta) : log(logit_cdf((2.0 * yi - 1.0) * eta)));
                 } else {
 #pragma unroll 1
                     for (int a = 0; a < 3 * NT; ++a) row[a] = 0.0;

@@ -53,13 +53,18 @@ struct ParChunk {
     SymBuf sym;                                    // PAR_WIN window entries, then the chunk's text as symbols
     size_t n = 0;                                  // symbols of text (sym[PAR_WIN .. PAR_WIN + n))
     uint64_t end_bit = 0; bool hit_final = false, ok = false; const char *err = nullptr;
+    size_t max_syms = 0;                           // a searching thread's bound on the text of its region (0 = none): a false head in a highly compressible
+                                                   // stretch could otherwise grow the buffer to gigabytes before stop_bit; beyond it the decode gives up
+                                                   // (std::bad_alloc, which the caller takes as "not a head") and the producer decodes the region itself
 };
 
 static inline bool par_is_text(const uint16_t *p, const uint16_t *e)
 {
     for (; p < e; ++p) {
         const uint16_t s = *p;
-        if (s < 0x8000 && !(s == '\n' || s == '\t' || s == '\r' || (s >= 32 && s < 127))) return false;
+        // literals: printable ASCII, or a byte >= 0x80 (sample names in UTF-8 / latin-1: until round 5 such a file never yielded an accepted
+        // region and every region was decoded twice); markers (>= 0x8000) stand for unknown bytes of the window
+        if (s < 0x80 && !(s == '\n' || s == '\t' || s == '\r' || (s >= 32 && s < 127))) return false;
     }
     return true;
 }
@@ -75,6 +80,7 @@ static bool par_decode(Decoder &d, const uint8_t *base, const uint8_t *end, ParC
     auto grow = [&](size_t need) {
         const size_t at = (size_t)(out - buf);
         if ((size_t)(lim - out) >= need) return;
+        if (c.max_syms && at + need > PAR_WIN + c.max_syms) throw std::bad_alloc();
         c.sym.resize(std::max(c.sym.size() + need, c.sym.size() + c.sym.size() / 2));
         buf = c.sym.data(); out = buf + at; lim = buf + c.sym.size();
     };

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <emmintrin.h>
 #include "route.h"
+#include "host_pool.h"
 #include "inflate_par.h"
 #include "crc32_clmul.h"
 #include <thread>
@@ -106,31 +107,7 @@ struct NameTable {
 // A small pool of SLEEPING workers (condition variables) instead of an OpenMP team: libgomp's workers spin after every parallel region,
 // and on the 256-thread GPU host 128-256 spinning threads starve the decoding thread (measured: gzip 10.5 k k-mers/s with 128 OpenMP
 // threads, 27.5 k with 32, plain text 48 k vs 226 k).  run(n, fn) calls fn(i) for i in [0, n) with dynamic scheduling and returns when done.
-struct ParPool {
-    std::vector<std::thread> th;
-    std::mutex mu; std::condition_variable cv_work, cv_done;
-    std::function<void(int64_t)> fn; int64_t n = 0, chunk = 1; std::atomic<int64_t> next{0}; int busy = 0; uint64_t gen = 0; bool quit = false;
-    explicit ParPool(int nthreads) {
-        for (int t = 0; t < nthreads; ++t) th.emplace_back([this] {
-            uint64_t seen = 0;
-            for (;;) {
-                { std::unique_lock<std::mutex> lk(mu); cv_work.wait(lk, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
-                work();
-                { std::lock_guard<std::mutex> lk(mu); if (--busy == 0) cv_done.notify_all(); }
-            }
-        });
-    }
-    void work() { for (;;) { const int64_t i0 = next.fetch_add(chunk); if (i0 >= n) return; const int64_t i1 = std::min(n, i0 + chunk); for (int64_t i = i0; i < i1; ++i) fn(i); } }
-    void run(int64_t count, int64_t chunk_, std::function<void(int64_t)> f) {
-        if (count <= 0) return;
-        if (th.empty() || count == 1) { for (int64_t i = 0; i < count; ++i) f(i); return; }
-        { std::lock_guard<std::mutex> lk(mu); fn = std::move(f); n = count; chunk = std::max<int64_t>(1, chunk_); next = 0; busy = (int)th.size(); ++gen; }
-        cv_work.notify_all();
-        work();                                                       // the caller works too
-        std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return busy == 0; });
-    }
-    ~ParPool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv_work.notify_all(); for (auto &t : th) t.join(); }
-};
+using shost::ParPool;          // (host_pool.h: the fixed-size fork-join pool; its size comes from the process-wide CPU budget)
 
 struct MemberEndAt { size_t at; uint32_t crc; };
 struct Slab {
@@ -308,6 +285,8 @@ static void produce_gzip_parallel(sh_reader *r)
     // where the time goes (SEERHIP_HOST_DEBUG: one line on stderr when the stream ends), seconds summed over the threads of a kind
     const bool dbg = std::getenv("SEERHIP_HOST_DEBUG") != nullptr;
     std::atomic<int64_t> ns_wslot{0}, ns_find{0}, ns_dec{0}, n_redo{0}, n_acc{0};
+    std::atomic<bool> give_up{false};                                 // the searched heads keep being wrong (stored / fixed blocks, an alphabet the text test does not know):
+                                                                      // the searching threads stop searching and the producer decodes alone, as produce_gzip does
     int64_t ns_await = 0, ns_redo = 0, ns_trans = 0, ns_put = 0;
     auto now_ns = [] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const int64_t t_begin = now_ns();
@@ -333,7 +312,10 @@ static void produce_gzip_parallel(sh_reader *r)
             for (uint32_t k = 0; k < PAR_WIN; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
             c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0; c.exact = false;
             const int64_t tf0 = dbg ? now_ns() : 0;
-            const uint64_t start = par_find_block(base, end, t->from_bit, t->to_bit == ~0ull ? (uint64_t)LEN * 8 : t->to_bit, *dec, c);
+            const uint64_t region_bytes = ((t->to_bit == ~0ull ? (uint64_t)LEN * 8 : t->to_bit) - t->from_bit) / 8;
+            c.max_syms = (size_t)std::max<uint64_t>(16u << 20, 64 * region_bytes);
+            const uint64_t start = give_up.load(std::memory_order_relaxed) ? ~0ull
+                                 : par_find_block(base, end, t->from_bit, t->to_bit == ~0ull ? (uint64_t)LEN * 8 : t->to_bit, *dec, c);
             const int64_t tf1 = dbg ? now_ns() : 0;
             c.ok = false; c.hit_final = false; c.err = nullptr; c.n = 0;
             if (start != ~0ull) {
@@ -405,6 +387,7 @@ static void produce_gzip_parallel(sh_reader *r)
         if (c->ok && c->start_bit == pos_bit) { ++r->par_accepted; ++n_acc; }
         else {
             ++n_redo;
+            if (n_redo.load() + n_acc.load() >= 8 && n_redo.load() * 4 > (n_redo.load() + n_acc.load()) * 3) give_up.store(true);
             redo.start_bit = pos_bit; redo.stop_bit = t->to_bit;
             if (redo.sym.size() < PAR_WIN + 65536) redo.sym.resize(PAR_WIN + 65536);
             for (uint32_t k = 0; k < PAR_WIN; ++k) redo.sym[k] = (uint16_t)(0x8000u | k);
@@ -452,7 +435,7 @@ static void produce_gzip_parallel(sh_reader *r)
             const size_t want = (size_t)std::min<double>((double)CHMAX, std::max<double>((double)CHMIN, r->par_target / std::max(1.0, ratio)));
             // at most ~768 MB of symbols in flight (a text that compresses 1000 : 1 would otherwise hold 64 regions of 128 MB)
             const double per = std::max(1.0, ratio) * (double)want * 2.0;
-            const int infl = (int)std::min<double>((double)INFL, std::max<double>(2.0, 768.0e6 / per));
+            const int infl = (int)std::min<double>((double)INFL, std::max<double>(2.0, 768.0e6 / (double)shost::host_streams() / per));
             { std::lock_guard<std::mutex> lk(mu); ch_cur = want; infl_cur = infl; }
             cv_w.notify_all();
         }
@@ -530,25 +513,16 @@ static void produce_bgzf(sh_reader *r)
 // Parser / CRC workers per reader: the CPUs this process may really use -- hardware threads cut by the cgroup CPU quota (a GPU box shows 256
 // CPUs under a quota of 16) -- shared between the readers that run at once (sh_reader_set_concurrency: `--kmers a.gz b.gz ...` opens one
 // reader per file, and 8 x 47 workers on 16 CPUs was the oversubscription the writer and the bench already avoid), at most 48, at least 2.
-static std::atomic<int> g_reader_concurrency{1};
 static int reader_threads()
 {
-    long t = (long)std::max(1u, std::thread::hardware_concurrency());
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[32]; long per = 0;
-        if (fscanf(f, "%31s %ld", q, &per) == 2 && q[0] != 'm' && per > 0) { const long qq = atol(q); if (qq > 0) t = std::min(t, (qq + per - 1) / per); }
-        fclose(f);
-    }
-    t = std::min<long>(48, t);
-    const int share = std::max(1, g_reader_concurrency.load());
-    return (int)std::max<long>(2, (t + share - 1) / share);
+    return std::max(2, std::min(48, shost::per_stream_cpus(2)));
 }
 
 extern "C" {
 
 const char *sh_reader_error(void) { return g_rerr.c_str(); }
 
-void sh_reader_set_concurrency(int n_readers) { g_reader_concurrency.store(n_readers < 1 ? 1 : n_readers); }
+void sh_reader_set_concurrency(int n_readers) { shost::streams().store(n_readers < 1 ? 1 : n_readers); }      // (= sh_set_host_streams)
 
 sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int n_samples)
 {
@@ -559,7 +533,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     r->index.build(sample_names, n_samples);
     int nt = reader_threads();
     if (const char *te = std::getenv("SEERHIP_READER_THREADS")) nt = std::max(1, std::atoi(te));
-    r->pool.reset(new ParPool(nt - 1));
+    r->pool.reset(new ParPool(nt - 1, shost::ST_READER_PARSE));
     const char *sel = std::getenv("SEERHIP_READER");
     if (sel && std::string(sel) == "zlib") {
         r->gz = gzopen(path, "rb");
@@ -581,8 +555,9 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     if (const char *pb = sh_route("reader_pad")) r->pad_bytes = std::max<size_t>(32768, (size_t)std::atoll(pb));
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
-    if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1)));
+    if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1), shost::ST_READER_DECODE));
     // one gzip member on several threads (inflate_par.h) unless SEERHIP_READER=serial, or there is nothing to share out
+    r->depth = std::max<size_t>(3, r->depth / (size_t)shost::host_streams());       // several readers at once share the memory as they share the CPUs
     if (const char *cd = sh_route("reader_depth")) r->depth = std::max<size_t>(1, (size_t)std::atoll(cd));
     size_t par_min = 1u << 20;                                      // files below this go through the one-thread decoder
     if (const char *cb = sh_route("reader_chunk")) { r->par_chunk = std::max<size_t>(4096, (size_t)std::atoll(cb)); par_min = 2 * r->par_chunk; }
@@ -593,7 +568,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
         int helpers = std::max(2, std::min(8, nt / 2));
         if (const char *ch = sh_route("reader_helpers")) helpers = std::max(1, std::atoi(ch));
         if (const char *ct = sh_route("reader_target")) r->par_target = std::max(65536.0, std::atof(ct));
-        r->pool_bgzf.reset(new ParPool(helpers));
+        r->pool_bgzf.reset(new ParPool(helpers, shost::ST_READER_DECODE));
     }
     r->producer = std::thread([r, par] {
         if (r->mode == 0) produce_plain(r); else if (r->mode == 1) { if (par) produce_gzip_parallel(r); else produce_gzip(r); } else produce_bgzf(r);

@@ -5,7 +5,7 @@
 //   [\t lineage] \t notes
 // numbers as '%.2E' (utils.py:60-75: '%.2E' % Decimal(x), i.e. the correctly rounded 3-significant-digit form, which glibc's
 // printf also produces), non-finite -> empty field; lineage label or NA; notes joined by ',' in the flag-bit order of
-// include/seerhip.h.  Rows are formatted in parallel (OpenMP) into per-thread buffers and concatenated in order.
+// include/seerhip.h.  Rows are formatted in parts by the calling thread and the process-wide host pool (host_pool.h) and concatenated in order.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -15,10 +15,10 @@
 #include <string>
 #include <vector>
 #include <algorithm>
-#ifdef _OPENMP
-#include <omp.h>
-#endif
+#include <atomic>
+#include <functional>
 #include "../../include/seerhip.h"
+#include "host_pool.h"
 
 static const char *const kNotes[9] = {"af-filter", "pre-filtering-failed", "bad-chisq", "high-bse", "perfectly-separable-data",
                                       "matrix-inversion-error", "firth-fail", "missing-data-error", "lrt-filtering-failed"};
@@ -101,9 +101,10 @@ static inline char *put_num(char *w, double x)
     return w + g_explen[e + 345];
 }
 
-// one thread's output: a malloc'ed buffer grown by doubling (no zero fill, no per-append capacity check: the row loop asks for a row's
-// upper bound once).  The buffers outlive the call (g_parts): a block's 10 - 20 MB of text would otherwise be page-faulted in afresh on
-// every call, under the process's one mmap lock with all threads at it.
+// one part's output: a malloc'ed buffer grown by doubling (no zero fill, no per-append capacity check: the row loop asks for a row's
+// upper bound once).  The buffers outlive the call: a block's 10 - 20 MB of text would otherwise be page-faulted in afresh on every call,
+// under the process's one mmap lock with all threads at it.  They belong to the CALLING thread (thread_local): until round 4 they were one
+// process-wide array behind a mutex held for the whole call, so the sinks of eight device streams formatted one after the other.
 struct alignas(128) Part {                          // (a cache line pair of its own: the row loop updates n per row)
     char *p = nullptr; size_t n = 0, cap = 0;
     ~Part() { free(p); }
@@ -112,71 +113,46 @@ struct alignas(128) Part {                          // (a cache line pair of its
         return p + n;
     }
 };
+static constexpr int kMaxParts = 32;
+struct Parts { Part a[kMaxParts]; };
+static Parts &my_parts() { static thread_local Parts p; return p; }
 
-static Part g_parts[32];
-static std::mutex g_parts_mutex;
+// how many sinks are inside the formatter right now (tests/test_sink_cpu.py: two sinks format concurrently)
+static std::atomic<int> g_inside{0}, g_inside_max{0};
+struct Inside { Inside() { const int n = ++g_inside; int m = g_inside_max.load(); while (n > m && !g_inside_max.compare_exchange_weak(m, n)) {} } ~Inside() { --g_inside; } };
 
-// threads worth starting: the cgroup CPU quota when there is one (a GPU box shows 256 CPUs under a quota of 16; an OpenMP team of 256
-// spinning threads then only steals time from the threads that feed the GPU), at most 32
-static int format_threads()
+// The rows are cut into `nth` parts, part i into the caller's parts[i]; the parts are shared out between the calling thread and whatever
+// workers of the process-wide pool are idle (host_pool.h: one CPU budget for readers, stagers and sinks; nothing is started per call).
+// Row r prints the values at position vp = sel ? sel[r] : r of cols / betas / flags / lineage and the name (and carrier count) of variant
+// np = name_idx ? name_idx[r] : vp.  af_counts != NULL: a first column count / n_samples (the reference's af, input.py:446) before cols.
+static int64_t format_core(const char *names, const int64_t *name_off, const int64_t *sel, const int32_t *name_idx, int64_t nsel,
+                           const int32_t *af_counts, int n_samples, const double *const *cols, int ncol, int64_t betas_stride,
+                           const double *betas, int q, const uint8_t *betas_valid, const int32_t *lineage, const char *const *lineage_labels,
+                           int n_labels, const uint32_t *flags, char *out, int64_t cap, const char **own_text)
 {
-    static const int n = [] {
-        int t = 1;
-#ifdef _OPENMP
-        t = omp_get_max_threads();
-#endif
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[32]; long per = 0;
-            if (fscanf(f, "%31s %ld", q, &per) == 2 && q[0] != 'm' && per > 0) { const long qq = atol(q); if (qq > 0) t = std::min<long>(t, (qq + per - 1) / per); }
-            fclose(f);
-        }
-        return std::max(1, std::min(t, 32));
-    }();
-    return n;
-}
-
-extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t *sel, int64_t nsel,
-                                  const double *const *cols, int ncol, const double *betas, int q, const uint8_t *betas_valid,
-                                  const int32_t *lineage, const char *const *lineage_labels, int n_labels,
-                                  const uint32_t *flags, char *out, int64_t cap)
-{
-    if (!names || !name_off || !sel || !cols || !flags || nsel < 0 || ncol < 1) return -1;
-    if (q > 0 && (!betas || !betas_valid)) return -1;
-    int nth = 1;
-#ifdef _OPENMP
-    nth = format_threads();
-#endif
+    Inside in_;
+    int nth = std::min(shost::host_cpus(), kMaxParts);
     if (nsel < 4096) nth = 1;
     size_t lab_max = 2;                                                    // "NA"
     std::vector<size_t> lab_len((size_t)std::max(n_labels, 0));
     for (int l = 0; l < n_labels; ++l) { lab_len[(size_t)l] = strlen(lineage_labels[l]); lab_max = std::max(lab_max, lab_len[(size_t)l]); }
-    const size_t fixed = (size_t)(ncol + std::max(q, 0)) * 13 + lab_max + 1 + 160 + 2 + 8;  // all but the name: numbers <= 12 + tab (put_num stores 8 bytes at its tail), notes <= 149
-    std::lock_guard<std::mutex> lock(g_parts_mutex);
-    Part *const parts = g_parts;
-    std::vector<int64_t> start((size_t)nth + 1, 0);
-    int64_t total = 0;
-    bool fits = false;
-    // The rows are cut into `nth` parts, part i into parts[i].  The runtime may deliver a smaller team than asked for (OMP_THREAD_LIMIT,
-    // OMP_DYNAMIC, a nested region): every member then takes the parts i = t, t + team, ... so that no part keeps the text of an earlier call.
-#pragma omp parallel num_threads(nth)
-    {
-        int t = 0, team = 1;
-#ifdef _OPENMP
-        t = omp_get_thread_num(); team = omp_get_num_threads();
-#endif
-      for (int part = t; part < nth; part += team) {
+    const size_t fixed = (size_t)(ncol + 1 + std::max(q, 0)) * 13 + lab_max + 1 + 160 + 2 + 8;  // all but the name: numbers <= 12 + tab (put_num stores 8 bytes at its tail), notes <= 149
+    Part *const parts = my_parts().a;
+    const std::function<void(int64_t)> body = [&](int64_t part) {
         const int64_t lo = nsel * part / nth, hi = nsel * (part + 1) / nth;
         Part &s = parts[(size_t)part];
         s.n = 0;
         s.room((size_t)(hi - lo) * 96 + fixed);
         for (int64_t r = lo; r < hi; ++r) {
-            const int64_t v = sel[r];
-            const size_t nl = (size_t)(name_off[v + 1] - name_off[v]);
+            const int64_t v = sel ? sel[r] : r;
+            const int64_t nv = name_idx ? (int64_t)name_idx[r] : v;
+            const size_t nl = (size_t)(name_off[nv + 1] - name_off[nv]);
             char *w = s.room(nl + fixed);
-            memcpy(w, names + name_off[v], nl); w += nl;
+            memcpy(w, names + name_off[nv], nl); w += nl;
+            if (af_counts) { *w++ = '\t'; w = put_num(w, (double)af_counts[nv] / (double)n_samples); }
             for (int c = 0; c < ncol; ++c) { *w++ = '\t'; w = put_num(w, cols[c][v]); }
             if (q > 0 && betas_valid[v])
-                for (int j = 0; j < q; ++j) { *w++ = '\t'; w = put_num(w, betas[(size_t)v * q + j]); }
+                for (int j = 0; j < q; ++j) { *w++ = '\t'; w = put_num(w, betas[(size_t)v * (size_t)(betas_stride == 1 ? q : 1) + (size_t)j * (size_t)betas_stride]); }
             if (lineage) {
                 *w++ = '\t';
                 const int32_t l = lineage[v];
@@ -193,17 +169,54 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
             *w++ = '\n';
             s.n = (size_t)(w - s.p);
         }
-      }
-#pragma omp barrier
-#pragma omp single
-        {
-            for (int i = 0; i < nth; ++i) start[(size_t)i + 1] = start[(size_t)i] + (int64_t)parts[(size_t)i].n;
-            total = start[(size_t)nth];
-            fits = out && total <= cap;
-        }                                                                  // (implicit barrier)
-        if (fits)
-            for (int part = t; part < nth; part += team) memcpy(out + start[(size_t)part], parts[(size_t)part].p, parts[(size_t)part].n);
+    };
+    {
+        shost::CpuScope cs(shost::ST_FORMAT);
+        shost::pool().run(nth, 1, body, shost::ST_FORMAT);
     }
-    if (!fits) return -(total + 1);                     // caller retries with at least `total` bytes
+    if (nth == 1 && own_text) { *own_text = parts[0].p; return (int64_t)parts[0].n; }      // (the caller reads the part itself: no second copy)
+    std::vector<int64_t> start((size_t)nth + 1, 0);
+    for (int i = 0; i < nth; ++i) start[(size_t)i + 1] = start[(size_t)i] + (int64_t)parts[(size_t)i].n;
+    const int64_t total = start[(size_t)nth];
+    if (own_text) {                                                        // gather into a buffer of the calling thread's own
+        static thread_local Part gather;
+        gather.n = 0; gather.room((size_t)total + 16);
+        out = gather.p; cap = total; *own_text = gather.p;
+    }
+    if (!out || total > cap) return -(total + 1);                      // caller retries with at least `total` bytes
+    const std::function<void(int64_t)> cat = [&](int64_t part) { memcpy(out + start[(size_t)part], parts[(size_t)part].p, parts[(size_t)part].n); };
+    {
+        shost::CpuScope cs(shost::ST_FORMAT);
+        shost::pool().run(nth, 1, cat, shost::ST_FORMAT);
+    }
     return total;
+}
+
+extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t *sel, int64_t nsel,
+                                  const double *const *cols, int ncol, const double *betas, int q, const uint8_t *betas_valid,
+                                  const int32_t *lineage, const char *const *lineage_labels, int n_labels,
+                                  const uint32_t *flags, char *out, int64_t cap)
+{
+    if (!names || !name_off || !sel || !cols || !flags || nsel < 0 || ncol < 1) return -1;
+    if (q > 0 && (!betas || !betas_valid)) return -1;
+    return format_core(names, name_off, sel, nullptr, nsel, nullptr, 0, cols, ncol, 1, betas, q, betas_valid, lineage, lineage_labels, n_labels, flags,
+                       out, cap, nullptr);
+}
+
+// The job stream's sink (csrc/job_api.inc): `nsel` compacted records as the device left them -- idx[r] = the variant's row in its block, its
+// flags, its statistics column by column (cols[c][r]; the covariate slopes column-major too: betas[j * stride + r]) -- into text owned by the
+// calling thread (valid until its next call).  Returns the number of bytes.
+int64_t sh_format_records(const char *names, const int64_t *name_off, const int32_t *counts, int n_samples, const int32_t *idx, int64_t nsel,
+                          const double *const *cols, int ncol, const double *betas, int64_t betas_stride, int q, const uint8_t *betas_valid,
+                          const uint32_t *flags, const char **text)
+{
+    return format_core(names, name_off, nullptr, idx, nsel, counts, n_samples, cols, ncol, betas_stride, betas, q, betas_valid, nullptr, nullptr, 0, flags,
+                       nullptr, 0, text);
+}
+
+extern "C" int sh_format_concurrency_max(int reset)
+{
+    const int m = g_inside_max.load();
+    if (reset) g_inside_max.store(0);
+    return m;
 }

@@ -257,4 +257,56 @@ class Engine(object):
         return out_t, flags_t
 
 
-__all__ = ["Engine", "pack_variants", "row_bytes_for"]
+class Job(object):
+    """The job stream of one context (include/seerhip.h sh_job_*): submit blocks of packed rows, collect the TSV text of the rows the run
+    prints and the block's (pre-filtered, tested, printed) counts.  Up to DEPTH blocks may be in flight; collect() returns them in order.
+    Everything a submitted block points at (rows, counts, names) is kept alive here until it has been collected."""
+    DEPTH = 3
+
+    def __init__(self, engine, lmm, print_filtered=False):
+        self._lib = engine._lib
+        self._eng = engine
+        h = self._lib.sh_job_open(engine._h, int(bool(lmm)), int(bool(print_filtered)))
+        if not h:
+            raise _abi.SeerHipError(_abi.SH_EINVAL, self._lib.sh_last_error().decode())
+        self._h = C.c_void_p(h)
+        self._held = []                       # per block in flight: the objects its pointers refer to
+        self._text = C.c_void_p(); self._n = C.c_int64(); self._cnt = (C.c_int64 * 4)()
+
+    def pending(self):
+        return len(self._held)
+
+    def submit(self, bits, counts, names_blob, name_off, rows_are_dma=False, keep=None):
+        """bits (V, row_bytes) uint8, counts (V,) int32, names_blob bytes-like, name_off (V + 1,) int64: C-contiguous arrays / buffers."""
+        V, rb = bits.shape
+        assert bits.dtype == np.uint8 and bits.flags.c_contiguous and counts.dtype == np.int32 and counts.flags.c_contiguous
+        assert name_off.dtype == np.int64 and name_off.flags.c_contiguous and counts.shape[0] == V and name_off.shape[0] == V + 1
+        nb = np.frombuffer(names_blob, dtype=np.uint8) if not isinstance(names_blob, np.ndarray) else names_blob
+        self._held.append((bits, counts, nb, name_off, keep))
+        rc = self._lib.sh_job_submit(self._h, bits.ctypes.data, rb, V, counts.ctypes.data, nb.ctypes.data, name_off.ctypes.data, int(bool(rows_are_dma)))
+        if rc:
+            self._held.pop()
+            _abi.check(rc)
+
+    def collect(self):
+        """-> (memoryview of the oldest block's text, valid until this thread's next collect; (pre-filtered, tested, printed), its keep object)"""
+        _abi.check(self._lib.sh_job_collect(self._h, C.byref(self._text), C.byref(self._n), self._cnt))
+        held = self._held.pop(0)
+        n = self._n.value
+        text = (C.c_char * n).from_address(self._text.value) if n else b""
+        return memoryview(text), (self._cnt[0], self._cnt[1], self._cnt[2]), held[4]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sh_job_close(self._h)
+            self._h = None
+            self._held = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["Engine", "Job", "pack_variants", "row_bytes_for"]

@@ -431,6 +431,26 @@ class _Repeat(object):
         return itertools.repeat(self.v, self.n)
 
 
+class RawBlock(object):
+    """One block as the job stream takes it (engine.Job.submit): the parsed rows and nothing derived from them -- the AF window, the masks,
+    the counters and the choice of the printed rows happen on the device.  dma: the rows may be read by the device where they lie
+    (a registered window of the packed-cache mapping); release(): called once the block has been collected."""
+    __slots__ = ("blob", "off", "counts", "bits", "dma", "release")
+
+    def __init__(self, blob, off, counts, bits, dma=False, release=None):
+        self.blob, self.off, self.counts, self.bits, self.dma, self.release = blob, off, counts, bits, dma, release
+
+    def __len__(self):
+        return int(self.counts.shape[0])
+
+
+def _raw_block(blob, off, counts, bits, dma=False, release=None):
+    off = np.require(off, dtype=np.int64, requirements=["A", "C"]); counts = np.require(counts, dtype=np.int32, requirements=["A", "C"])   # (views of a mapping may be misaligned)
+    for i in np.nonzero(counts == 0)[0]:                    # (read_variant's message, pyseer/input.py:441-443)
+        sys.stderr.write("No observations of " + bytes(blob[off[i]:off[i + 1]]).decode() + " in selected samples\n")
+    return RawBlock(blob, off, counts, bits, dma, release)
+
+
 def _block_from_raw(n, samples, order, names, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples):
     """PackedBlock from one raw block of the native reader / the packed cache (all parsed variants, before the AF filter)."""
     blk = PackedBlock(n, 0)
@@ -464,9 +484,9 @@ def _block_from_raw(n, samples, order, names, blob, off, bits, counts, min_af, m
     return blk
 
 
-def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, save_to=None):
+def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, save_to=None, raw=False):
     """Same PackedBlock stream as iter_packed_blocks for k-mer files, fed by the native reader.  save_to: a PackedCacheWriter that
-    receives every raw block (all parsed variants, before the AF filter)."""
+    receives every raw block (all parsed variants, before the AF filter).  raw: RawBlock objects for the job stream instead."""
     samples = [str(x) for x in p.index]
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
@@ -475,14 +495,17 @@ def iter_packed_blocks_native(p, path, min_af, max_af, block_size, want_patterns
         for bits, counts, blob, off in reader.raw_blocks():
             if save_to is not None:
                 save_to.write_block(blob, off, counts, bits)
-            yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
+            if raw:
+                yield _raw_block(blob, off, counts, bits)
+            else:
+                yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
 
     for blk in prefetched(finished()):
         yield blk
 
 
 def iter_packed_blocks_native_multi(p, paths, min_af, max_af, block_size, want_patterns=False, want_samples=False,
-                                    ahead_bytes=2 << 30):
+                                    ahead_bytes=2 << 30, raw=False):
     """Several k-mer files as ONE stream, in the order given (`--kmers a.gz b.gz ...`), with all of them read at once.
 
     A single gzip stream inflates serially (38 k k-mers/s at N = 5000 on the GPU host, against tens of millions per second of
@@ -551,7 +574,10 @@ def iter_packed_blocks_native_multi(p, paths, min_af, max_af, block_size, want_p
         _abi.load().sh_reader_set_concurrency(1)
     for f in feeds:
         for bits, counts, blob, off in f.blocks():
-            yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
+            if raw:
+                yield _raw_block(blob, off, counts, bits)
+            else:
+                yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -627,12 +653,92 @@ def packed_cache_complete(path):
         return False
 
 
-def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, part=None):
+class _DmaWindows(object):
+    """Windows of the packed-cache mapping registered with the HIP runtime (sh_host_register) so that a block's rows go from the page cache
+    to the device by DMA, with no CPU copy (4 ns of CPU per 632-byte row against 21 for the copy into pinned staging:
+    profiles/r05/host_feed_probe.txt).  Registering is cheap (1.2 ms per 160 MB, also with the device busy) but UNREGISTERING waits for the
+    device to drain (28 ms per call under load, tools/gpu_probe_register.py): so a window spans several stored blocks (up to WINDOW bytes,
+    cut at block boundaries: windows never share a page), is unregistered once all its blocks have been collected, and by the READER thread
+    (which runs two blocks ahead of the device and can afford the wait) when it next registers -- never by the thread that feeds the device."""
+    WINDOW = 1 << 30
+
+    def __init__(self, device):
+        import threading
+        from . import _abi
+        self._lib = _abi.load()
+        self._device = int(device)
+        self._lock = threading.Lock()
+        self._win_of = {}              # stored block -> window
+        self._done = []                # windows whose blocks have all been collected, to unregister
+        self._reader_done = False
+        self.ok = True
+
+    def plan(self, base_addr, extents, lo_blk, hi_blk):
+        j = lo_blk
+        while j < hi_blk:
+            k, lo = j, base_addr + extents[j][0]
+            hi = lo + extents[j][1]
+            while k + 1 < hi_blk and base_addr + extents[k + 1][0] + extents[k + 1][1] - lo <= self.WINDOW:
+                k += 1
+                hi = base_addr + extents[k][0] + extents[k][1]
+            w = {"lo": lo, "n": hi - lo, "blocks": k - j + 1, "taken": 0, "released": 0, "state": 0}     # state 0 new, 1 registered, -1 refused
+            for b in range(j, k + 1):
+                self._win_of[b] = w
+            j = k + 1
+
+    def _unregister_done(self):
+        with self._lock:
+            todo, self._done = self._done, []
+        for w in todo:
+            self._lib.sh_host_unregister(w["lo"])
+
+    def take(self, j):
+        """(dma, release) for stored block j, called on the reader thread just before the block is handed on."""
+        w = self._win_of.get(j)
+        if w is None or not self.ok:
+            return False, None
+        if w["state"] == 0:
+            self._unregister_done()
+            if self._lib.sh_host_register(w["lo"], w["n"], self._device) != 0:
+                w["state"] = -1
+                self.ok = False        # (a file system whose pages cannot be pinned: the rows are staged through pinned memory from here on)
+                if os.environ.get("SEERHIP_CLI_TIMING") is not None:
+                    sys.stderr.write("[cli timing] the packed-cache mapping cannot be registered for DMA (%s): rows are staged through pinned memory\n"
+                                     % self._lib.sh_last_error().decode())
+                return False, None
+            w["state"] = 1
+        if w["state"] != 1:
+            return False, None
+        w["taken"] += 1
+
+        def release():
+            with self._lock:
+                w["released"] += 1
+                last = w["released"] == w["blocks"] or (self._reader_done and w["released"] == w["taken"])
+                if last:
+                    self._done.append(w)
+                finish_here = last and self._reader_done
+            if finish_here:
+                self._unregister_done()    # (the reader has gone: the stream is draining, the device about to be idle)
+        return True, release
+
+    def reader_done(self):
+        with self._lock:
+            self._reader_done = True
+            for w in {id(x): x for x in self._win_of.values()}.values():
+                if w["state"] == 1 and w["released"] == w["taken"] and w not in self._done and w["released"] < w["blocks"]:
+                    self._done.append(w)
+        self._unregister_done()
+
+
+def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, part=None, raw=False, device=None):
     """PackedBlock stream from a packed cache written by --save-packed; the samples (and their order) must be the run's own.
     Stored blocks are re-cut to about `block_size` variants (stored blocks are never split, only merged).
     part = (i, n): only range i of n contiguous ranges of the cache's rows (the multi-GPU job: one range per device,
     pyseer_amd/__main__.py).  Ranges are made of whole blocks of the single stream, so the n parts yield exactly its blocks; they are
-    as equal as block_size allows (a cache of B blocks over n devices: ceil(B/n) against floor(B/n) blocks)."""
+    as equal as block_size allows (a cache of B blocks over n devices: ceil(B/n) against floor(B/n) blocks).
+    raw: RawBlock objects for the job stream; with `device` given, a block that is one stored block (no merge) is handed on as a window of the
+    mapping registered for DMA (sh_host_register: the rows go from the page cache to the device with no CPU copy)."""
     samples = [str(x) for x in p.index]
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
@@ -673,21 +779,24 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
             pos += nbytes
             return at
         lo_blk, hi_blk = 0, None
-        if part is not None:
+        extents = None                                     # (offset, bytes) of every stored block's bit rows, when somebody needs them up front
+        if part is not None or use_dma:
             # index pass: the 16-byte header of every stored block (a few hundred bytes of the mapping are touched).  The single stream merges
             # stored blocks until it holds block_size rows (merged() below); a part owns whole such groups -- the groups whose first row falls
             # into its share of the rows -- so every part hands the engine exactly the blocks the single stream would, and output that depends
             # on where blocks end (fit_lmm's filtered-first order, its stale-k lineage: pyseer/lmm.py:160-217) does not change
             start = pos
-            nvs = []
+            nvs, extents = [], []
             while True:
                 at = need(16)
                 nv, nb = (int(x) for x in np.frombuffer(mm, dtype="<u8", count=2, offset=at))
                 if nv == 0:
                     break
-                need(8 * (nv + 1) + 4 * nv + nb + nv * rb)
+                need(8 * (nv + 1) + 4 * nv + nb)
+                extents.append((need(nv * rb), nv * rb))
                 nvs.append(nv)
             pos = start
+        if part is not None:
             total = sum(nvs)
             i_, n_ = part
             owner, first_row, rows, row0 = [], 0, 0, 0
@@ -700,6 +809,8 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
                     rows = 0
             mine = [j for j, o in enumerate(owner) if o == i_]
             lo_blk, hi_blk = (mine[0], mine[-1] + 1) if mine else (0, 0)
+        if use_dma:
+            windows.plan(np.frombuffer(mm, dtype=np.uint8, count=1).ctypes.data, extents, lo_blk, len(extents) if hi_blk is None else hi_blk)
         j = -1
         while True:
             at = need(16)
@@ -715,9 +826,9 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
             off = np.frombuffer(mm, dtype="<i8", count=nv + 1, offset=need(8 * (nv + 1)))
             counts = np.frombuffer(mm, dtype="<i4", count=nv, offset=need(4 * nv))
             at = need(nb)
-            blob = mm[at:at + nb]
+            blob = np.frombuffer(mm, dtype=np.uint8, count=nb, offset=at) if raw else mm[at:at + nb]      # (raw: a view, the names are only read for printed rows)
             bits = np.frombuffer(mm, dtype=np.uint8, count=nv * rb, offset=need(nv * rb)).reshape(nv, rb)
-            yield blob, off, counts, bits
+            yield blob, off, counts, bits, j
 
     def merged():
         acc, rows = [], 0
@@ -729,17 +840,32 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
         if acc:
             yield acc
 
+    use_dma = raw and device is not None and os.environ.get("SEERHIP_DMA", "1") != "0"
+    windows = _DmaWindows(device) if use_dma else None
+
     def finished():                      # merging and a block's host preparation (6 ms per 262 144 rows) on the reader's thread, ahead of the engine
-        for group in merged():
-            if len(group) == 1:
-                blob, off, counts, bits = group[0]
-            else:
-                blob = b"".join(g[0] for g in group)
-                base = np.cumsum([0] + [len(g[0]) for g in group[:-1]])
-                off = np.concatenate([g[1][:-1] + b for g, b in zip(group, base)] + [np.array([len(blob)], dtype=np.int64)])
-                counts = np.concatenate([g[2] for g in group])
-                bits = np.concatenate([g[3] for g in group], axis=0)
-            yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
+        try:
+            for group in merged():
+                if raw and len(group) == 1:
+                    blob, off, counts, bits, j = group[0]
+                    dma, release = windows.take(j) if windows is not None else (False, None)
+                    yield _raw_block(blob, off, counts, bits, dma, release)
+                    continue
+                if len(group) == 1:
+                    blob, off, counts, bits, _ = group[0]
+                else:
+                    blob = b"".join(bytes(g[0]) for g in group)
+                    base = np.cumsum([0] + [len(g[0]) for g in group[:-1]])
+                    off = np.concatenate([g[1][:-1] + b for g, b in zip(group, base)] + [np.array([len(blob)], dtype=np.int64)])
+                    counts = np.concatenate([g[2] for g in group])
+                    bits = np.concatenate([g[3] for g in group], axis=0)
+                if raw:
+                    yield _raw_block(blob, off, counts, bits)
+                    continue
+                yield _block_from_raw(n, samples, order, None, blob, off, bits, counts, min_af, max_af, want_patterns, want_samples)
+        finally:
+            if windows is not None:
+                windows.reader_done()
 
     for blk in prefetched(finished()):
         yield blk

@@ -1,0 +1,179 @@
+"""The job stream (include/seerhip.h sh_job_*; csrc/job_api.inc, job_kernels.hip): blocks of packed rows in, the text of the printed rows and the
+counters out -- against the path it replaces (host result arrays -> mask_like_fit_lmm -> numpy selects -> sh_format_rows), byte for byte, which
+the CLI tests (tests/test_cli_gpu.py) in turn hold to the reference's own output (print loops pyseer/__main__.py:571-593, 805-827;
+format_output pyseer/utils.py:39-105)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rows(N, V, seed):
+    rng = np.random.default_rng(seed)
+    af = np.where(rng.random(V) < 0.1, rng.uniform(0.0, 0.02, V), rng.uniform(0.02, 0.98, V))
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    from pyseer_amd.engine import pack_variants
+    bits = pack_variants(K)
+    counts = K.sum(axis=1).astype(np.int32)
+    names = [("K%06d" % v) + "ACGT" * int(rng.integers(0, 6)) for v in range(V)]
+    from pyseer_amd.sink import names_blob
+    blob, off = names_blob(names)
+    return bits, counts, blob, off
+
+
+def _old_path(e, lmm, bits, counts, blob, off, n, print_filtered, min_af=0.01, max_af=0.99):
+    """What pyseer_amd/__main__.py run_stream.sink_block does with a block (the round-4 sink), restated for one block."""
+    from pyseer_amd.sink import RowFormatter
+    from pyseer_amd.lmm import mask_like_fit_lmm
+    r = e.lmm_batch(bits) if lmm else e.glm_batch(bits)
+    if lmm:
+        r = mask_like_fit_lmm(r)
+    afs = counts.astype(np.float64) / n
+    on = (afs >= min_af) & (afs <= max_af)
+    keys = ("prep", "pvalue", "beta", "bse", "frac_h2") if lmm else ("prep", "pvalue", "kbeta", "bse", "intercept")
+    cols = [afs] + [np.where(on, r[k], np.nan) for k in keys]
+    flags = np.where(on, r["flags"], np.uint32(1 | (1 << 16))).astype(np.uint32)
+    betas = valid = None
+    if not lmm and r["betas"].shape[1]:
+        betas = r["betas"]; valid = (on & (np.isfinite(r["kbeta"]) | np.isfinite(r["pvalue"]))).astype(np.uint8)
+    pf = (flags & (1 << 16)) != 0; ft = (flags & (1 << 17)) != 0
+    order = np.arange(len(on))
+    if lmm:
+        order = np.concatenate([order[pf], order[~pf]])
+    show = np.ones(len(on), bool) if print_filtered else (~pf & ~ft)
+    sel = order[show[order]]
+    text = RowFormatter().format(blob, off, sel, cols, flags, betas, valid) if len(sel) else b""
+    return text, (int(pf.sum()), int((~pf).sum()), int(len(sel)))
+
+
+def _setup(lmm, N, q=3, pret=1.0, lrtt=1.0, seed=5):
+    from pyseer_amd.engine import Engine
+    rng = np.random.default_rng(seed)
+    e = Engine(N); e.set_af_filter(0.01, 0.99)
+    if lmm:
+        d = np.load(os.path.join(G, "lmm_N300_D3.npz"))
+        assert int(d["N"]) == N
+        e.lmm_setup(d["U"], d["S"], d["y"], d["covar"], float(d["h2"]), filter_pvalue=pret, lrt_pvalue=lrtt)
+    else:
+        from pyseer_amd.model import fit_null
+        W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+        y = (rng.random(N) < 1 / (1 + np.exp(-(0.2 + W[:, 0])))).astype(float)
+        e0 = np.zeros((0, 0))
+        e.glm_setup(y, W, False, fit_null(y, W, e0, False).llf, fit_null(y, W, e0, False, firth=True), pret, lrtt)
+    return e
+
+
+@pytest.mark.parametrize("lmm", [True, False])
+@pytest.mark.parametrize("pret,lrtt,print_filtered", [(1.0, 1.0, False), (0.5, 0.2, False), (0.5, 0.2, True), (1.0, 1e-3, False)])
+def test_job_stream_equals_the_block_sink(lmm, pret, lrtt, print_filtered):
+    """Seven blocks of uneven sizes (one row, not a multiple of the selection kernel's 1024-row groups, more blocks than slots) through one
+    Job, three in flight: text and counters of every block equal the host sink's, in order."""
+    from pyseer_amd.engine import Job
+    N = 300
+    e = _setup(lmm, N, pret=pret, lrtt=lrtt)
+    sizes = [1500, 1, 1024, 3000, 1025, 7, 2047]
+    blocks = [_rows(N, v, 100 + i) for i, v in enumerate(sizes)]
+    want = [_old_path(e, lmm, *b, N, print_filtered) for b in blocks]
+    job = Job(e, lmm, print_filtered)
+    got = []
+    for i, (bits, counts, blob, off) in enumerate(blocks):
+        job.submit(bits, counts, blob, off)
+        while job.pending() > 2:
+            t, c, _ = job.collect(); got.append((bytes(t), c))
+    while job.pending():
+        t, c, _ = job.collect(); got.append((bytes(t), c))
+    job.close(); e.close()
+    assert len(got) == len(want)
+    for i, ((t, c), (wt, wc)) in enumerate(zip(got, want)):
+        assert c == wc, (i, c, wc)
+        assert t == wt, (i, t[:300], wt[:300])
+    assert sum(c[2] for _, c in got) > 0
+    if print_filtered:
+        assert all(c[2] == s for (_, c), s in zip(got, sizes))
+
+
+def test_job_stream_reads_registered_rows_by_dma():
+    """rows_are_dma: the device reads the rows where they lie (sh_host_register on the caller's memory, as the CLI does with the windows of the
+    packed-cache mapping); same text as the staged copy."""
+    from pyseer_amd.engine import Job
+    from pyseer_amd import _abi
+    lib = _abi.load()
+    N = 300
+    e = _setup(True, N)
+    bits, counts, blob, off = _rows(N, 5000, 7)
+    big = np.zeros((3 << 20,), dtype=np.uint8)                       # a page-aligned window well above the 1 MB the CLI bothers with
+    view = big[:bits.size].reshape(bits.shape); view[:] = bits
+    assert lib.sh_host_register(view.ctypes.data, view.nbytes, 0) == 0, lib.sh_last_error()
+    job = Job(e, True)
+    job.submit(view, counts, blob, off, rows_are_dma=True)
+    t1, c1, _ = job.collect(); t1 = bytes(t1)
+    job.submit(bits, counts, blob, off, rows_are_dma=False)
+    t2, c2, _ = job.collect(); t2 = bytes(t2)
+    job.close()
+    assert lib.sh_host_unregister(view.ctypes.data) == 0
+    e.close()
+    assert t1 == t2 and c1 == c2 and c1[2] > 0
+
+
+def test_job_stream_refuses_a_fourth_block_in_flight_and_bad_shapes():
+    from pyseer_amd.engine import Job
+    from pyseer_amd import _abi
+    N = 300
+    e = _setup(True, N)
+    job = Job(e, True)
+    b = _rows(N, 64, 1)
+    for _ in range(3):
+        job.submit(*b)
+    with pytest.raises(_abi.SeerHipError):
+        job.submit(*b)
+    assert job.pending() == 3
+    for _ in range(3):
+        job.collect()
+    with pytest.raises(_abi.SeerHipError):
+        job.collect()
+    narrow = np.zeros((4, 8), dtype=np.uint8)                         # 64 bits < 300 samples
+    with pytest.raises(_abi.SeerHipError):
+        job.submit(narrow, np.zeros(4, np.int32), b"abcd", np.arange(5, dtype=np.int64))
+    job.close(); e.close()
+
+
+def test_two_contexts_two_jobs_concurrently():
+    """Two job streams on two contexts of one device from two host threads (the --gpus job): each returns what it returns alone; their
+    formatting overlaps in time (no process-wide lock in csrc/writer.cpp any more)."""
+    import threading
+    from pyseer_amd.engine import Job
+    from pyseer_amd import _abi
+    lib = _abi.load()
+    N = 300
+    blocks = [_rows(N, 20000, 50 + i) for i in range(6)]
+    e0 = _setup(True, N)
+    want = [_old_path(e0, True, *b, N, True) for b in blocks]
+    e0.close()
+    lib.sh_format_concurrency_max(1)
+    res = {}
+
+    def work(tag):
+        e = _setup(True, N)
+        job = Job(e, True, True)
+        out = []
+        for b in blocks:
+            job.submit(*b)
+            while job.pending() > 2:
+                t, c, _ = job.collect(); out.append((bytes(t), c))
+        while job.pending():
+            t, c, _ = job.collect(); out.append((bytes(t), c))
+        job.close(); e.close()
+        res[tag] = out
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for tag in (0, 1):
+        assert [x[1] for x in res[tag]] == [w[1] for w in want]
+        assert [x[0] for x in res[tag]] == [w[0] for w in want]

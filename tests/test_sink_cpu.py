@@ -120,3 +120,76 @@ for n in (30000, 9000):
         assert r.returncode == 0, r.stderr.decode()[-1500:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] and len(outs[0].splitlines()) == 2
+
+
+def test_two_sinks_format_concurrently():
+    """Round 4 held a process-wide mutex for the whole of sh_format_rows (one shared array of text buffers), so the sinks of a --gpus job
+    formatted one after the other.  Now every calling thread owns its buffers: two threads are inside the formatter at the same time
+    (sh_format_concurrency_max) and each gets exactly the text it gets alone."""
+    import threading
+    from pyseer_amd import _abi
+    from pyseer_amd.sink import RowFormatter, names_blob
+    lib = _abi.load()
+    rng = np.random.default_rng(3)
+    n = 300000
+    names = ["K%d" % i for i in range(n)]
+    blob, off = names_blob(names)
+    jobs = []
+    for s in range(2):
+        cols = [rng.normal(size=n) * 10.0 ** rng.integers(-30, 30, n) for _ in range(6)]
+        flags = rng.integers(0, 512, n).astype(np.uint32)
+        jobs.append((cols, flags, np.arange(n, dtype=np.int64)))
+    alone = [RowFormatter().format(blob, off, sel, cols, flags) for cols, flags, sel in jobs]
+    lib.sh_format_concurrency_max(1)
+    out = [None, None]
+    go = threading.Barrier(2)
+
+    def work(i):
+        f = RowFormatter()
+        cols, flags, sel = jobs[i]
+        go.wait()
+        for _ in range(6):
+            out[i] = f.format(blob, off, sel, cols, flags)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert out[0] == alone[0] and out[1] == alone[1]
+    assert lib.sh_format_concurrency_max(0) == 2
+    assert lib.sh_host_pool_workers() <= max(0, lib.sh_host_cpus() - 1)      # one persistent pool, never more workers than the budget
+
+
+def test_format_records_equals_format_rows():
+    """sh_format_records (the job stream's sink: compacted records, names and af by variant index) prints what sh_format_rows prints for the
+    same rows with the af column made by the caller."""
+    import ctypes as C
+    from pyseer_amd import _abi
+    from pyseer_amd.sink import RowFormatter, names_blob
+    lib = _abi.load()
+    rng = np.random.default_rng(4)
+    nv, n_samples, q = 20000, 777, 3
+    names = ["V%d%s" % (i, "T" * (i % 5)) for i in range(nv)]
+    blob, off = names_blob(names)
+    counts = rng.integers(0, n_samples + 1, nv).astype(np.int32)
+    idx = np.sort(rng.choice(nv, 9000, replace=False)).astype(np.int32)
+    nsel = idx.shape[0]; cap = nsel + 37
+    cols = rng.normal(size=(5 + q, cap)) * 10.0 ** rng.integers(-200, 200, (5 + q, cap)); cols[1, ::7] = np.nan; cols[2, ::7] = np.nan
+    flags = rng.integers(0, 512, nsel).astype(np.uint32)
+    valid = (np.isfinite(cols[2, :nsel]) | np.isfinite(cols[1, :nsel])).astype(np.uint8)
+    cp = (_abi.c_dp * 5)(*[cols[a].ctypes.data_as(_abi.c_dp) for a in range(5)])
+    text = C.c_void_p()
+    n = lib.sh_format_records(blob, off.ctypes.data_as(C.POINTER(C.c_int64)), counts.ctypes.data_as(C.POINTER(C.c_int32)), n_samples,
+                              idx.ctypes.data_as(C.POINTER(C.c_int32)), nsel, cp, 5, cols[5].ctypes.data_as(_abi.c_dp), cap, q,
+                              valid.ctypes.data_as(_abi.c_u8p), flags.ctypes.data_as(_abi.c_u32p), C.byref(text))
+    got = C.string_at(text.value, n)
+    # the same through sh_format_rows: values scattered back to variant positions
+    full = [np.full(nv, np.nan) for _ in range(6)]
+    full[0] = counts.astype(np.float64) / n_samples
+    for a in range(5):
+        full[a + 1][idx] = cols[a, :nsel]
+    fb = np.full((nv, q), np.nan); fb[idx] = cols[5:, :nsel].T
+    fv = np.zeros(nv, np.uint8); fv[idx] = valid
+    ff = np.zeros(nv, np.uint32); ff[idx] = flags
+    want = RowFormatter().format(blob, off, idx.astype(np.int64), full, ff, fb, fv)
+    assert got == want

@@ -100,6 +100,41 @@ int main(int argc, char **argv)
       printf("    (%s: %s; register %.3f s, unregister %.3f s of the wall time; copies synchronous here)\n", nm,
              ro == 0 ? "MAP_SHARED read-only mapping, default flags" : ro == 1 ? "MAP_SHARED read-only mapping, hipHostRegisterReadOnly" : "MAP_PRIVATE writable mapping, default flags", treg, tunreg);
       munmap(m, S); close(fd); }
+    // G: as the command line does it (pyseer_amd/input.py): windows at odd offsets of ONE mapping, registered one ahead of the copy, unregistered after it
+    for (int var = 0; var < 4; ++var) {
+      ok = true; int fd = open(path.c_str(), O_RDONLY);
+      void *m = mmap(nullptr, S, PROT_READ, MAP_SHARED, fd, 0);
+      if (var & 1) madvise(m, S, MADV_SEQUENTIAL);
+      const size_t skew = (var & 2) ? 1234567 : 0, pg = 4096;
+      const double w0 = wall(), c0 = cpu(); double treg = 0, tunreg = 0, tcopy = 0;
+      auto win = [&](size_t o, uintptr_t &lo, size_t &len) { const size_t n = std::min(W, S - o); const uintptr_t a = (uintptr_t)m + o + (o ? skew : 0), b = std::min((uintptr_t)m + S, a + n);
+                                                               lo = a & ~(pg - 1); len = ((b + pg - 1) & ~(pg - 1)) - lo; if (lo + len > (uintptr_t)m + S) len = (uintptr_t)m + S - lo; };
+      uintptr_t lo0; size_t len0; win(0, lo0, len0);
+      { const double t0 = wall(); CK(hipHostRegister((void *)lo0, len0, hipHostRegisterDefault)); treg += wall() - t0; }
+      for (size_t o = 0; o < S && ok; o += W) {
+          uintptr_t lo, lo1 = 0; size_t len, len1 = 0; win(o, lo, len);
+          const double t1 = wall();
+          CK(hipMemcpyAsync(d, (void *)lo, std::min(len, W), hipMemcpyHostToDevice, st));
+          if (o + W < S) { win(o + W, lo1, len1); if (lo1 < lo + len) { len1 -= (lo + len - lo1); lo1 = lo + len; }      // (windows must not overlap)
+                           const double t0 = wall(); CK(hipHostRegister((void *)lo1, len1, hipHostRegisterDefault)); treg += wall() - t0; }
+          CK(hipStreamSynchronize(st));
+          const double t2 = wall(); tcopy += t2 - t1;
+          CK(hipHostUnregister((void *)lo)); tunreg += wall() - t2; }
+      char nm[8]; snprintf(nm, sizeof nm, "G%d", var);
+      report(nm, wall() - w0, cpu() - c0, ok);
+      printf("    (%s: madvise(SEQUENTIAL) %s, windows %s; register %.3f s (%.1f ms per window), unregister %.3f s, copy + overlapped register %.3f s)\n", nm, (var & 1) ? "yes" : "no",
+             (var & 2) ? "at odd offsets" : "page-aligned", treg, treg / ((S + W - 1) / W) * 1e3, tunreg, tcopy);
+      munmap(m, S); close(fd); }
+    // H: the whole mapping registered once
+    { ok = true; int fd = open(path.c_str(), O_RDONLY); void *m = mmap(nullptr, S, PROT_READ, MAP_SHARED, fd, 0);
+      const double w0 = wall(), c0 = cpu();
+      const double t0 = wall(); CK(hipHostRegister(m, S, hipHostRegisterDefault)); const double treg = wall() - t0;
+      for (size_t o = 0; o < S && ok; o += W) CK(hipMemcpyAsync(d, (uint8_t *)m + o, std::min(W, S - o), hipMemcpyHostToDevice, st));
+      CK(hipStreamSynchronize(st));
+      const double t2 = wall(); CK(hipHostUnregister(m)); const double tun = wall() - t2;
+      report("H", wall() - w0, cpu() - c0, ok);
+      printf("    (H: one registration of the whole mapping: register %.3f s, unregister %.3f s)\n", treg, tun);
+      munmap(m, S); close(fd); }
     // D: O_DIRECT
     { ok = true; int fd = open(path.c_str(), O_RDONLY | O_DIRECT);
       if (fd < 0) { printf("D   O_DIRECT open failed: %s\n", strerror(errno)); }
