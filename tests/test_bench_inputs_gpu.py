@@ -230,7 +230,8 @@ def test_bench_ranks_on_one_gpu(tmp_path, world):
     d = json.loads(line)
     assert d["n_gpus"] == world and d["world"] == world and len(d["per_rank_value"]) == world and d["finite_fraction"] == 1.0
     assert d["parity_checked"] == 64 and max(d["parity_max_rel_dev"].values()) < 1e-9
-    assert abs(d["value"] - world * vs * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    # (the line prints six significant digits of value and ms_per_step)
+    assert abs(d["value"] - world * vs * 2 / (d["ms_per_step"] * 2e-3)) < 1e-5 * d["value"]
     assert "cpu_baseline" not in d                                  # N = 1 only
     assert d["rccl_ranks_seen"] == world and d["collective_backend"] == "gloo"
 
