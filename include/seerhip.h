@@ -168,6 +168,18 @@ int sh_glm_batch_async(sh_ctx *ctx, const uint8_t *bits, int64_t row_bytes, int6
  * (3(q+2) + 1.5 (q+2)(q+3)/2 + 6) x 8 bytes per variant, 0.9 GB for 2^20 variants at q = 10); sh_glm_batch cuts host batches into
  * 2^18-variant chunks.  A variant's result does not depend on what else is in its batch or on the batch size. */
 int sh_glm_batch_dev(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
+/* The same batch on one of the context's LANES (csrc/lanes_api.inc; the counterpart of the reference's pool of `--cpu N` workers over
+ * blocks of variants, pyseer/__main__.py:541-568): a lane is a worker thread with its own stream and per-batch workspaces, set up from the
+ * arguments sh_glm_setup was called with.  The call records an event on the context's stream (the rows are ready there), hands the batch to
+ * the next free lane and returns; batches of consecutive calls run side by side on the device (one stream of fixed-effects batches leaves it
+ * idle between its per-variant kernels and behind the list-length read-backs of its launch code).  d_out / d_flags of a call are complete
+ * after sh_wait(ctx) -- which also reports the first error of a lane -- and bit-identical to sh_glm_batch_dev's (a batch is still one
+ * sh_glm_batch_dev on one stream).  At most 2 x lanes batches are accepted before the call blocks.  sh_set_lanes: 1..8, default 3; changing
+ * it waits for the lanes and tears them down (they are created at the next use).  The job stream (sh_job_*) of a fixed-effects model
+ * computes its blocks on the lanes too. */
+int sh_glm_batch_dev_async(sh_ctx *ctx, const void *d_bits, int64_t row_bytes, int64_t V, void *d_out, void *d_flags);
+int sh_set_lanes(sh_ctx *ctx, int n);
+int sh_get_lanes(sh_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * Lineage effect (replaces pyseer/model.py:151 fit_lineage_effect): logistic regression of each VARIANT on
@@ -242,7 +254,7 @@ int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t
  * leaves them).  Selection, the counters and the compaction of the printed rows' statistics run on the device (csrc/job_kernels.hip); the host
  * formats only printed rows.  The stream is pipelined three blocks deep: sh_job_submit queues the upload of block k and the kernels of block
  * k-1 and returns; sh_job_collect waits (asleep between polls of the block's event) for the OLDEST uncollected block and returns its text, valid until the
- * calling thread's next sh_job_collect / sh_format_* call.  At most 3 blocks may be submitted and not yet collected.
+ * calling thread's next sh_job_collect / sh_format_* call.  At most sh_job_depth(job) blocks may be submitted and not yet collected.
  *   bits/row_bytes/V: as sh_lmm_batch;  counts[v]: carriers of variant v (af = counts / n_samples, pyseer/input.py:446);
  *   names/name_off: concatenated variant names as sh_reader_next delivers them.  All four must stay valid until the block is collected.
  *   rows_are_dma != 0: `bits` lies in pinned or registered host memory (sh_host_register) and is read by the device where it lies;
@@ -257,6 +269,7 @@ int     sh_job_submit(sh_job *job, const uint8_t *bits, int64_t row_bytes, int64
                       const char *names, const int64_t *name_off, int rows_are_dma);
 int     sh_job_collect(sh_job *job, const char **text, int64_t *nbytes, int64_t *counters);
 int64_t sh_job_pending(sh_job *job);
+int     sh_job_depth(sh_job *job);     /* blocks that may be submitted and not yet collected: 3 (LMM), 2 + lanes (fixed effects) */
 /* the formatter behind sh_job_collect, callable on its own (tests): nsel compacted records -- idx[r] = the variant's index into names / counts,
  * flags[r], cols[c][r] (c < ncol), slopes betas[j * betas_stride + r] printed where betas_valid[r] -- as
  *   name \t counts[idx]/n_samples \t cols... [\t betas...] \t notes \n ; *text is owned by the calling thread (valid until its next call). */

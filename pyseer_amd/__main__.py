@@ -454,7 +454,7 @@ def main(argv=None):
                 "t0w": _time.time(), "rows": 0}
 
     def run_stream_job(engs, blocks, write_text, tm, stop=None):
-        """One stream of RawBlocks through the library's job stream, block k on context k % len(engs) (each context pipelined three deep:
+        """One stream of RawBlocks through the library's job stream, block k on context k % len(engs) (each context pipelined Job.depth deep:
         the rows of its next block cross PCIe while the block before runs its kernels and the one before that is written out here).
         Returns (pre-filtered, tested, printed)."""
         from .engine import Job
@@ -485,14 +485,14 @@ def main(argv=None):
                 if rb is None or (stop is not None and stop.is_set()):
                     break
                 jb = jobs[k % len(jobs)]
-                while jb.pending() >= Job.DEPTH:
+                while jb.pending() >= jb.depth:
                     take()
                 t_e = _time.perf_counter()
                 jb.submit(rb.bits, rb.counts, rb.blob, rb.off, rows_are_dma=rb.dma, keep=rb.release)
                 tm["engine"] += _time.perf_counter() - t_e; tm["blocks"] += 1
                 order.append(jb)
-                # two blocks stay in flight per context (one uploading, one computing); the third is collected, formatted and written
-                while len(order) > 2 * len(jobs):
+                # depth - 1 blocks stay in flight per context (one uploading, one computing per lane); the next is collected, formatted and written
+                while len(order) > (jobs[0].depth - 1) * len(jobs):
                     take()
                 k += 1
             while order:

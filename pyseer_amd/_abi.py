@@ -75,6 +75,10 @@ SIGNATURES = {
     "sh_job_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sh_job_collect": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sh_job_pending": (C.c_int64, [C.c_void_p]),
+    "sh_job_depth": (C.c_int, [C.c_void_p]),
+    "sh_glm_batch_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sh_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "sh_get_lanes": (C.c_int, [C.c_void_p]),
     "sh_format_records": (C.c_int64, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int64, C.POINTER(c_dp),
                                       C.c_int, c_dp, C.c_int64, C.c_int, c_u8p, c_u32p, C.POINTER(C.c_void_p)]),
     "sh_host_register": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),

@@ -4,6 +4,9 @@
 #include "route.h"
 #include "host_pool.h"
 #include <atomic>
+#include <deque>
+#include <mutex>
+#include <condition_variable>
 #include <functional>
 #include <string>
 #include <vector>
@@ -54,9 +57,14 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 template <typename T> static hipError_t dmalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)); }
 
+struct sh_lanes;
+// what sh_glm_setup was called with: the lanes of the context (lanes_api.inc) are set up from it
+struct GlmSetupArgs { std::vector<double> y, W; int q = 0, continuous = 0, force_firth = 0; double null_llf = 0, null_firth = 0, pret = 1, lrtt = 1; };
 struct sh_ctx {
     int device = 0, N = 0;
     hipStream_t stream = nullptr;
+    // ---- lanes (sh_glm_batch_dev_async, the job stream): worker threads with their own sub-context and stream, lanes_api.inc
+    sh_lanes *lanes = nullptr; int n_lanes = 3; bool is_lane = false; GlmSetupArgs glm_args;
     double min_af = 0.0, max_af = 1.0; int af_on = 0;
     // common per-run constants
     int NT = 0, Np = 0, NB64 = 0, NB64p = 0;
@@ -122,6 +130,10 @@ struct sh_ctx {
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
 };
 
+static void lanes_destroy(sh_ctx *c);
+static int lanes_wait(sh_ctx *c);
+static void lanes_set_timing(sh_ctx *c, int on);
+static int lanes_add_timing(sh_ctx *c, double *total_ms, int64_t *launches);
 static void free_ws(sh_ctx *c)
 {
     hipFree(c->d_T); hipFree(c->d_t11); hipFree(c->d_t01); hipFree(c->d_m); hipFree(c->d_xky); hipFree(c->d_dg);
@@ -468,6 +480,7 @@ void sh_destroy(sh_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    lanes_destroy(c);
     free_ws(c);
     if (c->h_nkeep) hipHostFree(c->h_nkeep);
     if (c->h_af_cnt) hipHostFree(c->h_af_cnt);
@@ -501,6 +514,7 @@ int sh_set_timing(sh_ctx *c, int on)
     if (!c) return fail(SH_EINVAL, "null ctx");
     for (auto &p : c->tev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     c->tev.clear(); c->timing = on;
+    if (c->lanes) { const int rc = lanes_wait(c); if (rc) return rc; lanes_set_timing(c, on); }
     return SH_OK;
 }
 
@@ -510,8 +524,11 @@ int sh_get_timing(sh_ctx *c, double *total_ms, int64_t *launches)
     HIPCHK(hipSetDevice(c->device));
     double tot = 0;
     for (auto &p : c->tev) { HIPCHK(hipEventSynchronize(p.second)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, p.first, p.second)); tot += ms; }
+    int64_t nl = (int64_t)c->tev.size();
+    // (batches of the lanes: every batch's own span on its lane's stream -- spans of different lanes overlap in time)
+    if (c->lanes) { const int rc = lanes_wait(c); if (rc) return rc; const int r2 = lanes_add_timing(c, &tot, &nl); if (r2) return r2; }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int64_t)c->tev.size();
+    if (launches) *launches = nl;
     return SH_OK;
 }
 
@@ -965,7 +982,9 @@ int sh_wait(sh_ctx *c)
 {
     if (!c) return fail(SH_EINVAL, "null ctx");
     HIPCHK(hipSetDevice(c->device));
-    return drain_pending(c);
+    const int rc = drain_pending(c);
+    const int rl = lanes_wait(c);                                      // (batches handed to the lanes: sh_glm_batch_dev_async)
+    return rc ? rc : rl;
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -1032,6 +1051,7 @@ int sh_sim_finish(sh_ctx *c, double *K)
 }
 
 #include "glm_api_impl.inc"
+#include "lanes_api.inc"
 #include "job_api.inc"
 
 }  // extern "C"

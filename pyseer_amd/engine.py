@@ -256,12 +256,24 @@ class Engine(object):
                                               C.c_void_p(flags_t.data_ptr())))
         return out_t, flags_t
 
+    def glm_batch_dev_async(self, bits_t, out_t, flags_t):
+        """The same batch on one of the context's lanes (sh_glm_batch_dev_async): returns at once; out_t / flags_t are complete after wait().
+        The caller keeps the three tensors alive (and the rows unchanged) until then."""
+        V, rb = bits_t.shape
+        _abi.check(self._lib.sh_glm_batch_dev_async(self._h, C.c_void_p(bits_t.data_ptr()), rb, V, C.c_void_p(out_t.data_ptr()),
+                                                    C.c_void_p(flags_t.data_ptr())))
+
+    def set_lanes(self, n):
+        _abi.check(self._lib.sh_set_lanes(self._h, int(n)))
+
+    def get_lanes(self):
+        return int(self._lib.sh_get_lanes(self._h))
+
 
 class Job(object):
     """The job stream of one context (include/seerhip.h sh_job_*): submit blocks of packed rows, collect the TSV text of the rows the run
-    prints and the block's (pre-filtered, tested, printed) counts.  Up to DEPTH blocks may be in flight; collect() returns them in order.
+    prints and the block's (pre-filtered, tested, printed) counts.  Up to self.depth blocks may be in flight; collect() returns them in order.
     Everything a submitted block points at (rows, counts, names) is kept alive here until it has been collected."""
-    DEPTH = 3
 
     def __init__(self, engine, lmm, print_filtered=False):
         self._lib = engine._lib
@@ -270,6 +282,7 @@ class Job(object):
         if not h:
             raise _abi.SeerHipError(_abi.SH_EINVAL, self._lib.sh_last_error().decode())
         self._h = C.c_void_p(h)
+        self.depth = int(self._lib.sh_job_depth(self._h))      # blocks in flight at most: 3 (LMM), 2 + lanes (fixed effects)
         self._held = []                       # per block in flight: the objects its pointers refer to
         self._text = C.c_void_p(); self._n = C.c_int64(); self._cnt = (C.c_int64 * 4)()
 
