@@ -351,65 +351,63 @@ def glm_workload(cfg, Vs, N, q):
             "variants_per_step_per_gpu": Vs, "n_samples": N, "sharding": "k-mer stream sharded by rank, no collective"}
 
 
-def glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, contexts=3, steps=15, warmup=None, check=None):
-    """The same fixed-effects steps on `contexts` engine contexts of ONE device at once, each with its own stream, workspaces and host thread
-    (what `python -m pyseer_amd --gpus 0,0,0` does for a job; the counterpart of the reference's --cpu N, pyseer/__main__.py:541-568): a step
-    is still one batch through one sh_glm_batch_dev call; the timed region runs exactly `steps` of them, handed to the contexts in turn.  One
-    stream leaves the device idle between its per-variant kernels, its list-length round trips to the host and the tails of its restart /
-    Firth kernels (valu_issue_frac 0.45 at N = 1000); the other streams fill that.  (Cutting ONE batch into slices inside the library was
-    measured too: the per-call join and the smaller launches give most of it back -- DESIGN.md section 5.2.)
-    check = (bits, out, fl) of the one-context run: a context repeats that batch after the timed region and must return the same bytes."""
-    import threading
+def glm_lanes_line(eng, cfg, bits, q, Vs, rb, steps=15, warmup=None, check=None):
+    """The fixed-effects steps through the context's LANES (sh_glm_batch_dev_async, csrc/lanes_api.inc; the library's default for a job):
+    a step is still one batch through one sh_glm_batch_dev -- on one of the context's worker threads, each with its own stream and
+    workspaces -- and the timed region runs exactly `steps` of them, submitted back to back and completed by sh_wait, bracketed by device
+    synchronisation.  One stream of batches leaves the device idle between its per-variant kernels, behind the list-length read-backs of
+    its launch code and in the tails of its passes; batches of consecutive calls fill that.  (The counterpart of the reference's pool of
+    --cpu N workers over blocks of variants, pyseer/__main__.py:541-568.)  Every step has its own result buffers.
+    check = (index into bits, out, fl) of a synchronous call: the lanes' rows for those bits must be the same bytes."""
     import torch
-    from pyseer_amd.engine import Engine
-    steps = (steps + contexts - 1) // contexts * contexts
-    warmup = contexts if warmup is None else warmup
-    ctxs = []
-    for c in range(contexts):
-        st = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(st):
-            eng = Engine(N, device=local); eng.use_torch_stream(); eng.set_af_filter(0.01, 0.99)
-            eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=(cfg == "C4"))
-            bits = [synth_bits(Vs, N, rb, 5151 + 10 * c + i, dev) for i in range(2)]
-            out = torch.empty((5 + q, Vs), dtype=torch.float64, device=dev); fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
-        ctxs.append((st, eng, bits, out, fl))
+    dev = bits[0].device
+    lanes = eng.get_lanes()
+    warmup = 2 * lanes if warmup is None else warmup
+    nb = len(bits)
+    nres = min(max(2 * lanes + 1, nb), steps)                          # result buffers in flight at most: 2 x lanes
+    outs = [torch.empty((5 + q, Vs), dtype=torch.float64, device=dev) for _ in range(nres)]
+    fls = [torch.empty((Vs,), dtype=torch.int32, device=dev) for _ in range(nres)]
+    for i in range(warmup):
+        eng.glm_batch_dev_async(bits[i % nb], outs[i % nres], fls[i % nres])
+    eng.wait(); torch.cuda.synchronize()
+    eng.set_timing(True)
+    sampler = ClockSampler(dev.index or 0).start()
     torch.cuda.synchronize()
-
-    def work(c, n):
-        st, eng, bits, out, fl = ctxs[c]
-        with torch.cuda.stream(st):
-            for i in range(n):
-                eng.glm_batch_dev(bits[i % 2], out, fl)
-            st.synchronize()
-
-    def timed(n_each):
-        th = [threading.Thread(target=work, args=(c, n_each)) for c in range(contexts)]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
-    timed(max(1, warmup // contexts))
-    dt = timed(steps // contexts)
-    res = {"contexts": contexts, "value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
-           "what": "%d engine contexts on one device, each with its own stream and host thread, batches handed to them in turn "
-                   "(the job path of --gpus 0,0,0; the reference's --cpu N); one step = one batch through one sh_glm_batch_dev call" % contexts}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.glm_batch_dev_async(bits[i % nb], outs[i % nres], fls[i % nres])
+    eng.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    clocks = sampler.stop()
+    span_ms, nspan = eng.get_timing()
+    eng.set_timing(False)
+    step_s = dt / steps
+    roof = with_clock(glm_roofline(cfg, q, Vs, step_s, steps, rb), clocks)
+    roof["kernel_ms_is"] = ("timed region / steps (device synchronised on both sides): the batches of different lanes overlap on the device, so a batch's own "
+                            "HIP-event span (batch_span_ms, on its lane's stream) is longer than the time the device spends per step")
+    roof["batch_span_ms"] = span_ms / max(nspan, 1)
+    res = {"lanes": lanes, "contexts": 1, "value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3,
+           "roofline": roof,
+           "what": "ONE engine context, batches through its %d lanes (sh_glm_batch_dev_async + sh_wait): worker threads with their own stream and "
+                   "workspaces inside the library; one step = one batch through one sh_glm_batch_dev on a lane" % lanes}
+    last = (steps - 1) % nres
+    res["_last"] = (bits[(steps - 1) % nb], outs[last], fls[last])
     if check is not None:
-        st, eng, _, out, fl = ctxs[0]
-        with torch.cuda.stream(st):
-            eng.glm_batch_dev(check[0], out, fl); st.synchronize()
-        same = bool(torch.equal(out.view(torch.int64), check[1].view(torch.int64))) and bool(torch.equal(fl, check[2]))
-        res["identical_to_one_context"] = same
-        if not same:                                                  # (never seen; reported rather than fatal: flags and the worst relative deviation)
-            a, b = out.double(), check[1].double()
+        bi, out0, fl0 = check
+        j = None
+        for i in range(steps - 1, max(steps - 1 - nres, -1), -1):     # a step of the timed region that ran those rows and whose buffers were not reused since
+            if i % nb == bi:
+                j = i % nres; break
+        if j is None:
+            eng.glm_batch_dev_async(bits[bi], outs[0], fls[0]); eng.wait(); torch.cuda.synchronize(); j = 0
+        same = bool(torch.equal(outs[j].view(torch.int64), out0.view(torch.int64))) and bool(torch.equal(fls[j], fl0))
+        res["identical_to_synchronous_call"] = same
+        if not same:                                                  # (never seen; reported rather than fatal)
+            a, b = outs[j].double(), out0.double()
             okm = torch.isfinite(a) & torch.isfinite(b)
-            res["flags_identical"] = bool(torch.equal(fl, check[2]))
-            res["max_rel_dev_from_one_context"] = float(((a - b).abs() / b.abs().clamp_min(1e-300))[okm].max().item()) if bool(okm.any()) else None
-    for c in ctxs:
-        c[1].close()
+            res["flags_identical"] = bool(torch.equal(fls[j], fl0))
+            res["max_rel_dev_from_synchronous_call"] = float(((a - b).abs() / b.abs().clamp_min(1e-300))[okm].max().item()) if bool(okm.any()) else None
     return res
 
 
@@ -452,24 +450,26 @@ def fixed_effects_line(cfg, dev, local, steps=5, warmup=1, Vs=None, cpu=True, pa
     dt = time.perf_counter() - t0
     clocks = sampler.stop()
     kms, klaunch = eng.get_timing()
+    eng.set_timing(False)
     kern_s = kms / max(klaunch, 1) * 1e-3
     metric, dtype = glm_metric(cfg, N)
-    res = {"metric": metric, "value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-           "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), "roofline": with_clock(glm_roofline(cfg, q, Vs, kern_s, klaunch, rb), clocks)}
+    sync = {"value": Vs * steps / dt, "unit": "variants/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "roofline": with_clock(glm_roofline(cfg, q, Vs, kern_s, klaunch, rb), clocks),
+            "what": "the same context, one synchronous sh_glm_batch_dev per step on one stream (rounds 1-4's measurement)"}
     if env:
-        res["env"] = dict(env)
+        # a switch read at set-up (the literal step-halving rule): measured the old way only
+        res = {"metric": metric, "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), **sync, "env": dict(env), "lanes": 1}
+        last = (bits[(warmup + steps - 1) % nb], out, fl)
+    else:
+        ln = glm_lanes_line(eng, cfg, bits, q, Vs, rb, check=((warmup + steps - 1) % nb, out, fl))
+        last = ln.pop("_last")
+        res = {"metric": metric, "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), **ln, "synchronous": sync}
+        res["config"]["workload"] += ", one engine context, batches through its %d lanes" % ln["lanes"]
     if parity:
-        n, devs = parity_glm(y, W, nl, nf, cfg == "C4", bits[(warmup + steps - 1) % nb], out, fl, N)
+        n, devs = parity_glm(y, W, nl, nf, cfg == "C4", last[0], last[1], last[2], N)
         res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
     eng.close()
-    if not env:
-        try:
-            res["three_contexts"] = glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, check=(bits[(warmup + steps - 1) % nb], out, fl))
-        except Exception as e:                                        # a secondary measurement must not take the line down
-            res["three_contexts"] = {"error": repr(e)}
-        vf = res["roofline"].get("valu_issue_frac")
-        if vf and "value" in res["three_contexts"]:                   # the same instructions per variant, issued in less time
-            res["three_contexts"]["valu_issue_frac"] = vf * res["three_contexts"]["value"] / res["value"]
+    del last
     del bits, out, fl
     if cpu:
         res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, cfg == "C4")
@@ -609,7 +609,7 @@ def slim(e):
     if not isinstance(e, dict):
         return e
     out = {k: e[k] for k in ("value", "unit", "steps", "ms_per_step", "n_limbs", "kernel_ms", "frac_of_int8_peak_main_pass", "refined_last_batch",
-                             "parity_checked", "bytes_per_variant_over_pcie", "identical_to_synchronous_call", "contexts", "identical_to_one_context",
+                             "parity_checked", "bytes_per_variant_over_pcie", "identical_to_synchronous_call", "contexts", "lanes",
                              "valu_issue_frac", "env", "error") if k in e}
     if isinstance(e.get("parity_max_rel_dev"), dict) and e["parity_max_rel_dev"]:
         out["parity_max_rel_dev"] = max_dev(e["parity_max_rel_dev"])
@@ -617,7 +617,7 @@ def slim(e):
         out["roofline"] = {k: e["roofline"][k] for k in ROOF_KEYS if k in e["roofline"] and k != "kernel"}
     if isinstance(e.get("cpu_baseline"), dict):
         out["cpu_baseline"] = {k: e["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind") if k in e["cpu_baseline"]}
-    for k in ("three_contexts", "pipelined"):
+    for k in ("synchronous", "pipelined"):
         if isinstance(e.get(k), dict):
             out[k] = slim(e[k])
     if isinstance(e.get("config"), dict) and "workload" in e["config"]:
@@ -632,15 +632,16 @@ def fixed_effects_summary(extra):
             return None
         r = e.get("roofline", {})
         o = {"value": e["value"], "unit": e.get("unit"), "ms_per_step": e.get("ms_per_step"), "frac": r.get("frac"), "valu_issue_frac": r.get("valu_issue_frac"),
-             "bound": r.get("bound"), "traffic": r.get("traffic"), "contexts": 1}
+             "bound": r.get("bound"), "traffic": r.get("traffic"), "contexts": 1, "lanes": e.get("lanes", 1)}
         if isinstance(e.get("parity_max_rel_dev"), dict) and e["parity_max_rel_dev"]:
             o["parity_max_rel_dev"] = max_dev(e["parity_max_rel_dev"])
-        t = e.get("three_contexts")
+        t = e.get("synchronous")
         if isinstance(t, dict) and "value" in t:
-            o["three_contexts_value"] = t["value"]
+            o["synchronous_value"] = t["value"]; o["synchronous_valu_issue_frac"] = t.get("roofline", {}).get("valu_issue_frac")
         return o
     return {"logistic": one(extra.get("C2N5000")), "firth": one(extra.get("C4")),
-            "workloads": "C2N5000 / C4: 2^18 synthetic k-mers x 5000 samples per step, 10 covariates, rows resident in HBM, ONE engine context"}
+            "workloads": "C2N5000 / C4: 2^18 synthetic k-mers x 5000 samples per step, 10 covariates, rows resident in HBM, ONE engine context, "
+                         "batches through its lanes (sh_glm_batch_dev_async); synchronous_value = one sh_glm_batch_dev per step on one stream"}
 
 
 def emit(res):
@@ -653,8 +654,8 @@ def emit(res):
         line["roofline"] = {k: v for k, v in res["roofline"].items() if k not in ("ops", "traffic_source", "traffic_unit", "clock_source")}
     if isinstance(res.get("cpu_baseline"), dict) and len(json.dumps(res["cpu_baseline"])) > 400:
         cb = dict(res["cpu_baseline"]); cb["sample"] = str(cb.get("sample", ""))[:160]; line["cpu_baseline"] = cb
-    if isinstance(res.get("three_contexts"), dict):
-        line["three_contexts"] = slim(res["three_contexts"])
+    if isinstance(res.get("synchronous"), dict):
+        line["synchronous"] = slim(res["synchronous"])
     order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
              "fixed_effects_n5000", "roofline", "cpu_baseline"]
     line = {**{k: line[k] for k in order if k in line}, **{k: v for k, v in line.items() if k not in order}}
@@ -737,17 +738,31 @@ def main():
         eng.set_af_filter(0.01, 0.99)
         eng.glm_setup(y, W, False, nl, nf, 1.0, 1.0, force_firth=(cfg == "C4"))
         nrow = 5 + q
-        run = eng.glm_batch_dev
+        run = None                                               # (the lanes: below)
 
     nbuf = args.steps + args.warmup
     # every step has its own rows (seed + rank shard), all resident in HBM before the timed region; at most 16 distinct buffers (10 GB)
     ndist = min(nbuf, 16)
     bits = [synth_bits(Vs, N, rb, 1003 + 1000 * rank + i, dev) for i in range(ndist)]
-    out = torch.empty((nrow, Vs), dtype=torch.float64, device=dev)
-    fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
-
+    if lmm:
+        out = torch.empty((nrow, Vs), dtype=torch.float64, device=dev)
+        fl = torch.empty((Vs,), dtype=torch.int32, device=dev)
+        step = lambda i: run(bits[i % ndist], out, fl)
+        finish = lambda: None
+    else:
+        # fixed effects: every step is one batch through one sh_glm_batch_dev on one of the context's lanes (sh_glm_batch_dev_async: worker
+        # threads with their own stream and workspaces inside the library, csrc/lanes_api.inc); the timed region submits exactly K of them
+        # and completes them (sh_wait) before the closing synchronisation.  Every batch in flight has its own result buffers.
+        lanes = eng.get_lanes()
+        nres = min(2 * lanes + 1, nbuf)
+        outs = [torch.empty((nrow, Vs), dtype=torch.float64, device=dev) for _ in range(nres)]
+        fls = [torch.empty((Vs,), dtype=torch.int32, device=dev) for _ in range(nres)]
+        step = lambda i: eng.glm_batch_dev_async(bits[i % ndist], outs[i % nres], fls[i % nres])
+        finish = eng.wait
+        out, fl = outs[(nbuf - 1) % nres], fls[(nbuf - 1) % nres]   # the last timed step's
     for i in range(args.warmup):
-        run(bits[i % ndist], out, fl)
+        step(i)
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -756,7 +771,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run(bits[(args.warmup + i) % ndist], out, fl)
+        step(args.warmup + i)
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -764,7 +780,7 @@ def main():
     clocks = sampler.stop() if sampler is not None else {}
     dt = dt_local
     kms, klaunch = eng.get_timing()
-    if not lmm and os.environ.get("SEERHIP_GLM_DEBUG"):
+    if not lmm and ("glm" in os.environ.get("SEERHIP_DEBUG", "").split(",")):
         eng.glm_info()                                       # the library prints its development counters to stderr
     # sanity: the timed work produced finite statistics (row 2 = beta / kbeta; AF-filtered rows of the fixed-effects configs are NaN by contract)
     fin = torch.isfinite(out[2])
@@ -785,7 +801,9 @@ def main():
         last = bits[(args.warmup + args.steps - 1) % ndist]
         total = float(Vs) * args.steps * world
         value = total / dt
-        kern_s = kms / max(klaunch, 1) * 1e-3
+        # LMM: the HIP-event time of the contraction kernel per launch.  Fixed effects on the lanes: the batches of different lanes overlap on
+        # the device, so the time the device spends per step is the timed region / steps (a batch's own event span is reported beside it)
+        kern_s = kms / max(klaunch, 1) * 1e-3 if lmm else dt_local / args.steps
         res = {"value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "data": "synthetic", "world": world, "rccl_ranks_seen": ranks_seen, "collective_backend": args.backend if world > 1 else None,
@@ -825,7 +843,7 @@ def main():
                 res["extra"] = {
                     "C2N5000": fixed_effects_line("C2N5000", dev, local, cpu=cpu, parity=not args.no_parity),
                     "C4": fixed_effects_line("C4", dev, local, cpu=cpu, parity=not args.no_parity),
-                    "C4_literal": fixed_effects_line("C4", dev, local, cpu=False, parity=not args.no_parity, env={"SEERHIP_FIRTH_LITERAL": "1"}),
+                    "C4_literal": fixed_effects_line("C4", dev, local, cpu=False, parity=not args.no_parity, env={"SEERHIP_ROUTE": "firth_literal=1"}),
                     "C2": fixed_effects_line("C2", dev, local, steps=3, cpu=False, parity=False),
                     "C3_five_limbs": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=5),
                     "C3_all_refined_56bit": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=0, tol=1e-300),
@@ -836,19 +854,35 @@ def main():
         else:
             force = cfg == "C4"
             metric, dtype = glm_metric(cfg, N)
-            res.update({"metric": metric, "dtype": dtype, "config": glm_workload(cfg, Vs, N, q),
+            res.update({"metric": metric, "dtype": dtype, "config": glm_workload(cfg, Vs, N, q), "lanes": lanes, "contexts": 1,
                         "roofline": with_clock(glm_roofline(cfg, q, Vs, kern_s, klaunch, rb), clocks)})
+            res["config"]["workload"] += ", one engine context, batches through its %d lanes" % lanes
+            res["roofline"]["batch_span_ms"] = kms / max(klaunch, 1)
+            res["roofline"]["kernel_ms_is"] = "timed region / steps (the batches of different lanes overlap; batch_span_ms = one batch's own HIP-event span on its lane's stream)"
             if not args.no_parity:
                 n, devs = parity_glm(y, W, nl, nf, force, last, out, fl, N)
                 res["parity_checked"] = n; res["parity_max_rel_dev"] = devs
             if world == 1 and not args.no_extra:
+                # the same context, one synchronous sh_glm_batch_dev per step on one stream (rounds 1-4's measurement), and its rows for the
+                # last timed batch: the lanes' must be the same bytes
                 try:
-                    res["three_contexts"] = glm_contexts_line(cfg, dev, local, y, W, nl, nf, N, q, Vs, rb, check=(last, out, fl))
+                    eng.set_timing(False)
+                    o1 = torch.empty_like(out); f1 = torch.empty_like(fl)
+                    eng.glm_batch_dev(last, o1, f1); torch.cuda.synchronize()
+                    res["identical_to_synchronous_call"] = bool(torch.equal(o1.view(torch.int64), out.view(torch.int64))) and bool(torch.equal(f1, fl))
+                    eng.set_timing(True)
+                    ns = max(3, min(args.steps, 6))
+                    t1 = time.perf_counter()
+                    for i in range(ns):
+                        eng.glm_batch_dev(bits[i % ndist], o1, f1)
+                    torch.cuda.synchronize()
+                    d1 = time.perf_counter() - t1
+                    k1, n1 = eng.get_timing()
+                    res["synchronous"] = {"value": Vs * ns / d1, "unit": "variants/s", "steps": ns, "ms_per_step": d1 / ns * 1e3,
+                                          "roofline": glm_roofline(cfg, q, Vs, k1 / max(n1, 1) * 1e-3, n1, rb)}
+                    del o1, f1
                 except Exception as e:
-                    res["three_contexts"] = {"error": repr(e)}
-                vf = res["roofline"].get("valu_issue_frac")
-                if vf and "value" in res["three_contexts"]:
-                    res["three_contexts"]["valu_issue_frac"] = vf * res["three_contexts"]["value"] / res["value"]
+                    res["synchronous"] = {"error": repr(e)}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline_glm(y, W, nl, nf, N, force)
         emit(res)

@@ -224,7 +224,7 @@ int64_t     sh_reader_names_needed(sh_reader *r);
 /* bytes of inflated text currently buffered (bounded by one block of lines + one read slab; for tests) */
 int64_t     sh_reader_buffered(sh_reader *r);
 /* gzip members decoded on several threads (csrc/inflate_par.h): chunks accepted so far that started from a SEARCHED block head (0: the
- * stream was decoded by one thread -- small file, stored/fixed blocks only, SEERHIP_READER=serial, BGZF, plain text). */
+ * stream was decoded by one thread -- small file, stored/fixed blocks only, SEERHIP_ROUTE reader=serial, BGZF, plain text). */
 int64_t     sh_reader_par_chunks(sh_reader *r);
 
 /* introspection: how many variants of the LAST batch went through the Firth kernel / its pinv slow path */

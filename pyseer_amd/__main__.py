@@ -16,6 +16,8 @@ import os
 import sys
 import warnings
 
+from . import _route
+
 
 def _torch_reachable(argv):
     """torch is used by the command line for one thing: the eigendecomposition of a similarity matrix on the GPU (--lmm without
@@ -60,7 +62,7 @@ def _warm_device():
             libc.dlopen(_abi.LIB_PATH.encode(), os.RTLD_NOW)
         lib = _abi.load()
         # a job's host threads wait for the device asleep (include/seerhip.h sh_set_wait_mode): the runtime's default spins a CPU per waiting stream
-        lib.sh_set_wait_mode(0 if os.environ.get("SEERHIP_WAIT") == "spin" else 1)
+        lib.sh_set_wait_mode(0 if _route.route("wait") == "spin" else 1)
         lib.sh_warmup(dev)
     except Exception:
         pass
@@ -293,7 +295,7 @@ def main(argv=None):
         if wt is not None:
             wt.join()                                      # (the device's wait mode is chosen at its first use: by the warm-up, not by a context racing it)
         from . import _abi as _abi_w
-        _abi_w.load().sh_set_wait_mode(0 if os.environ.get("SEERHIP_WAIT") == "spin" else 1)
+        _abi_w.load().sh_set_wait_mode(0 if _route.route("wait") == "spin" else 1)
         if options.gpus is None:
             return [Engine(n, device=options.gpu)]
         devs = [int(x) for x in options.gpus.split(",")] if "," in options.gpus else list(range(int(options.gpus)))
@@ -420,7 +422,7 @@ def main(argv=None):
     # window, the NaN masks, the counters and the choice of rows run on the device, the host formats printed rows only.  Output without
     # --print-filtered does not depend on where blocks end, so short blocks are coalesced (a 3000-row block is 90 us of GPU time).
     job_path = ((native or bool(options.load_packed)) and not options.lineage and not options.print_samples and not options.output_patterns
-                and not options.python_sink and not options.serial_sink and os.environ.get("SEERHIP_JOB", "1") != "0")
+                and not options.python_sink and not options.serial_sink and _route.route("job", "1") != "0")
     job_block = options.block_size if (options.print_filtered or not job_path) else max(options.block_size, 1 << 16)
     if options.load_packed:
         blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
@@ -447,7 +449,7 @@ def main(argv=None):
 
     import collections
     import time as _time
-    cli_timing = os.environ.get("SEERHIP_CLI_TIMING") is not None
+    cli_timing = _route.debug("cli")
 
     def new_tm():
         return {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0,

@@ -59,7 +59,8 @@ template <typename T> static hipError_t dmalloc(T **p, size_t n) { return hipMal
 
 struct sh_lanes;
 // what sh_glm_setup was called with: the lanes of the context (lanes_api.inc) are set up from it
-struct GlmSetupArgs { std::vector<double> y, W; int q = 0, continuous = 0, force_firth = 0; double null_llf = 0, null_firth = 0, pret = 1, lrtt = 1; };
+struct GlmSetupArgs { std::vector<double> y, W; int q = 0, continuous = 0, force_firth = 0; double null_llf = 0, null_firth = 0, pret = 1, lrtt = 1;
+                      std::string route; };   // (route: the SEERHIP_ROUTE string the set-up ran under)
 struct sh_ctx {
     int device = 0, N = 0;
     hipStream_t stream = nullptr;
@@ -85,7 +86,7 @@ struct sh_ctx {
     unsigned long long *d_bmax = nullptr; int64_t cap_ref = 0;
     int qf_split = 1;             // 1: one block per (variant tile, limb) (0: one block per tile loops over the limbs; not selectable any more)
     int qf_variant = 4;           // hot-kernel variant: 4 = k_lmm_quadform_i8w (one wavefront per SIMD; the launcher falls back to 0 where its conditions do not
-                                  // hold), SEERHIP_QF=0 = k_lmm_quadform_i8 (two wavefronts per SIMD), other values = timing ablations (lmm_kernels.hip)
+                                  // hold), SEERHIP_ROUTE qf=0 = k_lmm_quadform_i8 (two wavefronts per SIMD), other values = timing ablations (lmm_kernels.hip)
     // ---- GLM state
     GlmState glm;
     // ---- per-batch workspace (grown on demand)
@@ -249,7 +250,7 @@ static int host_batch(sh_ctx *c, const uint8_t *bits, int64_t row_bytes, int64_t
     std::vector<int64_t> cut{0};
     for (int64_t step = 1 << 17; cut.back() < V; step = CH) cut.push_back(std::min(V, cut.back() + step));
     const int64_t nchunk = (int64_t)cut.size() - 1;
-    const bool dbg = std::getenv("SEERHIP_HOST_DEBUG") != nullptr;
+    const bool dbg = sh_debug("host");
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const uint8_t *const nb_bits = c->next_bits; const int64_t nb_rb = c->next_row_bytes, nb_V = c->next_V;   // (an announcement serves one batch)
     c->next_bits = nullptr;
@@ -469,7 +470,8 @@ sh_ctx *sh_create(int device, int n_samples)
     apply_wait_mode(device);
     sh_ctx *c = new sh_ctx();
     c->device = device; c->N = n_samples;
-    if (const char *qv = std::getenv("SEERHIP_QF")) c->qf_variant = std::atoi(qv);
+    if (const char *qv = sh_route("qf")) c->qf_variant = std::atoi(qv);
+    if (const char *lv = sh_route("lanes")) c->n_lanes = std::max(1, std::min(8, std::atoi(lv)));
     if (const char *ac = sh_route("afcompact")) c->af_compact = std::atoi(ac);
     c->NT = (n_samples + 255) / 256; c->Np = c->NT * 256;
     c->NB64 = (n_samples + 63) / 64; c->NB64p = c->NT * 4;
@@ -573,8 +575,8 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
         // Automatic limb count: the smallest L in {4, 5} whose TYPICAL a-posteriori bound (an AF-0.5 variant, section 3 of DESIGN.md) is at most a
         // quarter of lmm_tol, so that the extra-limb pass stays the exception; a variant whose own bound exceeds lmm_tol gets the extra limbs
         // whichever L was chosen.  The base-256 digits do not depend on where the main pass stops, only how many of them it contracts does:
-        // L = 4 is 20 % less int8 work than L = 5.  SEERHIP_LMM_LIMBS=n forces a count.
-        const char *fe = std::getenv("SEERHIP_LMM_LIMBS");
+        // L = 4 is 20 % less int8 work than L = 5.  SEERHIP_ROUTE lmm_limbs=n forces a count.
+        const char *fe = sh_route("lmm_limbs");
         if (fe && std::atoi(fe) > 0) n_limbs = std::atoi(fe);
         else {
             const int rc4 = sh_lmm_setup(c, U, S, k, y, C, D, h2, continuous, pret, lrtt, 4);
@@ -741,7 +743,7 @@ int sh_lmm_setup(sh_ctx *c, const double *U, const double *S, int k, const doubl
 
     c->k = k; c->D = D; c->L = L; c->DP = DP; c->E = E;
     c->complement = ones_in_span && !(sh_route("complement") && std::atoi(sh_route("complement")) == 0);
-    if (const char *tv = std::getenv("SEERHIP_LMM_TOL")) c->lmm_tol = std::atof(tv);
+    if (const char *tv = sh_route("lmm_tol")) c->lmm_tol = std::atof(tv);
     LmmFinParams &P = c->fin;
     P.N = N; P.D = D; P.continuous = continuous; P.n1 = n1; P.n0 = n0; P.yc_sum = ycs; P.yc_sq = ycq;
     P.yKy = yKy; P.inv_scale = amax > 0 ? 1.0 / c->quant_scale : 0.0; P.pret = pret; P.lrtt = lrtt;

@@ -24,52 +24,7 @@
 // variant n: exactly the B operand of the MFMA (column n, k = 8 h + j), so a lane's eight weights go to the matrix core as they are.  The A
 // operand (32 monomials x 16 samples) is read from the run's table (GlmParams.ff_tab) one 16-byte fragment per lane.  Accumulators: T2 tiles
 // (w . m2), T3 tiles (c . m3), T2 tiles (c k . m2), 16 registers each: 240 AGPRs at Q = 10; one wavefront per SIMD.
-#include <hip/hip_runtime.h>
-#include <utility>
-#include "glm_device.h"
-
-typedef _Float16 ff_v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 ff_v2h __attribute__((ext_vector_type(2)));
-typedef float ff_v16f __attribute__((ext_vector_type(16)));
-typedef float ff_v2f __attribute__((ext_vector_type(2)));
-typedef uint32_t ff_v4u __attribute__((ext_vector_type(4)));
-typedef double ff_v2d __attribute__((ext_vector_type(2)));
-
-#define FF_SCALE 4096.0            /* weights are scaled by 2^12 before the hi / lo split (their lo parts stay normal halves); exact */
-#define FF_TAU 1e-5                /* an increase of the one-pass F beyond this is a real step halving: the fit leaves for the exact rounds */
-#ifndef FF_ABL
-#define FF_ABL 0                   /* timing ablations (results meaningless): 1 = no MFMAs, 2 = no LDS-DMA / barriers, 4 = no sample arithmetic; 8 (results valid) = every fit finished by the exact kernel */
-#endif
-#ifndef FF_RHO
-#define FF_RHO 0.05               /* largest relative change of I's diagonal against the null model for a fit to be finished from the one-pass F */
-#endif
-#ifndef FF_STAGGER
-#define FF_STAGGER 0              /* s_sleep units (64 cycles) between the wavefronts of a block after every barrier */
-#endif
-#ifndef FF_SCHED
-#define FF_SCHED 8                 /* vector instructions between two MFMAs of a pair's instruction stream (0: the compiler's own order) */
-#endif
-#define FF_MAXIT 8                 /* passes after which a fit that has not met the stop rule leaves for the exact rounds */
-
-__host__ __device__ constexpr int ff_tri(int a) { return a * (a + 1) / 2; }
-__host__ __device__ constexpr int ff_tet(int a) { return a * (a + 1) * (a + 2) / 6; }
-struct FFMono { int a, b, c; };
-// (z1 = (1, z), Z1 = Q + 1 entries.)  Degree-3 table: row r = tet(a) + tri(b) + c holds z1_a z1_b z1_c, a >= b >= c.  Degree-2 table: the Z1
-// monomials with the constant come first -- row a holds z1_a (a = 0: 1) -- so that tile 0 alone serves the k-row of I (sum w k z1_a); rows
-// Z1 + tri(a - 1) + (b - 1) hold z1_a z1_b for a >= b >= 1.
-__host__ __device__ constexpr FFMono ff_dec_tri(int r) { int a = 0; while (ff_tri(a + 1) <= r) ++a; return FFMono{a, r - ff_tri(a), 0}; }
-__host__ __device__ constexpr FFMono ff_dec3(int r) { int a = 0; while (ff_tet(a + 1) <= r) ++a; const FFMono m = ff_dec_tri(r - ff_tet(a)); return FFMono{a, m.a, m.b}; }
-__host__ __device__ constexpr FFMono ff_dec2(int r, int z1) { if (r < z1) return FFMono{r, 0, 0}; const FFMono m = ff_dec_tri(r - z1); return FFMono{m.a + 1, m.b + 1, 0}; }
-__host__ __device__ constexpr int ff_row2(int a, int b, int z1) { return b == 0 ? a : z1 + ff_tri(a - 1) + (b - 1); }
-__host__ __device__ constexpr int ff_design(int z1) { return z1 == 0 ? 0 : z1 + 1; }      // column of x = (1, k, z) that holds z1's entry
-
-template <int Q> struct FFC {
-    static constexpr int Z1 = Q + 1, PC = Q + 2, NH = PC * (PC + 1) / 2;
-    static constexpr int N2 = ff_tri(Z1), N3 = ff_tet(Z1);
-    static constexpr int T2 = (N2 + 31) / 32, T3 = (N3 + 31) / 32, NTA = T2 + T3, NACC = 2 * T2 + T3 + 1, AWK = 2 * T2 + T3;   // (AWK: the k-row of I)
-    static_assert(Z1 <= 32, "the k-row of I lives in tile 0 of the degree-2 table");
-    static constexpr int RS = (Q + 3 + 1) & ~1;           // doubles per sample record: z_s[Q], s = 1 - 2 y, live (1 / 0), w0 (the null model's weight), padding to 16 bytes
-};
+#include "firth_fast_common.h"
 #ifndef FF_F32_TU
 extern "C" int shk_firth_fast_supported(int Q) { return Q >= 1 && Q <= 10; }
 extern "C" int shk_firth_fast_row2(int Q, int a, int b) { return ff_row2(a, b, Q + 1); }
@@ -81,48 +36,6 @@ extern "C" int shk_firth_fast_tiles(int Q, int *t2, int *t3, int *rs)
 }
 #endif
 
-// g_x += sum over the distinct arrangements of the multiset {A, B, C} of t V_yz: for every distinct element x, the other two (y, z) give
-// 2 t V_yz if y != z, t V_yy otherwise
-template <int PC, int A, int B, int C>
-__device__ __forceinline__ void ff_contrib(double t, const double (&V)[PC * (PC + 1) / 2], double (&g)[PC])
-{
-    auto Vs = [&](int i, int j) { return i >= j ? V[sidx(i, j)] : V[sidx(j, i)]; };
-    g[A] = fma(t * (B == C ? 1.0 : 2.0), Vs(B, C), g[A]);
-    if (B != A) g[B] = fma(t * (A == C ? 1.0 : 2.0), Vs(A, C), g[B]);
-    if (C != A && C != B) g[C] = fma(t * (A == B ? 1.0 : 2.0), Vs(A, B), g[C]);
-}
-// row R of the degree-3 table: the entry T_{abc} without k
-template <int Q, int R>
-__device__ __forceinline__ void ff_row3(float tv, const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC])
-{
-    if constexpr (R < FFC<Q>::N3) {
-        constexpr FFMono m = ff_dec3(R);
-        ff_contrib<FFC<Q>::PC, ff_design(m.a), ff_design(m.b), ff_design(m.c)>((double)tv, V, g);
-    }
-}
-// row R of the degree-2 table against c k: the entries {k, a, b}; a monomial that holds the constant also stands for {k, k, a} (k^2 = k), and
-// the constant alone for {k, k, k}
-template <int Q, int R>
-__device__ __forceinline__ void ff_row2k(float tv, const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC])
-{
-    if constexpr (R < FFC<Q>::N2) {
-        constexpr FFMono m = ff_dec2(R, FFC<Q>::Z1);
-        ff_contrib<FFC<Q>::PC, 1, ff_design(m.a), ff_design(m.b)>((double)tv, V, g);
-        if constexpr (m.b == 0) ff_contrib<FFC<Q>::PC, 1, 1, ff_design(m.a)>((double)tv, V, g);
-        if constexpr (m.a == 0 && m.b == 0) ff_contrib<FFC<Q>::PC, 1, 1, 1>((double)tv, V, g);
-    }
-}
-// row R of the degree-2 table against w: the entry I_{ab} of the covariate block (design columns other than k)
-template <int Q, int R>
-__device__ __forceinline__ void ff_row2i(float tv, const double *__restrict__ inull, double (&I)[FFC<Q>::NH], double &rho)
-{
-    if constexpr (R < FFC<Q>::N2) {
-        constexpr FFMono m = ff_dec2(R, FFC<Q>::Z1);
-        const double v0 = inull[R];
-        I[sidx(ff_design(m.a), ff_design(m.b))] = v0 + (double)tv;
-        if constexpr (m.a == m.b) rho = fmax(rho, fabs((double)tv) / v0);       // how far the weights are from the null model's, on the diagonal
-    }
-}
 // the 32 rows of one accumulator tile, every lane seeing all of them: register r of a lane holds row (r & 3) + 8 (r >> 2) + 4 h
 __device__ __forceinline__ void ff_rows(const ff_v16f &acc, int h, float (&row)[32])
 {
@@ -134,22 +47,6 @@ __device__ __forceinline__ void ff_rows(const ff_v16f &acc, int h, float (&row)[
         row[r0] = h ? o : x;
         row[r0 + 4] = h ? x : o;
     }
-}
-template <int Q, int TILE, int... Rs>
-__device__ __forceinline__ void ff_tile3(const float (&row)[32], const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC], std::integer_sequence<int, Rs...>)
-{
-    (ff_row3<Q, TILE * 32 + Rs>(row[Rs], V, g), ...);
-}
-template <int Q, int TILE, int... Rs>
-__device__ __forceinline__ void ff_tile2k(const float (&row)[32], const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC], std::integer_sequence<int, Rs...>)
-{
-    (ff_row2k<Q, TILE * 32 + Rs>(row[Rs], V, g), ...);
-}
-template <int Q, int TILE, int... Rs>
-__device__ __forceinline__ void ff_tile2i(const float (&row)[32], const double *__restrict__ inull, double (&I)[FFC<Q>::NH], double &rho,
-                                          std::integer_sequence<int, Rs...>)
-{
-    (ff_row2i<Q, TILE * 32 + Rs>(row[Rs], inull, I, rho), ...);
 }
 template <int Q, int... Ts>
 __device__ __forceinline__ void ff_all3(const ff_v16f (&acc)[FFC<Q>::NACC], int h, float unscale, const double (&V)[FFC<Q>::NH], double (&g)[FFC<Q>::PC],
@@ -322,8 +219,9 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         if (ta < T2) { three(acc[ta], Pw); three(acc[T2 + T3 + ta], Pk); if (ta == 0) three(acc[C::AWK], Px); }
         else three(acc[T2 + (ta - T2)], Pc);
     };
-    // one sample: returns the scaled weights (w, c, c k) as floats
-    auto sample = [&](const RT (&rc)[RS], uint32_t bit, float &wf, float &cf, float &kf, float &xf) {
+    // one sample: returns the scaled weights (w - w0, c) as floats.  (c k and (w - w0) k are not formed per sample: k is 0 / 1, so their
+    // halves are the halves of c and w - w0 under the pair's presence bits -- pair_mask below; round 5: 14 -> 7 instructions per pair)
+    auto sample = [&](const RT (&rc)[RS], uint32_t bit, float &wf, float &cf) {
         if constexpr (F32) {
             // the FIRST pass (at the start vector, some 1e-2 from the fit) in single precision: its step need not be better than the 1e-5 the
             // next point is from the fit anyway; no log-likelihood (nothing to compare F with yet)
@@ -344,8 +242,6 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             for (int j = 0; j < Q; ++j) nU[2 + j] = fmaf(rc[j], r, nU[2 + j]);
             wf = (wgt - rc[Q + 2]) * (float)FF_SCALE;
             cf = -(wgt * hm) * (float)FF_SCALE;
-            kf = bit ? cf : 0.0f;
-            xf = bit ? wf : 0.0f;
         } else {
         const double xd = (double)bit;
         double eta = fma(bs[1], xd, bs[0]);
@@ -368,9 +264,12 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         for (int j = 0; j < Q; ++j) nU[2 + j] = fma(rc[j], r, nU[2 + j]);
         wf = (float)((wgt - rc[Q + 2]) * FF_SCALE);                             // w - w0: I = I(null model) + sum (w - w0) m2, the sum an order of magnitude smaller than I
         cf = (float)(-(wgt * hm) * FF_SCALE);                                   // c = w (1/2 - mu)
-        kf = bit ? cf : 0.0f;
-        xf = bit ? wf : 0.0f;
         }
+    };
+    // 0xffff in the half of the even / the odd sample of pair pp that carries the variant (bits 2 pp, 2 pp + 1 of the group's byte)
+    auto pair_mask = [&](uint32_t byte, int pp) -> uint32_t {
+        const uint32_t ev = (uint32_t)((int32_t)(byte << (31 - 2 * pp)) >> 31), od = (uint32_t)((int32_t)(byte << (30 - 2 * pp)) >> 31);
+        return (ev & 0xffffu) | (od & 0xffff0000u);
     };
     auto stash = [&](uint32_t (&B)[2][4], int e, float a, float b) {
         const ff_v2h hh = __builtin_convertvector(ff_v2f{a, b}, ff_v2h);
@@ -406,8 +305,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             const int ta = q2 * 4 + pp;
             if (q2 >= lo && q2 < hi && ta < NTA) {
                 ah[q2] = *(const ff_v4u *)(buf + (ta * 2 + 0) * 1024 + lane * 16);
-                if constexpr (!F32) al[q2] = *(const ff_v4u *)(buf + (ta * 2 + 1) * 1024 + lane * 16);
-                else al[q2] = ah[q2];
+                if constexpr (!F32) al[q2] = *(const ff_v4u *)(buf + (ta * 2 + 1) * 1024 + lane * 16);   // (the single-precision pass never reads al)
             }
         }
     };
@@ -415,7 +313,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
         for (int q2 = 0; q2 < PER; ++q2) {
             const int ta = q2 * 4 + pp;
-            if (q2 >= lo && q2 < hi && ta < NTA) tile_mfma(ta, ah[q2], al[q2]);
+            if (q2 >= lo && q2 < hi && ta < NTA) tile_mfma(ta, ah[q2], F32 ? ah[q2] : al[q2]);
         }
     };
     dma(0);
@@ -448,12 +346,12 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         // hundred vector instructions and the MFMA issue waits for the pipe)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            float w0, c0, k0, x0, w1, c1, k1, x1;
+            float w0, c0, w1, c1;
             fetch_rec(buf, 2 * pp + 1, rb);
             slot_load(buf, pp, 1, PER, ah, al);
             __builtin_amdgcn_sched_barrier(0);
-            if (FF_ABL & 4) { w0 = (float)ra[0]; c0 = (float)ra[1]; k0 = (float)ra[2]; x0 = k0; nU[pp] += ra[3]; }
-            else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0, k0, x0);
+            if (FF_ABL & 4) { w0 = (float)ra[0]; c0 = (float)ra[1]; nU[pp] += ra[3]; }
+            else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0);
             slot_mfma(pp, 0, 1, ah, al);
 #if FF_SCHED
 #pragma unroll
@@ -464,17 +362,22 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #endif
             // (the fences order instructions with side effects; plain arithmetic is placed wherever its operands allow.  Empty volatile asms that
             // "define" the even sample's results pin its arithmetic in front of the next fence, i.e. UNDER the LDS reads issued above)
-            if constexpr (F32) asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(Ik0));
-            else asm volatile("" : "+v"(w0), "+v"(c0), "+v"(k0), "+v"(x0), "+v"(apos), "+v"(prod), "+v"(Ik0));
+            if constexpr (F32) asm volatile("" : "+v"(w0), "+v"(c0), "+v"(Ik0));
+            else asm volatile("" : "+v"(w0), "+v"(c0), "+v"(apos), "+v"(prod), "+v"(Ik0));
 #pragma unroll
             for (int a = 0; a < PC; ++a) asm volatile("" : "+v"(nU[a]));
             __builtin_amdgcn_sched_barrier(0);
             if (pp < 3) { fetch_rec(buf, 2 * pp + 2, ra); slot_load(buf, pp + 1, 0, 1, ah, al); }
             else { fetch_rec(bufn, 0, ra); slot_load(bufn, 0, 0, 1, ah, al); }
             __builtin_amdgcn_sched_barrier(0);
-            if (FF_ABL & 4) { w1 = (float)rb[0]; c1 = (float)rb[1]; k1 = (float)rb[2]; x1 = k1; nU[pp] += rb[3]; }
-            else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1, k1, x1);
-            stash(Bw, pp, w0, w1); stash(Bc, pp, c0, c1); stash(Bk, pp, k0, k1); stash(Bx, pp, x0, x1);
+            if (FF_ABL & 4) { w1 = (float)rb[0]; c1 = (float)rb[1]; nU[pp] += rb[3]; }
+            else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1);
+            stash(Bw, pp, w0, w1); stash(Bc, pp, c0, c1);
+            {
+                const uint32_t pm = pair_mask(byte, pp);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) { Bk[q2][pp] = Bc[q2][pp] & pm; Bx[q2][pp] = Bw[q2][pp] & pm; }
+            }
             slot_mfma(pp, 1, PER, ah, al);
 #if FF_SCHED
             // one MFMA, then a run of vector instructions, and so on through the sample

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
             const double d = cand[a] - fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s];
             stepmax = fmax(stepmax, fabs(d)); sn = fma(d, d, sn);
         }
-        // default: the two noise rules (GlmParams.firth_noise / firth_accept); SEERHIP_FIRTH_LITERAL=1 sets both to 0 = the reference's
+        // default: the two noise rules (GlmParams.firth_noise / firth_accept); SEERHIP_ROUTE firth_literal=1 sets both to 0 = the reference's
         // literal F(new) > F(old)
         if (Fcand > Fcur + P.firth_noise * fabs(Fcur) && !(stepmax < P.firth_accept)) {   // step halving, model.py:467-474
             accept = false;

@@ -19,7 +19,7 @@ struct GlmParams {
     int firth_handoff;            // accepted Firth steps after which a variant leaves the rounds for k_firth_blk (16, or 0 for the routed variants of an ordinary run at N >= 768)
     int f32_steps;                // first Newton steps of the fast path taken entirely in single precision (default 3, 2 with the warm start)
     // Firth step halving (model.py:465-474).  Default: an increase of F within firth_noise * |F| (4 ulp) is evaluation noise, and a step
-    // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_FIRTH_LITERAL=1 / SEERHIP_FIRTH_STRICT=1 set both
+    // whose largest component is below firth_accept (1e-10) is accepted outright.  SEERHIP_ROUTE firth_literal=1 / SEERHIP_ROUTE firth_strict=1 set both
     // to 0: the reference's literal `F(new) > F(old)`, spurious firth-fails on last-bit ties included (case 1).
     double firth_noise, firth_accept;
     int firth_last_taylor;        // 1 (default with the noise rules): k_firth_step2 finishes a fit whose stop rule is already met and whose step is <= 1e-7

@@ -14,7 +14,7 @@
 //      the symbols of all accepted chunks are then translated to bytes in parallel.
 // The first chunk of a round starts from the exact position the previous round ended on, with the real window in front of it: same code,
 // no markers.  The member's CRC-32 and ISIZE are checked by the caller as for the one-thread decoder.  Test infrastructure: zlib
-// (tests/test_reader_cpu.py decodes the same files through python's gzip and through SEERHIP_READER=serial).
+// (tests/test_reader_cpu.py decodes the same files through python's gzip and through SEERHIP_ROUTE reader=serial).
 #pragma once
 #include <vector>
 #include <new>

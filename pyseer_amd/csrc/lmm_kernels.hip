@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64 * QF_WAVES, QF_JT == 2 ? 2 : 1) void k_lmm_quadf
     // with stage s + QF_AHEAD.  Landing one stage EARLY lets the last sub-step of stage s prefetch the first fragments and bit
     // words of stage s+1, so no wave starts a stage by waiting on LDS.  (Tried and measured slower, +1.4 % / +3 %: taking the
     // barrier half a stage apart on the two waves that share a SIMD; the stalls are not a phase-alignment effect.  The barrier
-    // itself: a timing build without it (SEERHIP_QF=46) runs 4.7 % faster, but one barrier per TWO stages over a 6-slot ring gains
+    // itself: a timing build without it (SEERHIP_ROUTE qf=46) runs 4.7 % faster, but one barrier per TWO stages over a 6-slot ring gains
     // only 0.25 %: what costs is the waves waiting for each other, not the instruction.)
     auto sync_refill = [&](int s) {
         const int newer = max(0, min(total - 2 - s, QF_AHEAD - 2));   // stages allowed to be still in flight: s+2 .. s+QF_AHEAD-1

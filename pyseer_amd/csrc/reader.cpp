@@ -102,7 +102,7 @@ struct NameTable {
 // Every slab is preceded, in the same allocation, by the tail of the text before it (PAD bytes: the decoder's 32 KB history lives there
 // anyway), so a line that straddles two slabs is contiguous in the second one and the parser never copies text.  The CRC-32 of every
 // gzip member is verified by the consumer's worker pool over whole slabs (zlib's crc32 + crc32_combine), not by the decoding thread.
-// SEERHIP_READER=zlib selects zlib's gzread instead (A/B, and a fallback should a stream ever disagree).
+// SEERHIP_ROUTE reader=zlib selects zlib's gzread instead (A/B, and a fallback should a stream ever disagree).
 // ---------------------------------------------------------------------------------------------------------------------------------
 // A small pool of SLEEPING workers (condition variables) instead of an OpenMP team: libgomp's workers spin after every parallel region,
 // and on the 256-thread GPU host 128-256 spinning threads starve the decoding thread (measured: gzip 10.5 k k-mers/s with 128 OpenMP
@@ -120,7 +120,7 @@ struct Slab {
 
 struct sh_reader {
     int fd = -1; const uint8_t *map = nullptr; size_t map_len = 0;
-    gzFile gz = nullptr;                 // SEERHIP_READER=zlib
+    gzFile gz = nullptr;                 // SEERHIP_ROUTE reader=zlib
     std::vector<char> zbuf;              //   its text (unconsumed part), as in round 1
     size_t zpos = 0;
     int n = 0;
@@ -282,8 +282,8 @@ static void produce_gzip_parallel(sh_reader *r)
     size_t next_from = 0, ch_cur = std::min<size_t>(CHMAX, std::max<size_t>(CHMIN, 1u << 18));
     int infl_cur = INFL;                                              // regions in flight now: fewer when the text of a region is large (ratio)
     bool exhausted = LEN == 0, quit = false;
-    // where the time goes (SEERHIP_HOST_DEBUG: one line on stderr when the stream ends), seconds summed over the threads of a kind
-    const bool dbg = std::getenv("SEERHIP_HOST_DEBUG") != nullptr;
+    // where the time goes (SEERHIP_DEBUG=host: one line on stderr when the stream ends), seconds summed over the threads of a kind
+    const bool dbg = sh_debug("host");
     std::atomic<int64_t> ns_wslot{0}, ns_find{0}, ns_dec{0}, n_redo{0}, n_acc{0};
     std::atomic<bool> give_up{false};                                 // the searched heads keep being wrong (stored / fixed blocks, an alphabet the text test does not know):
                                                                       // the searching threads stop searching and the producer decodes alone, as produce_gzip does
@@ -532,9 +532,9 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     r->n = n_samples;
     r->index.build(sample_names, n_samples);
     int nt = reader_threads();
-    if (const char *te = std::getenv("SEERHIP_READER_THREADS")) nt = std::max(1, std::atoi(te));
+    if (const char *te = sh_route("reader_threads")) nt = std::max(1, std::atoi(te));
     r->pool.reset(new ParPool(nt - 1, shost::ST_READER_PARSE));
-    const char *sel = std::getenv("SEERHIP_READER");
+    const char *sel = sh_route("reader");
     if (sel && std::string(sel) == "zlib") {
         r->gz = gzopen(path, "rb");
         if (!r->gz) { g_rerr = std::string("cannot open ") + path; delete r; return nullptr; }
@@ -556,7 +556,7 @@ sh_reader *sh_reader_open(const char *path, const char *const *sample_names, int
     if (r->map_len == 0) { r->eof = true; return r; }
     r->mode = (r->map_len >= 2 && r->map[0] == 0x1f && r->map[1] == 0x8b) ? (bgzf_member(r->map, r->map + r->map_len) ? 2 : 1) : 0;
     if (r->mode == 2) r->pool_bgzf.reset(new ParPool(std::max(1, std::min(32, std::max(2, nt / 2)) - 1), shost::ST_READER_DECODE));
-    // one gzip member on several threads (inflate_par.h) unless SEERHIP_READER=serial, or there is nothing to share out
+    // one gzip member on several threads (inflate_par.h) unless SEERHIP_ROUTE reader=serial, or there is nothing to share out
     r->depth = std::max<size_t>(3, r->depth / (size_t)shost::host_streams());       // several readers at once share the memory as they share the CPUs
     if (const char *cd = sh_route("reader_depth")) r->depth = std::max<size_t>(1, (size_t)std::atoll(cd));
     size_t par_min = 1u << 20;                                      // files below this go through the one-thread decoder
@@ -638,7 +638,7 @@ int64_t sh_reader_next(sh_reader *r, int64_t max_variants, uint8_t *bits, int64_
     std::vector<std::pair<const char *, const char *>> lines;   // [begin, end) without the newline; they point into slabs held until the end of the call
     const char *ptr0 = nullptr;
     if (r->gz) {
-        // ---- zlib path (SEERHIP_READER=zlib): one growing buffer, as in round 1
+        // ---- zlib path (SEERHIP_ROUTE reader=zlib): one growing buffer, as in round 1
         if (r->zpos > 0) { r->zbuf.erase(r->zbuf.begin(), r->zbuf.begin() + r->zpos); r->zpos = 0; }
         size_t scan = 0, lstart = 0;
         std::vector<std::pair<size_t, size_t>> lo;

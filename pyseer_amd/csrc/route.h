@@ -1,6 +1,12 @@
 // Test hook: ONE environment variable that forces the routes a run would otherwise choose from its data, so that the tests can put every
 // fallback kernel under the same inputs (tests/test_glm_gpu.py::test_logistic_fit_paths_agree and friends).  Not a tuning interface.
 //   SEERHIP_ROUTE="key=value,key=value,..."      unknown keys are an error (sh_create / sh_reader_open refuse)
+// and ONE for diagnostics on stderr:
+//   SEERHIP_DEBUG="firth,host,cli,glm"            (any subset; sh_debug("firth") ...)
+// Round 5 folded the remaining single-purpose variables into the two (SEERHIP_FIRTH_LITERAL / _STRICT / _FAST, SEERHIP_LMM_LIMBS / _TOL,
+// SEERHIP_QF, SEERHIP_READER / _THREADS, SEERHIP_WAIT / _JOB / _DMA -> route keys; SEERHIP_FIRTH_DEBUG / _HOST_DEBUG / _CLI_TIMING ->
+// SEERHIP_DEBUG items).  A context reads its routes at set-up; the lanes of a context (lanes_api.inc) are set up under the route string
+// their parent saw (sh_route_override), whatever the environment holds by then.
 // Keys (default in brackets):
 //   chord=0          [1]  logistic: fp64-score Newton passes instead of the chord rounds (the form a run without covariates takes)
 //   chord_n32=K      [5]  single-precision Newton rounds before the chord rounds (1..8); stragglers restart in fp64
@@ -20,6 +26,16 @@
 //   reader_slab=B, reader_pad=B   reader: bytes per decoded slab / carried over between slabs
 //   reader_depth=D   [10] slabs decoded ahead of the parser;  reader_helpers=H  translating threads beside the producer [reader threads / 2, <= 8];
 //                    reader_target=B  text bytes a region is sized for [12e6]
+//   firth_literal=1  [0]  Firth step halving by the reference's literal F(new) > F(old) on the rounds' own evaluation order
+//   firth_strict=1   [0]  literal rule + the reference's start vector + one log per sample (the A/B closest to the reference's own order)
+//   firth_fast=0     [1]  forced Firth at N >= 4096 through the exact two-pass rounds instead of the one-pass kernel (firth_fast.hip)
+//   firth_w=0        [1]  the one-pass kernel's single-precision first pass at one wavefront per SIMD (firth_fast.hip) instead of two (firth_fast_w.hip)
+//   lmm_limbs=L      [auto] int8 limbs of the LMM contraction;  lmm_tol=X [1e-8] bound above which a variant is contracted with the extra limbs
+//   qf=V             [4]  LMM contraction kernel: 0 = k_lmm_quadform_i8 (two wavefronts per SIMD), 3x = timing ablations
+//   lanes=n          [3]  lanes of a fixed-effects context (sh_set_lanes overrides)
+//   reader=serial|zlib [par] container decoder of the native reader;  reader_threads=T  its parser workers
+//   wait=spin        [sleep], job=0 [1], dma=0 [1]   command line (pyseer_amd/__main__.py, input.py): host threads spin on the device; the
+//                    Python block loop instead of the job stream; rows through pinned slabs instead of DMA from the registered cache mapping
 //   reader_chunk=B   [4 MB] most compressed bytes per region of the parallel gzip decoder (regions are sized for ~12 MB of text; small values:
 //                    many regions in a small file);  reader_workers=W  its decoding threads [2/3 of the reader's threads, at most 32]
 #pragma once
@@ -30,13 +46,17 @@
 static inline const char *const *sh_route_keys()
 {
     static const char *const keys[] = {"chord", "chord_n32", "chord_enter", "bitdot", "first_bordered", "pk", "warm", "fin_rounds", "ll_first", "newton",
-                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", "reader_chunk", "reader_workers", "reader_depth", "reader_helpers", "reader_target", nullptr};
+                                       "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", "reader_chunk", "reader_workers", "reader_depth", "reader_helpers", "reader_target",
+                                       "firth_literal", "firth_strict", "firth_fast", "firth_w", "lmm_limbs", "lmm_tol", "qf", "lanes", "reader", "reader_threads", "wait", "job", "dma", nullptr};
     return keys;
 }
+// the route string in force for the calling thread: the environment's, or the one a parent context was set up under (lanes_api.inc)
+static inline const char *&sh_route_override() { static thread_local const char *p = nullptr; return p; }
+static inline const char *sh_route_string() { const char *o = sh_route_override(); return o ? o : std::getenv("SEERHIP_ROUTE"); }
 // the value of `key` in SEERHIP_ROUTE, or nullptr (the returned string lives until the calling thread's next sh_route)
 static inline const char *sh_route(const char *key)
 {
-    const char *e = std::getenv("SEERHIP_ROUTE");
+    const char *e = sh_route_string();
     if (!e) return nullptr;
     static thread_local std::string val;
     const size_t kl = std::strlen(key);
@@ -51,7 +71,7 @@ static inline const char *sh_route(const char *key)
 // empty when every key of SEERHIP_ROUTE is known, else the offending item
 static inline std::string sh_route_unknown()
 {
-    const char *e = std::getenv("SEERHIP_ROUTE");
+    const char *e = sh_route_string();
     if (!e) return std::string();
     for (const char *p = e; *p;) {
         const char *end = std::strchr(p, ','); if (!end) end = p + std::strlen(p);
@@ -62,4 +82,18 @@ static inline std::string sh_route_unknown()
         p = *end ? end + 1 : end;
     }
     return std::string();
+}
+
+// is `item` in SEERHIP_DEBUG (a comma-separated list)?
+static inline bool sh_debug(const char *item)
+{
+    const char *e = std::getenv("SEERHIP_DEBUG");
+    if (!e) return false;
+    const size_t kl = std::strlen(item);
+    for (const char *p = e; *p;) {
+        const char *end = std::strchr(p, ','); if (!end) end = p + std::strlen(p);
+        if ((size_t)(end - p) == kl && std::memcmp(p, item, kl) == 0) return true;
+        p = *end ? end + 1 : end;
+    }
+    return false;
 }

@@ -15,6 +15,7 @@ import numpy as np
 import pandas as pd
 
 from . import classes as var_obj
+from . import _route
 from .packing import row_bytes_for
 
 
@@ -702,7 +703,7 @@ class _DmaWindows(object):
             if self._lib.sh_host_register(w["lo"], w["n"], self._device) != 0:
                 w["state"] = -1
                 self.ok = False        # (a file system whose pages cannot be pinned: the rows are staged through pinned memory from here on)
-                if os.environ.get("SEERHIP_CLI_TIMING") is not None:
+                if _route.debug("cli"):
                     sys.stderr.write("[cli timing] the packed-cache mapping cannot be registered for DMA (%s): rows are staged through pinned memory\n"
                                      % self._lib.sh_last_error().decode())
                 return False, None
@@ -840,7 +841,7 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
         if acc:
             yield acc
 
-    use_dma = raw and device is not None and os.environ.get("SEERHIP_DMA", "1") != "0"
+    use_dma = raw and device is not None and _route.route("dma", "1") != "0"
     windows = _DmaWindows(device) if use_dma else None
 
     def finished():                      # merging and a block's host preparation (6 ms per 262 144 rows) on the reader's thread, ahead of the engine

@@ -263,22 +263,21 @@ def test_bench_one_rank_under_torchrun_equals_the_plain_launch():
 def test_automatic_limb_count_follows_the_tolerance(c3, monkeypatch):
     """sh_lmm_setup(n_limbs = 0) takes the smallest L in {4, 5} whose typical a-posteriori bound is at most a quarter of the tolerance:
     4 on the benchmark's kinship at the default 1e-8, 5 when the tolerance is tightened 100x or the extra-limb pass is off; an
-    explicit count and SEERHIP_LMM_LIMBS override it.  Whatever was chosen, the reported typical bound respects the rule."""
+    explicit count and SEERHIP_ROUTE lmm_limbs override it.  Whatever was chosen, the reported typical bound respects the rule."""
     from pyseer_amd.engine import Engine
 
-    def limbs(n_limbs=0, **env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    def limbs(n_limbs=0, **route):
+        if route:
+            monkeypatch.setenv("SEERHIP_ROUTE", ",".join("%s=%s" % kv for kv in route.items()))
         e = Engine(c3["N"]); e.lmm_setup(c3["U"], c3["S"], c3["y"], c3["C"], c3["h2"], n_limbs=n_limbs); info = e.lmm_info(); e.close()
-        for k in env:
-            monkeypatch.delenv(k)
+        monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
         return info
     a = limbs()
     assert a["n_limbs"] == 4 and a["bound_rel_typical"] <= 0.25e-8, a
-    b = limbs(SEERHIP_LMM_TOL="1e-10")
+    b = limbs(lmm_tol="1e-10")
     assert b["n_limbs"] == 5 and b["bound_rel_typical"] <= 0.25e-10 * 1.0001, b
-    assert limbs(SEERHIP_LMM_TOL="0")["n_limbs"] == 5            # no extra-limb pass: nothing would catch a variant over the bound
-    assert limbs(n_limbs=6)["n_limbs"] == 6 and limbs(SEERHIP_LMM_LIMBS="5")["n_limbs"] == 5
+    assert limbs(lmm_tol="0")["n_limbs"] == 5            # no extra-limb pass: nothing would catch a variant over the bound
+    assert limbs(n_limbs=6)["n_limbs"] == 6 and limbs(lmm_limbs="5")["n_limbs"] == 5
 
 
 def test_lmm_setup_reports_a_certificate_above_the_power_iteration(c3):

@@ -1,4 +1,4 @@
-"""SEERHIP_FIRTH_STRICT=1: the Firth step-halving test is the reference's literal `F(new) > F(old)` (pyseer/model.py:465-474) -- no
+"""SEERHIP_ROUTE firth_strict=1: the Firth step-halving test is the reference's literal `F(new) > F(old)` (pyseer/model.py:465-474) -- no
 "accept steps below 1e-10", no "an increase within 4 ulp of F is noise" (case 1; GlmParams.firth_noise /
 firth_accept).  In this mode the kernels are compared with the UNMODIFIED oracle (orc_fit_firth with both test knobs at 0), spurious
 firth-fails included.  The only fallback allowed is exact-tie detection: a row that differs must equal the oracle re-run with the first
@@ -33,12 +33,12 @@ def _oracle_variants(fn):
 
 def _run_strict(monkeypatch, N, q, W, y, K, nl, nf):
     from pyseer_amd.engine import Engine, pack_variants
-    monkeypatch.setenv("SEERHIP_FIRTH_STRICT", "1")
+    monkeypatch.setenv("SEERHIP_ROUTE", "firth_strict=1")
     e = Engine(N)
     e.glm_setup(y, W, False, nl, nf, force_firth=True)             # the switch is read by sh_glm_setup
     r = e.glm_batch(pack_variants(K))
     e.close()
-    monkeypatch.delenv("SEERHIP_FIRTH_STRICT")
+    monkeypatch.delenv("SEERHIP_ROUTE")
     return r
 
 
@@ -88,8 +88,8 @@ def _run_env(monkeypatch, env, N, W, y, K, nl, nf):
 
 def test_the_three_firth_modes_differ_only_where_documented(monkeypatch):
     """One forced-Firth batch in the three modes: default (the two noise rules: an increase of F within 4 ulp is not an increase, steps
-    below 1e-10 are accepted), SEERHIP_FIRTH_LITERAL=1 (the reference's literal `F(new) > F(old)` on the rounds' own evaluation of F; the
-    1000-step walk at the fixed point of the halving map is cut short with the same verdict) and SEERHIP_FIRTH_STRICT=1 (literal rule, one
+    below 1e-10 are accepted), SEERHIP_ROUTE firth_literal=1 (the reference's literal `F(new) > F(old)` on the rounds' own evaluation of F; the
+    1000-step walk at the fixed point of the halving map is cut short with the same verdict) and SEERHIP_ROUTE firth_strict=1 (literal rule, one
     log per sample, the reference's start vector).  Statistics agree to the noise floor of the halving test (3e-7 absolute) wherever two
     modes both converge; the only flag that may differ is firth-fail (with the filter bits that follow it); the default mode never fails
     where a literal mode converges -- a literal-mode failure on such a row is the reference's spurious step_limit exhaustion, which depends
@@ -102,9 +102,9 @@ def test_the_three_firth_modes_differ_only_where_documented(monkeypatch):
     K = (rng.random((V, N)) < rng.uniform(0.02, 0.98, V)[:, None]).astype(np.uint8)
     e0 = np.zeros((0, 0))
     nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
-    d = _run_env(monkeypatch, {"SEERHIP_FIRTH_LITERAL": "1"}, N, W, y, K, nl, nf)
+    d = _run_env(monkeypatch, {"SEERHIP_ROUTE": "firth_literal=1"}, N, W, y, K, nl, nf)
     t = _run_env(monkeypatch, {}, N, W, y, K, nl, nf)
-    s = _run_env(monkeypatch, {"SEERHIP_FIRTH_STRICT": "1"}, N, W, y, K, nl, nf)
+    s = _run_env(monkeypatch, {"SEERHIP_ROUTE": "firth_strict=1"}, N, W, y, K, nl, nf)
     ff = {k: (r["flags"] >> 6) & 1 for k, r in (("literal", d), ("default", t), ("strict", s))}
     assert (ff["default"] <= ff["literal"]).all() and (ff["default"] <= ff["strict"]).all()
     for a, b, na, nb in ((d, t, "literal", "default"), (d, s, "literal", "strict"), (t, s, "default", "strict")):

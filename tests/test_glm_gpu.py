@@ -715,7 +715,7 @@ def test_strong_effects_and_awkward_covariates_sweep(N, q, V, seed):
 @pytest.mark.parametrize("N,q,V", [(5000, 10, 4096), (4100, 1, 1024), (4099, 3, 777), (6007, 7, 1500), (4096, 10, 640), (8200, 5, 512)])
 def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     """Forced Firth at N >= 4096 (BASELINE config C4's mode): the one-pass iteration (firth_fast.hip: third-moment tensor and information matrix
-    on the matrix cores, fits finished in the kernel) against the exact two-pass rounds (SEERHIP_FIRTH_FAST=0).  Same flags; statistics to
+    on the matrix cores, fits finished in the kernel) against the exact two-pass rounds (SEERHIP_ROUTE firth_fast=0).  Same flags; statistics to
     1e-6 relative (kbeta: or 2e-8 absolute -- the penalty's share of the fixed point carries the matrix-core sums' 1e-6); sample counts that
     are not multiples of 16 or 64, every supported design width, majority-carrier rows (taken by their complement), rare rows, rows no
     iteration can fit (all carriers share the phenotype: those leave the fast passes for the exact kernels)."""
@@ -737,9 +737,9 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     out = {}
     for mode, val in (("two", "0"), ("one", None)):
         if val is None:
-            monkeypatch.delenv("SEERHIP_FIRTH_FAST", raising=False)
+            monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
         else:
-            monkeypatch.setenv("SEERHIP_FIRTH_FAST", val)
+            monkeypatch.setenv("SEERHIP_ROUTE", "firth_fast=" + val)
         e = Engine(N); e.set_af_filter(0.01, 0.99); e.glm_setup(y, W, False, nl, nf, force_firth=True); out[mode] = e.glm_batch(bits); e.close()
     a, b = out["two"], out["one"]
     assert np.array_equal(a["flags"], b["flags"]), np.where(a["flags"] != b["flags"])[0][:10]
@@ -804,3 +804,60 @@ def test_contexts_on_one_device_run_concurrently_and_agree_bit_for_bit():
     assert (np.bitwise_and(want[0][1], 0x7C) != 0).sum() > 10         # Firth-routed rows were among them
     for _, e in ctxs:
         e.close()
+
+
+def test_the_lanes_of_a_context_return_the_synchronous_rows(monkeypatch):
+    """sh_glm_batch_dev_async (csrc/lanes_api.inc): batches handed to the worker threads of ONE context -- each with its own stream and
+    workspaces, set up from the arguments and the route string of the context's own sh_glm_setup -- return the bytes of the synchronous call
+    for the same rows, with 1, 2 and 4 lanes (sh_set_lanes; SEERHIP_ROUTE lanes=n sets the default), more batches in flight than lanes, and
+    after the model of the context has been replaced.  The counterpart of the reference's pool of --cpu N workers over blocks of
+    variants (pyseer/__main__.py:541-568)."""
+    import torch
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    N, q, V = 700, 5, 30000
+    rng = np.random.default_rng(32)
+    W = rng.standard_normal((N, q))
+    y = (rng.random(N) < 1 / (1 + np.exp(-(-0.3 + 0.9 * W[:, 0])))).astype(float)
+    af = np.concatenate([rng.uniform(0.02, 0.98, V - V // 5), rng.uniform(0.0, 0.02, V // 5)])
+    K = (rng.random((V, N)) < af[:, None]).astype(np.uint8)
+    K[:300] = (rng.random((300, N)) < (0.1 + 0.8 * y)[None, :]).astype(np.uint8)
+    e0 = np.zeros((0, 0))
+    rows = [torch.from_numpy(pack_variants(K[s::5])).cuda() for s in range(5)]          # five different batches
+    monkeypatch.setenv("SEERHIP_ROUTE", "lanes=2")
+    e = Engine(N); e.set_af_filter(0.01, 0.99)
+    monkeypatch.delenv("SEERHIP_ROUTE")
+    assert e.get_lanes() == 2
+
+    def both(y_, W_, force):
+        nl = fit_null(y_, W_, e0, False).llf; nf = fit_null(y_, W_, e0, False, firth=True)
+        e.glm_setup(y_, W_, False, nl, nf, 1.0, 1.0, force_firth=force)
+        want = []
+        for r in rows:
+            o, f = e.glm_batch_dev(r); torch.cuda.synchronize()
+            want.append((o.cpu().numpy().copy(), f.cpu().numpy().copy()))
+        for lanes in (None, 1, 4):
+            if lanes is not None:
+                e.set_lanes(lanes)
+            outs = [torch.zeros((5 + W_.shape[1], r.shape[0]), dtype=torch.float64, device="cuda") for r in rows * 2]
+            fls = [torch.zeros((r.shape[0],), dtype=torch.int32, device="cuda") for r in rows * 2]
+            for i in range(10):                                        # ten batches in flight at most: more than 2 x lanes
+                e.glm_batch_dev_async(rows[i % 5], outs[i], fls[i])
+            e.wait(); torch.cuda.synchronize()
+            for i in range(10):
+                assert np.array_equal(outs[i].cpu().numpy().view(np.uint8), want[i % 5][0].view(np.uint8)), (lanes, i)
+                assert np.array_equal(fls[i].cpu().numpy(), want[i % 5][1]), (lanes, i)
+        return want
+    w1 = both(y, W, False)
+    assert (np.bitwise_and(w1[0][1], 0x7C) != 0).sum() > 10           # Firth-routed rows were among them
+    # another model on the same context (the lanes are torn down and set up again from it), every variant through Firth
+    y2 = (rng.random(N) < 0.35).astype(float)
+    w2 = both(y2, W[:, :3].copy(), True)
+    assert not np.array_equal(w1[0][0][2], w2[0][0][2])
+    # a shape error is reported by the call itself
+    import pytest as _pt
+    from pyseer_amd._abi import SeerHipError
+    with _pt.raises(SeerHipError):
+        e.glm_batch_dev_async(rows[0][:, :40].contiguous(), torch.zeros((8, rows[0].shape[0]), dtype=torch.float64, device="cuda"),
+                              torch.zeros((rows[0].shape[0],), dtype=torch.int32, device="cuda"))
+    e.close()

@@ -126,6 +126,7 @@ def test_job_stream_refuses_a_fourth_block_in_flight_and_bad_shapes():
     N = 300
     e = _setup(True, N)
     job = Job(e, True)
+    assert job.depth == 3
     b = _rows(N, 64, 1)
     for _ in range(3):
         job.submit(*b)
@@ -140,6 +141,28 @@ def test_job_stream_refuses_a_fourth_block_in_flight_and_bad_shapes():
     with pytest.raises(_abi.SeerHipError):
         job.submit(narrow, np.zeros(4, np.int32), b"abcd", np.arange(5, dtype=np.int64))
     job.close(); e.close()
+    # a fixed-effects job computes its blocks on the context's lanes: its ring is 2 + lanes deep, and what it returns does not depend on them
+    texts = {}
+    for lanes in (3, 1):
+        e = _setup(False, N)
+        e.set_lanes(lanes)
+        job = Job(e, False)
+        assert job.depth == (2 + lanes if lanes > 1 else 3)
+        blocks = [_rows(N, 3000, 7 + i) for i in range(7)]
+        got = []
+        for b in blocks:
+            while job.pending() >= job.depth:
+                t, c, _ = job.collect(); got.append((bytes(t), c))
+            job.submit(*b)
+        if lanes > 1:
+            assert job.pending() == job.depth
+            with pytest.raises(_abi.SeerHipError):
+                job.submit(*blocks[0])
+        while job.pending():
+            t, c, _ = job.collect(); got.append((bytes(t), c))
+        texts[lanes] = got
+        job.close(); e.close()
+    assert texts[3] == texts[1] and sum(c[2] for _, c in texts[3]) > 0
 
 
 def test_two_contexts_two_jobs_concurrently():

@@ -596,7 +596,7 @@ def test_complemented_rows_change_nothing_but_rounding(engine_mod, monkeypatch):
 
 @pytest.mark.parametrize("N,V,limbs", [(520, 700, 0), (660, 513, 4), (680, 512, 4), (760, 100, 5), (1100, 1536, 5), (2049, 600, 4)])
 def test_one_wave_and_two_wave_contractions_agree_bit_for_bit(engine_mod, monkeypatch, N, V, limbs):
-    """k_lmm_quadform_i8w (one wavefront per SIMD, the default where its conditions hold: here N >= 512) and k_lmm_quadform_i8 (SEERHIP_QF=0, read
+    """k_lmm_quadform_i8w (one wavefront per SIMD, the default where its conditions hold: here N >= 512) and k_lmm_quadform_i8 (SEERHIP_ROUTE qf=0, read
     when the context is created; also the fallback for fewer than four row tiles) are the same exact integer contraction with the same fp64
     recombination: every output double must be identical, whatever the shape (V not a multiple of the block, several launches' worth of tiles).
     The sample counts cover the one-wave kernel's treatment of the last 128-row tile (NR = 2 ceil(N / 256) row tiles): all padding and dropped
@@ -607,11 +607,11 @@ def test_one_wave_and_two_wave_contractions_agree_bit_for_bit(engine_mod, monkey
     bits = pack(Kv)
     out = []
     for qf in ("4", "0"):
-        monkeypatch.setenv("SEERHIP_QF", qf)
+        monkeypatch.setenv("SEERHIP_ROUTE", "qf=" + qf)
         e = Engine(N)
         e.lmm_setup(U, S, y, covar, 0.33, n_limbs=limbs)
         out.append(e.lmm_batch(bits)); e.close()
-    monkeypatch.delenv("SEERHIP_QF")
+    monkeypatch.delenv("SEERHIP_ROUTE")
     a, b = out
     assert np.array_equal(a["flags"], b["flags"])
     for f in ("prep", "beta", "bse", "pvalue", "frac_h2"):

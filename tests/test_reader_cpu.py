@@ -200,7 +200,7 @@ def _kmer_text(samples, nlines, seed):
 
 def test_every_container_gives_the_same_blocks(tmp_path, monkeypatch):
     """Plain text, single-member gzip (levels 1/6/9, stored blocks), concatenated members, BGZF, and zlib's own gzread as the yardstick:
-    the in-tree inflate (csrc/inflate_fast.h) on one thread (SEERHIP_READER=serial) and on several (csrc/inflate_par.h; by default only for
+    the in-tree inflate (csrc/inflate_fast.h) on one thread (SEERHIP_ROUTE reader=serial) and on several (csrc/inflate_par.h; by default only for
     files of two chunks or more, so the chunk is made tiny here) and the member-parallel BGZF path hand the parser the same bytes."""
     import zlib
     samples = ["iso%03d" % i for i in range(150)]
@@ -223,9 +223,8 @@ def test_every_container_gives_the_same_blocks(tmp_path, monkeypatch):
                 if sel.startswith("par"):                                   # one member on several threads (csrc/inflate_par.h), tiny chunks
                     monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=50000,reader_chunk=" + sel[3:])
                 else:
-                    monkeypatch.setenv("SEERHIP_READER", sel)
+                    monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=50000,reader=" + sel)
             got = [(n, b.copy(), c.copy()) for n, b, c in NativeKmerReader(path, samples, 97)]
-            monkeypatch.delenv("SEERHIP_READER", raising=False)
             monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=50000")
             names = sum((g[0] for g in got), [])
             bits = np.concatenate([g[1] for g in got]); counts = np.concatenate([g[2] for g in got])
@@ -260,10 +259,7 @@ def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
     assert gzip.decompress(files["mixed.gz"]) == text
     del co, co2, mixed
     def read(path, route, sel=None, threads=None):
-        monkeypatch.setenv("SEERHIP_ROUTE", route)
-        for k, v in (("SEERHIP_READER", sel), ("SEERHIP_READER_THREADS", threads)):
-            if v is None: monkeypatch.delenv(k, raising=False)
-            else: monkeypatch.setenv(k, v)
+        monkeypatch.setenv("SEERHIP_ROUTE", ",".join([route] + ["%s=%s" % (k, v) for k, v in (("reader", sel), ("reader_threads", threads)) if v is not None]))
         rd = NativeKmerReader(path, samples, 1000)
         names, bits, counts, pc = [], [], [], 0
         for n, b, c in rd:
@@ -520,7 +516,7 @@ def test_packed_cache_ranges_partition_the_rows(tmp_path, n_parts):
 
 
 def test_parser_worker_count_does_not_change_the_rows(tmp_path, monkeypatch):
-    """SEERHIP_READER_THREADS (parser workers of the native reader; default min(48, cores)): one worker and five give the rows of the default."""
+    """SEERHIP_ROUTE reader_threads (parser workers of the native reader; default min(48, cores)): one worker and five give the rows of the default."""
     import gzip
     samples = ["s%03d" % i for i in range(61)]
     p = pd.Series(np.arange(61, dtype=float), index=samples)
@@ -535,9 +531,9 @@ def test_parser_worker_count_does_not_change_the_rows(tmp_path, monkeypatch):
     got = {}
     for nt in (None, "1", "5"):
         if nt is None:
-            monkeypatch.delenv("SEERHIP_READER_THREADS", raising=False)
+            monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
         else:
-            monkeypatch.setenv("SEERHIP_READER_THREADS", nt)
+            monkeypatch.setenv("SEERHIP_ROUTE", "reader_threads=" + nt)
         blocks = list(iter_packed_blocks_native(p, path, 0.0, 1.0, 128))
         got[nt] = (np.concatenate([np.array(b.bits) for b in blocks]), b"".join(bytes(b.names_blob) for b in blocks))
     assert np.array_equal(got[None][0], got["1"][0]) and np.array_equal(got[None][0], got["5"][0])

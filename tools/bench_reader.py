@@ -1,6 +1,6 @@
 """Throughput of the native k-mer reader (csrc/reader.cpp) on a synthetic k-mer file, N samples x V k-mers, by container:
-plain text, gzip through zlib's gzread (SEERHIP_READER=zlib, the round-1 path), gzip through the in-tree inflate on one thread
-(SEERHIP_READER=serial) and on several (the default, csrc/inflate_par.h), BGZF (member-parallel).
+plain text, gzip through zlib's gzread (SEERHIP_ROUTE reader=zlib, the round-1 path), gzip through the in-tree inflate on one thread
+(SEERHIP_ROUTE reader=serial) and on several (the default, csrc/inflate_par.h), BGZF (member-parallel).
 No GPU involved; run it on the GPU host to see what feeds the engine there.  Prints one JSON line."""
 import gzip, json, os, struct, sys, time, zlib
 import numpy as np
@@ -42,8 +42,10 @@ want = None
 TAGS = os.environ.get("TAGS", "").split(",") if os.environ.get("TAGS") else None
 for tag, path, env in (("plain", "k.txt", None), ("gzip_zlib", "k.gz", "zlib"), ("gzip_fast", "k.gz", "serial"), ("gzip_par", "k.gz", None), ("bgzf", "k.bgzf.gz", None)):
     if TAGS and tag not in TAGS: continue
-    if env: os.environ["SEERHIP_READER"] = env
-    else: os.environ.pop("SEERHIP_READER", None)
+    base = ",".join(it for it in os.environ.get("SEERHIP_ROUTE", "").split(",") if it and not it.startswith("reader="))
+    route = ",".join(x for x in (base, "reader=" + env if env else "") if x)
+    if route: os.environ["SEERHIP_ROUTE"] = route
+    else: os.environ.pop("SEERHIP_ROUTE", None)
     best = 0.0
     for rep in range(int(os.environ.get("REPS", 2))):
         t0 = time.time(); tot = 0; cs = 0
@@ -56,7 +58,7 @@ for tag, path, env in (("plain", "k.txt", None), ("gzip_zlib", "k.gz", "zlib"), 
         assert cs == want, (tag, cs, want)
     res[tag + "_kmers_per_s"] = best; res[tag + "_text_MBps"] = best * len(text) / V / 1e6
 if TAGS:
-    res["reader_threads"] = os.environ.get("SEERHIP_READER_THREADS"); res["route"] = os.environ.get("SEERHIP_ROUTE")
+    res["route"] = os.environ.get("SEERHIP_ROUTE")
     print(json.dumps(res)); sys.exit(0)
 # the same gzip text cut into NF files at line boundaries and read as one stream (--kmers a.gz b.gz ...): one reader thread per file
 import pandas as pd

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): tools/gpu_ab.sh <config> <name> [<name> ...]   -- per-kernel averages of bench.py --config <config> for A/B builds in pyseer_amd/ab/
-# ("cur" = the in-tree library).  Extra environment (e.g. SEERHIP_FIRTH_NOISE=1) is passed through.
+# ("cur" = the in-tree library).  Extra environment (e.g. SEERHIP_ROUTE=firth_literal=1) is passed through.
 R=$GRAFT_REPO_ROOT; cfg=$1; shift
 cd /tmp; export TMPDIR=/tmp
 for n in "$@"; do

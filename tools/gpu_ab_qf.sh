@@ -3,5 +3,5 @@
 R=$GRAFT_REPO_ROOT
 for n in "$@"; do
   lib=$R/pyseer_amd/ab/libseerhip_$n.so; [ "$n" = "cur" ] && lib=$R/pyseer_amd/libseerhip.so
-  echo "== $n $(SEERHIP_LIB=$lib SEERHIP_QF=${QF:-4} V=${V:-262144} L=${L:-4} python $R/tools/gpu_probe_lmm.py 2>&1 | grep 'quadform ms')"
+  echo "== $n $(SEERHIP_LIB=$lib SEERHIP_ROUTE=qf=${QF:-4} V=${V:-262144} L=${L:-4} python $R/tools/gpu_probe_lmm.py 2>&1 | grep 'quadform ms')"
 done

@@ -21,7 +21,7 @@ af = rows.mean(axis=1); inwin = (af >= 0.01) & (af <= 0.99)
 orc.set_threads(bench.effective_cpus())
 w = orc.firth_batch(y, rows, W)
 res = {"restatement": dict(kbeta=w["kbeta"], bse=w["bse"], intercept=w["intercept"], fail=(w["status"] != 0) & inwin)}
-for mode, env in (("noise", {}), ("literal", {"SEERHIP_FIRTH_LITERAL": "1"}), ("strict", {"SEERHIP_FIRTH_STRICT": "1"})):
+for mode, env in (("noise", {}), ("literal", {"SEERHIP_ROUTE": "firth_literal=1"}), ("strict", {"SEERHIP_ROUTE": "firth_strict=1"})):
     for k, v_ in env.items():
         os.environ[k] = v_
     e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)

@@ -22,7 +22,7 @@ with open(d + "/cov.tsv", "w") as f:
     for i in range(N):
         f.write(names[i] + "\t" + "\t".join(repr(float(x)) for x in W[i]) + "\n")
 V = None
-env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_CLI_TIMING"] = "1"
+env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_DEBUG"] = "cli"
 res = {"n_samples": N, "block_size": BLK, "covariates": 10, "cache_GB": os.path.getsize(src + "/kmers.seerpack") / 1e9}
 runs = [("overlapped", []), ("serial", ["--serial-sink"])]
 if os.environ.get("E2E_EXTRA"):                              # e.g. "--gpus 0,0": a probe, not part of the record

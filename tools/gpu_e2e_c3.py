@@ -3,7 +3,7 @@
 the kinship decomposition of bench.py's C3 workload saved as the reference's --save-lmm cache, the k-mer rows generated on the GPU in the
 bench's AF mix and written in the packed-cache format (no text involved: this measures the steady state a second run over a k-mer file sees).
 Reports rows/s end to end and the split of a block's time into engine call (H2D + GPU + D2H) / sink (masking, formatting) / write, measured
-with SEERHIP_CLI_TIMING=1; runs the default (overlapped) loop and --serial-sink, and compares their output bytes."""
+with SEERHIP_DEBUG=cli; runs the default (overlapped) loop and --serial-sink, and compares their output bytes."""
 import json, os, resource, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -39,7 +39,7 @@ open(d + "/kmers.txt", "w").write("AAAA | sample_00000:1\n")    # the CLI wants 
 print("inputs: %d k-mers x %d samples, cache %.2f GB, written in %.1f s" % (V, N, os.path.getsize(d + "/kmers.seerpack") / 1e9, time.time() - t0))
 del U
 torch.cuda.empty_cache()
-env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_CLI_TIMING"] = "1"
+env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_DEBUG"] = "cli"
 res = {"n_samples": N, "k_mers": V, "block_size": BLK, "cache_GB": os.path.getsize(d + "/kmers.seerpack") / 1e9}
 runs = [("overlapped", [], {}), ("serial", ["--serial-sink"], {})]
 if os.environ.get("E2E_GPUS"):            # e.g. "0,0": two contexts on one device = the multi-device job path (one pipelined stream per context over its

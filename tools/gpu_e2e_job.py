@@ -1,7 +1,7 @@
 """The host budget of the `--gpus` job (VERDICT r04 "next" 1): C3 as a user runs it from a packed cache --
 `python -m pyseer_amd --lmm --load-lmm cache.npz --load-packed kmers.seerpack [--lrt-pvalue 1e-3] [--gpus 0,0,0,0,0,0,0,0]` at N = 5000 over V
 packed k-mers -- with one context and with EIGHT contexts on the one device of the box (the only stand-in for an 8-GPU node), through the
-round-4 sink (SEERHIP_JOB=0) and through the job stream, output compared byte for byte.  For every run: wall time, rows/s, and the CPU
+round-4 sink (SEERHIP_ROUTE job=0) and through the job stream, output compared byte for byte.  For every run: wall time, rows/s, and the CPU
 seconds the block loop cost (process getrusage over the loop, the library's per-stage thread CPU, the loop threads' CPU: the "[cli budget]"
 line of pyseer_amd/__main__.py).  Writes gpurun_out/r05/host_budget.json:
     cpu_s_per_million_rows (by stage)  and  cpus_needed_at_8x33M = cpu_s_per_million_rows x 8 x 33 (million rows/s) against the box's quota."""
@@ -46,7 +46,7 @@ try:
     quota = None if q == "max" else float(q) / float(per)
 except Exception:
     pass
-env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_CLI_TIMING"] = "1"
+env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_DEBUG"] = "cli"
 res = {"n_samples": N, "k_mers": V, "block_size": BLK, "cache_GB": os.path.getsize(d + "/kmers.seerpack") / 1e9, "cpu_quota": quota, "nproc": os.cpu_count(), "runs": {}}
 
 
@@ -99,13 +99,14 @@ for lrt, tag in [x.split(":") for x in os.environ.get("E2E_LRT", "1e-3:lrt1e-3,1
     md5 = set()
     for w_ in WHICH:
         extra = L + (["--gpus", GPUS8] if "8ctx" in w_ else [])
-        env_more = {}
+        rt = []
         if w_.startswith("r04sink"):
-            env_more["SEERHIP_JOB"] = "0"
+            rt.append("job=0")
         if w_.endswith("_spin"):
-            env_more["SEERHIP_WAIT"] = "spin"
+            rt.append("wait=spin")
         if w_.endswith("_staged"):
-            env_more["SEERHIP_DMA"] = "0"
+            rt.append("dma=0")
+        env_more = {"SEERHIP_ROUTE": ",".join(rt)} if rt else {}
         md5.add(run(w_ + "_" + tag, extra, env_more)["md5"])
     res["identical_" + tag] = len(md5) == 1
     print("outputs identical (%s): %s" % (tag, res["identical_" + tag]), flush=True)

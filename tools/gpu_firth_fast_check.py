@@ -1,4 +1,4 @@
-"""The one-pass Firth iteration (firth_fast.hip) against the two-pass rounds (SEERHIP_FIRTH_FAST=0) on the C4 workload: same flags, statistics to
+"""The one-pass Firth iteration (firth_fast.hip) against the two-pass rounds (SEERHIP_ROUTE firth_fast=0) on the C4 workload: same flags, statistics to
 1e-6, and the time of a batch each way.  Also the reference's own answers on the 106 rows of tests/golden/n5000_firth.npz."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 bits = bench.synth_bits(V, N, row_bytes_for(N), 4242, dev)
 res = {}
 outs = {}
-for mode, env in (("two_pass", {"SEERHIP_FIRTH_FAST": "0"}), ("one_pass", {})):
+for mode, env in (("two_pass", {"SEERHIP_ROUTE": "firth_fast=0"}), ("one_pass", {})):
     for k, v_ in env.items():
         os.environ[k] = v_
     e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)

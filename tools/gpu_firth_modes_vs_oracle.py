@@ -1,8 +1,8 @@
 """Which Firth step-halving mode agrees with the reference restatement (the CPU oracle, oracle/seer_oracle.c orc_fit_firth, both test knobs 0)
 row by row?  C4 workload (N = 5000, 10 covariates, every variant through fit_firth), V variants:
   noise     (default) an increase within 4 ulp of F is not an increase, steps below 1e-10 are accepted
-  literal   SEERHIP_FIRTH_LITERAL=1: the reference's `F(new) > F(old)`, F as the round kernels evaluate it
-  strict    SEERHIP_FIRTH_STRICT=1: literal rule, one log per sample, the reference's start vector
+  literal   SEERHIP_ROUTE firth_literal=1: the reference's `F(new) > F(old)`, F as the round kernels evaluate it
+  strict    SEERHIP_ROUTE firth_strict=1: literal rule, one log per sample, the reference's start vector
 Counts firth-fail rows of each and of the oracle, their overlaps, and the largest |kbeta - oracle| over rows both fit.  Writes gpurun_out/r03/."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +23,7 @@ ofail = (w["status"] != 0) & inwin
 res = {"workload": "C4: N=%d, q=%d, %d variants (%d inside the AF window), force_firth" % (N, q, V, int(inwin.sum())),
        "oracle_firth_fail": int(ofail.sum()), "oracle_seconds": t_or}
 out = {}
-for mode, env in (("noise", {}), ("literal", {"SEERHIP_FIRTH_LITERAL": "1"}), ("strict", {"SEERHIP_FIRTH_STRICT": "1"})):
+for mode, env in (("noise", {}), ("literal", {"SEERHIP_ROUTE": "firth_literal=1"}), ("strict", {"SEERHIP_ROUTE": "firth_strict=1"})):
     for k, v_ in env.items():
         os.environ[k] = v_
     e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)

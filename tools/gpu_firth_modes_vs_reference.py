@@ -2,8 +2,8 @@
 C4 workload: tests/golden/n5000_firth.npz holds the 82 rows on which the modes or the C restatement disagreed (firth-fail flag, or
 |dkbeta| > 1e-7) plus 24 controls, with the reference's own answer for each (tests/golden/make_n5000_golden.py).
   noise     (default) an increase of F within 4 ulp is not an increase, steps below 1e-10 are accepted
-  literal   SEERHIP_FIRTH_LITERAL=1: `F(new) > F(old)` on the rounds' own evaluation of F
-  strict    SEERHIP_FIRTH_STRICT=1: literal rule, one log per sample, the reference's start vector
+  literal   SEERHIP_ROUTE firth_literal=1: `F(new) > F(old)` on the rounds' own evaluation of F
+  strict    SEERHIP_ROUTE firth_strict=1: literal rule, one log per sample, the reference's start vector
 Also the CPU restatement (oracle/seer_oracle.c) as it is now (log-likelihood summed in numpy's pairwise order) .
 Writes gpurun_out/r04/firth_modes_vs_real_reference.json (copied to profiles/r04/)."""
 import json, os, sys
@@ -34,7 +34,7 @@ res = {"rows": int(bits.shape[0]), "disputed_rows": int(d["disputed"].sum()), "r
 w = orc.firth_batch(y, np.unpackbits(bits, axis=1, bitorder="little")[:, :N].astype(float), W)
 res["restatement_pairwise_loglike"] = score(w["kbeta"], w["bse"], w["intercept"], w["status"] != 0)
 res["restatement_round3_running_sum"] = score(d["r3_restatement_kbeta"], d["r3_restatement_bse"], d["r3_restatement_intercept"], d["r3_restatement_fail"])
-for mode, env in (("noise", {}), ("literal", {"SEERHIP_FIRTH_LITERAL": "1"}), ("strict", {"SEERHIP_FIRTH_STRICT": "1"})):
+for mode, env in (("noise", {}), ("literal", {"SEERHIP_ROUTE": "firth_literal=1"}), ("strict", {"SEERHIP_ROUTE": "firth_strict=1"})):
     for k, v_ in env.items():
         os.environ[k] = v_
     e = Engine(N); e.set_af_filter(0.01, 0.99)

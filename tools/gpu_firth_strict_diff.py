@@ -1,5 +1,5 @@
 """How often do the default Firth noise rules change an output?  C4 workload (N = 5000, 10 covariates, every variant through Firth) in the
-default mode and with SEERHIP_FIRTH_STRICT=1 (the reference's literal step-halving test); writes a small JSON (copied to profiles/r02/)."""
+default mode and with SEERHIP_ROUTE firth_strict=1 (the reference's literal step-halving test); writes a small JSON (copied to profiles/r02/)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ bits = bench.synth_bits(V, N, row_bytes_for(N), 4242, dev)
 res = {}
 for mode in ("default", "strict"):
     if mode == "strict":
-        os.environ["SEERHIP_FIRTH_STRICT"] = "1"
+        os.environ["SEERHIP_ROUTE"] = "firth_strict=1"
     e = Engine(N); e.use_torch_stream(); e.set_af_filter(0.01, 0.99)
     e.glm_setup(y, W, False, nl, nf, force_firth=True)
     e.glm_batch_dev(bits); torch.cuda.synchronize()

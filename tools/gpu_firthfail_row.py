@@ -13,7 +13,7 @@ for path in sorted(glob.glob(os.path.join(root, "tests", "golden", "glm_exit_fir
     ff = np.where(d["notes"] & 0x40)[0]
     res[name] = {"N": int(d["N"]), "q": int(d["q"]), "reference_firth_fail_rows": ff.tolist(),
                  "reference_notes_in_three_other_sample_orders": d["perm_notes"][ff].tolist()}
-    for mode, env in (("default", {}), ("literal", {"SEERHIP_FIRTH_LITERAL": "1"}), ("strict", {"SEERHIP_FIRTH_STRICT": "1"})):
+    for mode, env in (("default", {}), ("literal", {"SEERHIP_ROUTE": "firth_literal=1"}), ("strict", {"SEERHIP_ROUTE": "firth_strict=1"})):
         os.environ.update(env)
         e = Engine(int(d["N"])); e.set_af_filter(0.01, 0.99)
         e.glm_setup(d["y"], d["m"], False, float(d["null_llf"]), float(d["null_firth"]), 1.0, 1.0)

@@ -1,4 +1,4 @@
-"""One-off fuzz: k_lmm_quadform_i8w (SEERHIP_QF=4, the default) against k_lmm_quadform_i8 (SEERHIP_QF=0) on random shapes -- every output double
+"""One-off fuzz: k_lmm_quadform_i8w (SEERHIP_ROUTE qf=4, the default) against k_lmm_quadform_i8 (SEERHIP_ROUTE qf=0) on random shapes -- every output double
 must be identical (the two kernels are the same exact integer contraction; tests/test_lmm_gpu.py holds six fixed shapes)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,7 @@ for c in range(cases):
     bits = pack_variants(Kv)
     out = []
     for qf in ("4", "0"):
-        os.environ["SEERHIP_QF"] = qf
+        os.environ["SEERHIP_ROUTE"] = "qf=" + qf
         e = Engine(N); e.lmm_setup(U, S, y, covar, 0.3, n_limbs=limbs); out.append(e.lmm_batch(bits)); e.close()
     a, b = out
     same = np.array_equal(a["flags"], b["flags"]) and all(np.array_equal(a[f].view(np.uint64), b[f].view(np.uint64)) for f in ("prep", "beta", "bse", "pvalue", "frac_h2"))
