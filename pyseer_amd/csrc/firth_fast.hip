@@ -455,7 +455,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             }
             fw.st[(int64_t)fw_snp<PC>() * cap + s] = INFINITY;
             fw.iter[s] = -1; fw.halv[s] = 0;
-            exact_list[atomicAdd(exact_count, 1)] = s;
+            list_push(true, exact_list, exact_count, s);
         }
         return;
     }
@@ -541,11 +541,11 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = INFINITY;
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = last ? sn : INFINITY;
         if (!last) { fw.iter[s] = -1; }
-        exact_list[atomicAdd(exact_count, 1)] = s;
+        list_push(true, exact_list, exact_count, s);
     } else {
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = F32 ? (double)INFINITY : F;
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = sn;
-        next_fast[atomicAdd(next_fast_count, 1)] = s;
+        list_push(true, next_fast, next_fast_count, s);
     }
 }
 

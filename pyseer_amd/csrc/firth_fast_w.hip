@@ -20,6 +20,9 @@
 #include "firth_fast_common.h"
 
 typedef float ffw_v4f __attribute__((ext_vector_type(4)));
+#ifndef FFW_ABL
+#define FFW_ABL 0                  /* timing ablations of k_firth_fastw_fin (results meaningless): 1 = no carrier count, 2 = no contraction */
+#endif
 
 template <int Q> struct FFW {
     typedef FFC<Q> C;
@@ -70,6 +73,7 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
     // beta (columns as given) -> the standardised basis x_s = (1, k, (z - m) / s):  b_s0 = b0 + sum m_j b_j,  b_s(2+j) = s_j b_(2+j)
     // a k-mer carried by most samples is taken by its complement (x_1 -> 1 - x_1: b_0 += b_1, b_1 = -b_1), as in firth_fast.hip
     int carriers = 0;
+#pragma unroll 5
     for (int sb = kq; sb < P.NB64; sb += 4) carriers += __popcll(T[(int64_t)sb * Vpad + v]);
     carriers += __shfl_xor(carriers, 16); carriers += __shfl_xor(carriers, 32);
     const bool flip = 2 * carriers > N;
@@ -167,11 +171,23 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
     __syncthreads();
     constexpr int TPP = (NTA + 3) / 4;                     // table tiles whose MFMAs follow each pair of samples
-    uint64_t w64 = 0;
+    // The variant's presence bits, 64 samples per load, fetched a pair of groups ahead BY INLINE ASSEMBLY: a load the compiler knows of gets
+    // `s_waitcnt vmcnt(0)` in front of its first use -- which also waits for every table copy in flight (the compiler does not count them),
+    // i.e. for the stage issued a moment ago, every other iteration.  Here the load is issued in front of this iteration's copies and is
+    // complete at the iteration's own counted wait (it is older than the copies that may stay in flight); its register is read by nothing
+    // but the move behind that wait.
+    // (32 bits per group and iteration, two groups ahead: no branch in the loop)
+    const uint32_t *const T32 = (const uint32_t *)T;
+    auto bits_at = [&](int gi) { const int gc = min(gi, 2 * P.NB64 - 1); return T32 + (((int64_t)(gc >> 1) * Vpad + v) * 2 + (gc & 1)); };
+    uint32_t wcur = *bits_at(0), wnext = *bits_at(1), wraw = 0;
+    asm volatile("" : "+v"(wcur), "+v"(wnext));            // (the compiler's wait for these two loads sits HERE, not in the loop's header)
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
-        if ((g & 1) == 0) w64 = T[(int64_t)min(g >> 1, P.NB64 - 1) * Vpad + v];
-        const uint32_t byte = ((uint32_t)(w64 >> (32 * (g & 1) + 8 * kq)) & 0xffu) ^ flipm;
+        {
+            const uint32_t *wp = bits_at(g + 2);
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(wraw) : "v"(wp));
+        }
+        const uint32_t byte = ((wcur >> (8 * kq)) & 0xffu) ^ flipm;
         dma(min(g + 2, NG));
         const char *const buf = lds + (g % NRING) * STAGE;
         uint32_t Bw[4], Bc[4];
@@ -193,6 +209,8 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
         // this wavefront's share of the next stage has landed (the one after it may be in flight); the bare barrier: everyone's has, and
         // everyone is done reading this stage
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
+        wcur = wnext;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(wnext) : "v"(wraw));
     }
     {                                                       // the MFMAs of the last group
         const char *const buf = lds + (NG % NRING) * STAGE;
@@ -217,6 +235,13 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
 }
 
 // ---- per fit: I, its factor, V, the penalty's contraction, the step, the routing (firth_fast.hip's epilogue on the handed-over sums) -------------
+// A tile's 32 loads are issued together and waited for ONCE: left alone the compiler (under the register pressure of I, V and the gradient)
+// sinks every load to its use -- ~450 serialised global loads per lane, 3.4 ms for 2^18 fits on the first build.
+#define FFW_ROWS_LANDED(row)                                                          \
+    do {                                                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
+        _Pragma("unroll") for (int r_ = 0; r_ < 32; ++r_) row[r_] *= unscale;         \
+    } while (0)
 template <int Q, int... Ts>
 __device__ __forceinline__ void ffw_all2i(const float *__restrict__ ws, int64_t ws_cap, int64_t col, float unscale, const double *__restrict__ inull,
                                           double (&I)[FFC<Q>::NH], double &rho, std::integer_sequence<int, Ts...>)
@@ -225,7 +250,8 @@ __device__ __forceinline__ void ffw_all2i(const float *__restrict__ ws, int64_t 
         constexpr int TL = decltype(tile)::value;
         float row[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) row[r] = (TL * 32 + r < FFW<Q>::T2H * 16) ? ws[(int64_t)(TL * 32 + r) * ws_cap + col] * unscale : 0.0f;
+        for (int r = 0; r < 32; ++r) row[r] = (TL * 32 + r < FFW<Q>::T2H * 16) ? ws[(int64_t)(TL * 32 + r) * ws_cap + col] : 0.0f;
+        FFW_ROWS_LANDED(row);
         ff_tile2i<Q, TL>(row, inull, I, rho, std::make_integer_sequence<int, 32>{});
     };
     (one(std::integral_constant<int, Ts>{}), ...);
@@ -238,7 +264,8 @@ __device__ __forceinline__ void ffw_all3(const float *__restrict__ ws, int64_t w
         constexpr int TL = decltype(tile)::value;
         float row[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) row[r] = (TL * 32 + r < FFW<Q>::T3H * 16) ? ws[(int64_t)(FFW<Q>::T2H * 16 + TL * 32 + r) * ws_cap + col] * unscale : 0.0f;
+        for (int r = 0; r < 32; ++r) row[r] = (TL * 32 + r < FFW<Q>::T3H * 16) ? ws[(int64_t)(FFW<Q>::T2H * 16 + TL * 32 + r) * ws_cap + col] : 0.0f;
+        FFW_ROWS_LANDED(row);
         ff_tile3<Q, TL>(row, V, g, std::make_integer_sequence<int, 32>{});
     };
     (one(std::integral_constant<int, Ts>{}), ...);
@@ -252,7 +279,8 @@ __device__ __forceinline__ void ffw_all2k(const float *__restrict__ ws, int64_t 
         float row[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r)
-            row[r] = (TL * 32 + r < FFW<Q>::T2H * 16) ? ws[(int64_t)((FFW<Q>::T2H + FFW<Q>::T3H) * 16 + TL * 32 + r) * ws_cap + col] * unscale : 0.0f;
+            row[r] = (TL * 32 + r < FFW<Q>::T2H * 16) ? ws[(int64_t)((FFW<Q>::T2H + FFW<Q>::T3H) * 16 + TL * 32 + r) * ws_cap + col] : 0.0f;
+        FFW_ROWS_LANDED(row);
         ff_tile2k<Q, TL>(row, V, g, std::make_integer_sequence<int, 32>{});
     };
     (one(std::integral_constant<int, Ts>{}), ...);
@@ -280,7 +308,9 @@ __global__ __launch_bounds__(64) void k_firth_fastw_fin(const uint64_t *__restri
 #pragma unroll
     for (int a = 0; a < PC; ++a) cand[a] = fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s];
     int carriers = 0;
+#if !(FFW_ABL & 1)
     for (int sb = 0; sb < P.NB64; ++sb) carriers += __popcll(T[(int64_t)sb * Vpad + v]);
+#endif
     const bool flip = 2 * carriers > N;
     double nUd[PC];
 #pragma unroll
@@ -314,7 +344,7 @@ __global__ __launch_bounds__(64) void k_firth_fastw_fin(const uint64_t *__restri
         }
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = INFINITY;
         fw.iter[s] = -1; fw.halv[s] = 0;
-        exact_list[atomicAdd(exact_count, 1)] = s;
+        list_push(true, exact_list, exact_count, s);
         return;
     }
     double Vm[NH];                                          // V = I^-1, packed lower
@@ -331,8 +361,10 @@ __global__ __launch_bounds__(64) void k_firth_fastw_fin(const uint64_t *__restri
     double gp[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) gp[a] = 0.0;
+#if !(FFW_ABL & 2)
     ffw_all3<Q>(ws, ws_cap, li, unscale, Vm, gp, std::make_integer_sequence<int, T3>{});
     ffw_all2k<Q>(ws, ws_cap, li, unscale, Vm, gp, std::make_integer_sequence<int, T2>{});
+#endif
     double U[PC], d[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) U[a] = gp[a] - nUd[a];
@@ -368,11 +400,11 @@ __global__ __launch_bounds__(64) void k_firth_fastw_fin(const uint64_t *__restri
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = INFINITY;
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = last ? sn : INFINITY;
         if (!last) fw.iter[s] = -1;
-        exact_list[atomicAdd(exact_count, 1)] = s;
+        list_push(true, exact_list, exact_count, s);
     } else {
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = INFINITY;
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = sn;
-        next_fast[atomicAdd(next_fast_count, 1)] = s;
+        list_push(true, next_fast, next_fast_count, s);
     }
 }
 

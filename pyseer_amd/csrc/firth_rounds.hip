@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
     }
     const bool singular = !ldl_factor<PC>(A, SING_TOL, &det);
     if (singular) {                     // handled by k_glm_firth_pinv (numpy.linalg.pinv semantics, model.py:450)
-        const int s2 = atomicAdd(pinv_count, 1); pinv_list[s2] = (int)v;
+        list_push(true, pinv_list, pinv_count, (int)v);
         return;
     }
     const double Fcand = -(ll + 0.5 * log(det));                     // firth_likelihood, model.py:410-411
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
                 // ~1e-7), so about half of them are halved once, a quarter twice, ...: the first few halvings are ordinary rounds with long
                 // lists.  After firth_halv_handoff of them the lists are short (a round costs a pass' latency whatever its length) and the
                 // variant is finished by one workgroup, which re-evaluates F(beta) its own way before it compares anything.
-                if (h >= P.firth_halv_handoff) fw.blk_list[atomicAdd(fw.blk_count, 1)] = s;
-                else next_eval[atomicAdd(next_eval_count, 1)] = s;
+                if (h >= P.firth_halv_handoff) list_push(true, fw.blk_list, fw.blk_count, s);
+                else list_push(true, next_eval, next_eval_count, s);
             }
         } else {
             sn = sqrt(sn);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
         }
         fw.st[(int64_t)fw_snp<PC>() * cap + s] = INFINITY;
         fw.iter[s] = -1; fw.halv[s] = 0; fw.var[s] = (int)v;
-        next_eval[atomicAdd(next_eval_count, 1)] = s;
+        list_push(true, next_eval, next_eval_count, s);
         return;
     }
     if (accept && !failed && !conv) {                                // beta <- cand; keep the factor for the score pass
@@ -289,15 +289,15 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
         for (int a = 0; a < NH; ++a) fw.st[(int64_t)(fw_fac<PC>() + a) * cap + s] = A[a];
         fw.st[(int64_t)fw_fcur<PC>() * cap + s] = Fcand;
         fw.iter[s] = iter; fw.halv[s] = 0;
-        if (iter >= P.firth_handoff) fw.blk_list[atomicAdd(fw.blk_count, 1)] = s;
+        if (iter >= P.firth_handoff) list_push(true, fw.blk_list, fw.blk_count, s);
         else {
             // k_firth_step2 evaluates the hat diagonal in single precision in the standardised basis: safe while that basis' factor is well
             // conditioned.  Every pivot against its own diagonal entry (1 - R^2 of that column on the ones before it):
             bool well = A[sidx(1, 1)] >= FIRTH_HAT32_PIVOT * i11c;
 #pragma unroll
             for (int j = 0; j < Q; ++j) well = well && (A[sidx(2 + j, 2 + j)] >= FIRTH_HAT32_PIVOT * hdiag[j]);
-            if (fw.s64_list && !well) fw.s64_list[atomicAdd(fw.s64_count, 1)] = s;
-            else step_list[atomicAdd(step_count, 1)] = s;
+            if (fw.s64_list && !well) list_push(true, fw.s64_list, fw.s64_count, s);
+            else list_push(true, step_list, step_count, s);
         }
         return;
     }
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(512) void k_firth_step2(const uint64_t *__restrict_
     }
 #pragma unroll
     for (int a = 0; a < PC; ++a) fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = beta[a] - nU[a];
-    next_eval[atomicAdd(next_eval_count, 1)] = s;
+    list_push(true, next_eval, next_eval_count, s);
 }
 
 

@@ -712,7 +712,7 @@ def test_strong_effects_and_awkward_covariates_sweep(N, q, V, seed):
     close(r["pvalue"][~firth], want["pvalue"][~firth], rtol=1e-6, atol=1e-300, what="pvalue")
 
 
-@pytest.mark.parametrize("N,q,V", [(5000, 10, 4096), (4100, 1, 1024), (4099, 3, 777), (6007, 7, 1500), (4096, 10, 640), (8200, 5, 512)])
+@pytest.mark.parametrize("N,q,V", [(5000, 10, 8192), (4100, 1, 1024), (4099, 3, 777), (6007, 7, 1500), (4096, 10, 640), (8200, 5, 512)])
 def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     """Forced Firth at N >= 4096 (BASELINE config C4's mode): the one-pass iteration (firth_fast.hip: third-moment tensor and information matrix
     on the matrix cores, fits finished in the kernel) against the exact two-pass rounds (SEERHIP_ROUTE firth_fast=0).  Same flags; statistics to
@@ -735,21 +735,35 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
     bits = pack_variants(K)
     out = {}
-    for mode, val in (("two", "0"), ("one", None)):
-        if val is None:
+    # two: the exact rounds;  one: the one-pass kernels, their single-precision first pass at two wavefronts per SIMD (firth_fast_w.hip: 16-row
+    # tiles, 16 variants per wavefront, sums handed to a per-fit kernel);  one_w0: that pass at one wavefront per SIMD (firth_fast.hip, round 4)
+    for mode, route in (("two", "firth_fast=0"), ("one", None), ("one_w0", "firth_w=0")):
+        if route is None:
             monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
         else:
-            monkeypatch.setenv("SEERHIP_ROUTE", "firth_fast=" + val)
+            monkeypatch.setenv("SEERHIP_ROUTE", route)
         e = Engine(N); e.set_af_filter(0.01, 0.99); e.glm_setup(y, W, False, nl, nf, force_firth=True); out[mode] = e.glm_batch(bits); e.close()
-    a, b = out["two"], out["one"]
-    assert np.array_equal(a["flags"], b["flags"]), np.where(a["flags"] != b["flags"])[0][:10]
+    monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
+    a = out["two"]
     ok = np.isfinite(a["kbeta"])
-    assert ok.sum() > V // 2 and np.array_equal(ok, np.isfinite(b["kbeta"]))
-    close(b["pvalue"][ok], a["pvalue"][ok], rtol=1e-6, atol=1e-300, what="pvalue")
-    close(b["bse"][ok], a["bse"][ok], rtol=1e-6, what="bse")
-    close(b["kbeta"][ok], a["kbeta"][ok], rtol=1e-6, atol=2e-8, what="kbeta")
-    close(b["intercept"][ok], a["intercept"][ok], rtol=1e-6, atol=2e-8, what="intercept")
-    close(b["betas"][ok], a["betas"][ok], rtol=1e-6, atol=2e-8, what="betas")
+    assert ok.sum() > V // 2
+    for mode in ("one", "one_w0"):
+        b = out[mode]
+        assert np.array_equal(a["flags"], b["flags"]), (mode, np.where(a["flags"] != b["flags"])[0][:10])
+        assert np.array_equal(ok, np.isfinite(b["kbeta"])), mode
+        dev = {f: float(np.max(np.abs(b[f][ok] - a[f][ok]) / np.maximum(np.abs(a[f][ok]), 1e-300))) for f in ("pvalue", "bse")}
+        # kbeta in units of the test's own tolerance (1e-6 relative or 2e-8 absolute): |d| / (1e-6 |kbeta| + 2e-8)
+        dev["kbeta_tol_units"] = float(np.max(np.abs(b["kbeta"][ok] - a["kbeta"][ok]) / (1e-6 * np.abs(a["kbeta"][ok]) + 2e-8)))
+        print("one-pass Firth (%s) against the exact rounds, N=%d q=%d, %d fits: max rel pvalue %.2e bse %.2e, kbeta %.2f of its tolerance"
+              % (mode, N, q, int(ok.sum()), dev["pvalue"], dev["bse"], dev["kbeta_tol_units"]))
+        close(b["pvalue"][ok], a["pvalue"][ok], rtol=1e-6, atol=1e-300, what="pvalue")
+        close(b["bse"][ok], a["bse"][ok], rtol=1e-6, what="bse")
+        close(b["kbeta"][ok], a["kbeta"][ok], rtol=1e-6, atol=2e-8, what="kbeta")
+        close(b["intercept"][ok], a["intercept"][ok], rtol=1e-6, atol=2e-8, what="intercept")
+        close(b["betas"][ok], a["betas"][ok], rtol=1e-6, atol=2e-8, what="betas")
+        # measured on the C4 workload (profiles/r04/firth_fast_check_q10.json, 259 560 fits): kbeta 4.9e-9 absolute, bse 2.3e-8, p 1.0e-8;
+        # the ceilings here leave a factor ~10 on this test's harsher rows (real effects, rare and majority carriers)
+        assert dev["kbeta_tol_units"] <= 0.25 and dev["bse"] <= 3e-7 and dev["pvalue"] <= 1.5e-7, (mode, dev)
 
 
 def test_contexts_on_one_device_run_concurrently_and_agree_bit_for_bit():
