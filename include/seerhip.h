@@ -19,7 +19,7 @@
  *  - a context is bound to one device and is NOT thread-safe; use one context per device per host thread.
  *  - presence bits: V rows x row_bytes bytes, variant-major; bit (i & 7) of byte (i >> 3) of row v is the
  *    presence of sample i in variant v (LSB first).  Bits at i >= n_samples are ignored.
- *  - flags[v]: bits 0..8 = notes in the order of docs/usage.rst:553-566 (SH_NOTE_*), bit 16 = Seer/LMM.prefilter,
+ *  - flags[v]: bits 0..8 = notes in the order of docs/usage.rst:553-566 (SH_NOTE_*), bit 18 = SH_FLAG_FIRTH_SENSITIVE, bit 16 = Seer/LMM.prefilter,
  *    bit 17 = Seer/LMM.filter.
  */
 #ifndef SEERHIP_H
@@ -52,6 +52,19 @@ extern "C" {
 #define SH_NOTE_LRT_FILTER       (1u << 8)
 #define SH_FLAG_PREFILTER        (1u << 16)
 #define SH_FLAG_FILTER           (1u << 17)
+/* A row fitted by fit_firth (model.py:414-504) on which the REFERENCE's own answer is fragile -- it may depend on the order of the reference's
+ * floating-point sums.  Set when
+ *   (a) the variant all but separates the phenotype: a cell of its 2 x 2 table holds at most one sample.  Every `firth-fail` the reference
+ *       itself was seen to return (tests/golden/glm_exit_firthfail_*.npz: 13 rows, N = 300 ... 5000) is such a row: near its stop
+ *       `firth_likelihood(new) > firth_likelihood(old)` (model.py:467) compares values one ulp apart, for 1000 halvings if the last bits
+ *       fall that way, and the reference fits the same row with the samples in another order.  Nothing order-independent tells those rows
+ *       from their neighbours that the reference fits (profiles/r05/firthfail_trace.txt), so the whole class is marked;
+ *   (b) the iteration took 12 or more accepted steps (linear convergence), or its stop rule (model.py:477-479) was met within 1e-8 of the
+ *       limit: the answer then moves by a whole step (~1e-4) with the last bit of a norm;
+ *   (c) this library itself reports firth-fail (SEERHIP_ROUTE firth_literal / firth_strict).
+ * Informational: set beside the row's statistics, never a reason to filter; < 1e-3 of the rows of a forced-Firth run on random k-mers.
+ * DESIGN.md section 6. */
+#define SH_FLAG_FIRTH_SENSITIVE  (1u << 18)
 
 typedef struct sh_ctx sh_ctx;
 

@@ -12,6 +12,7 @@ NOTE_ORDER = ('af-filter', 'pre-filtering-failed', 'bad-chisq', 'high-bse', 'per
               'matrix-inversion-error', 'firth-fail', 'missing-data-error', 'lrt-filtering-failed')
 FLAG_PREFILTER = 1 << 16
 FLAG_FILTER = 1 << 17
+FLAG_FIRTH_SENSITIVE = 1 << 18          # include/seerhip.h SH_FLAG_FIRTH_SENSITIVE: the reference's own Firth answer on this row depends on the order of its sums
 
 
 def notes_from_flags(flags):

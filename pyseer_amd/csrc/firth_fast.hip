@@ -527,7 +527,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         const double lrstat = -2.0 * (P.null_firth - fitll);
         double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
         const double b1 = cand[1] + d[1];
-        uint32_t fl = flags[v];
+        uint32_t fl = flags[v] | firth_sensitive(iter + 1, sn);
         out[V + v] = pval; out[2 * V + v] = b1; out[3 * V + v] = sqrt(i11); out[4 * V + v] = cand[0] + d[0];   // bse = sqrt(I11), model.py:491
 #pragma unroll
         for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = cand[2 + j] + d[2 + j];

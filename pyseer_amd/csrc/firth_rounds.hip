@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
     const double Fcand = -(ll + 0.5 * log(det));                     // firth_likelihood, model.py:410-411
     int iter = fw.iter[s];
     bool accept = true, failed = false, conv = false;
-    double sn = 0.0;
+    double sn = 0.0, sn_tested = INFINITY;
     if (iter < 0) {                                                  // F(beta_0): nothing to compare with
         iter = 0;
     } else {
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
             sn = sqrt(sn);
             const double snp = fw.st[(int64_t)fw_snp<PC>() * cap + s];
             conv = (iter > 0) && (snp < 1e-4);                       // tests the PREVIOUS step, model.py:477-479
+            sn_tested = snp;
             fw.st[(int64_t)fw_snp<PC>() * cap + s] = sn;
             ++iter;
             if (!conv && iter >= 1000) failed = true;                // step_limit exhausted, model.py:482-484
@@ -302,9 +303,9 @@ __global__ __launch_bounds__(512) void k_firth_eval2(const uint64_t *__restrict_
         return;
     }
     if (!failed && !conv) return;                                    // halved: queued above
-    uint32_t fl = flags[v];
+    uint32_t fl = flags[v] | firth_sensitive(iter, sn_tested);
     if (failed) {
-        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                           // model.py:357-362
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER | SH_FLAG_FIRTH_SENSITIVE;                           // model.py:357-362
         out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
 #pragma unroll
         for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(512) void k_firth_step2(const uint64_t *__restrict_
             const double lrstat = -2.0 * (P.null_firth - fitll);
             double pval = 1.0; if (lrstat > 0.0) pval = sh_chi2_sf1(lrstat);      // model.py:366-369
             const double b1 = beta[1] - nU[1];
-            uint32_t fl = flags[v];
+            uint32_t fl = flags[v] | firth_sensitive(fw.iter[s] + 1, fw.st[(int64_t)fw_snp<PC>() * cap + s]);
             out[V + v] = pval; out[2 * V + v] = b1; out[3 * V + v] = sqrt(i11); out[4 * V + v] = beta[0] - nU[0];   // bse = sqrt(I11), model.py:491
 #pragma unroll
             for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = beta[2 + j] - nU[2 + j];

@@ -19,7 +19,7 @@ __device__ __forceinline__ double ll_y0(double lm, double eta) { return eta < -7
 // ---- a1 prefilter from the packed bits ------------------------------------------------------------------------------
 __device__ __forceinline__ double glm_prefilter(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, int NB64, int N,
                                                 const uint64_t *__restrict__ y1, const uint64_t *__restrict__ y0,
-                                                const double *__restrict__ yc, const GlmParams &P, bool *bad, int *mcount)
+                                                const double *__restrict__ yc, const GlmParams &P, bool *bad, int *mcount, bool *cell1 = nullptr)
 {
     int t11 = 0, t01 = 0, m = 0;
     double s1 = 0, q1 = 0;
@@ -36,7 +36,16 @@ __device__ __forceinline__ double glm_prefilter(const uint64_t *__restrict__ T, 
     }
     *mcount = m;
     *bad = false;
+    // (cell1: a cell of the 2 x 2 table holds at most one sample -- the variant all but separates the phenotype; SH_FLAG_FIRTH_SENSITIVE)
+    if (cell1) *cell1 = !P.continuous && min(min(t11, P.n1 - t11), min(t01, P.n0 - t01)) <= 1;
     if (P.continuous) return sh_prefilter_welch((double)m, s1, q1, (double)(N - m), P.yc_sum - s1, P.yc_sq - q1);
     return sh_prefilter_binary(t11, P.n1 - t11, t01, P.n0 - t01, bad);
+}
+
+// SH_FLAG_FIRTH_SENSITIVE (include/seerhip.h): accepted steps of the fit, and the step norm its stop rule tested (model.py:477-479)
+#define FIRTH_SLOW_ITERS 12
+__device__ __forceinline__ uint32_t firth_sensitive(int accepted_steps, double tested_step_norm)
+{
+    return (accepted_steps >= FIRTH_SLOW_ITERS || fabs(tested_step_norm - 1e-4) <= 1e-8) ? SH_FLAG_FIRTH_SENSITIVE : 0u;
 }
 

@@ -491,9 +491,9 @@ __global__ __launch_bounds__(CHORD ? 256 : 64, CHORD ? 1 : GLM_FAST_WAVES) void 
     const int N = P.N, NB64 = P.NB64;
     const double nobs = (double)N;
     uint32_t fl = 0;
-    bool want_fit = live, to_firth = false, bad = false;
+    bool want_fit = live, to_firth = false, bad = false, cell1 = false;
     int m = 0;
-    double prep = glm_prefilter(T, Vpad, vr, NB64, N, y1, y0, yc, P, &bad, &m);
+    double prep = glm_prefilter(T, Vpad, vr, NB64, N, y1, y0, yc, P, &bad, &m, &cell1);
     if (P.af_on) {
         const double af = (double)m / (double)N;
         if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; want_fit = false; prep = NAN; }
@@ -501,6 +501,7 @@ __global__ __launch_bounds__(CHORD ? 256 : 64, CHORD ? 1 : GLM_FAST_WAVES) void 
     if (want_fit) {
         if (bad) fl |= SH_NOTE_BAD_CHISQ;
         if (prep > P.pret || !isfinite(prep)) { fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER; want_fit = false; }   // model.py:266 (>)
+        else if (cell1) fl |= SH_FLAG_FIRTH_SENSITIVE;               // a (quasi-)separating variant on its way to fit_firth: include/seerhip.h
     }
     if (want_fit && (bad || P.force_firth)) { to_firth = true; want_fit = false; }
 
@@ -2062,7 +2063,7 @@ __global__ __launch_bounds__(LEAN ? FIRTH_EVAL_THREADS : 512) void k_firth_eval(
     const double Fcand = -(ll + 0.5 * log(det));                     // firth_likelihood, model.py:410-411
     int iter = fw.iter[s];
     bool accept = true, failed = false, conv = false;
-    double sn = 0.0;
+    double sn = 0.0, sn_tested = INFINITY;
     if (iter < 0) {                                                  // F(beta_0): nothing to compare with
         iter = 0;
     } else {
@@ -2096,6 +2097,7 @@ __global__ __launch_bounds__(LEAN ? FIRTH_EVAL_THREADS : 512) void k_firth_eval(
             sn = sqrt(sn);
             const double snp = fw.st[(int64_t)fw_snp<PC>() * cap + s];
             conv = (iter > 0) && (snp < 1e-4);                       // tests the PREVIOUS step, model.py:477-479
+            sn_tested = snp;
             fw.st[(int64_t)fw_snp<PC>() * cap + s] = sn;
             ++iter;
             if (!conv && iter >= 1000) failed = true;                // step_limit exhausted, model.py:482-484
@@ -2125,9 +2127,9 @@ __global__ __launch_bounds__(LEAN ? FIRTH_EVAL_THREADS : 512) void k_firth_eval(
         return;
     }
     if (!failed && !conv) return;                                    // halved: queued above
-    uint32_t fl = flags[v];
+    uint32_t fl = flags[v] | firth_sensitive(iter, sn_tested);
     if (failed) {
-        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                           // model.py:357-362
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER | SH_FLAG_FIRTH_SENSITIVE;                           // model.py:357-362
         out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
 #pragma unroll
         for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
@@ -2417,7 +2419,9 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
                         } else {
                             sn = sqrt(sn);
                             conv = (iter > 0) && (snp < 1e-4);                           // the PREVIOUS step, model.py:477-479
+                            const double sn_tested = snp;
                             snp = sn; ++iter;
+                            if (failed || conv || iter >= 1000) flags[v] |= firth_sensitive(iter, sn_tested);
                             if (!conv && iter >= 1000) failed = true;                    // step_limit exhausted, model.py:482-484
                             if (!conv && !failed) {
                                 for (int a = 0; a < PC; ++a) s_beta[a] = s_cand[a];
@@ -2429,7 +2433,7 @@ __global__ __launch_bounds__(256) void k_firth_blk(const uint64_t *__restrict__ 
                         if (failed || conv) {
                             uint32_t fl = flags[v];
                             if (failed) {
-                                fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;               // model.py:357-362
+                                fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER | SH_FLAG_FIRTH_SENSITIVE;               // model.py:357-362
                                 out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
                                 for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
                             } else {
@@ -2654,6 +2658,7 @@ __global__ __launch_bounds__(256) void k_glm_firth_pinv(const uint64_t *__restri
                 for (int a = 0; a < PC; ++a) { const double d = s_cand[a] - s_beta[a]; sn = fma(d, d, sn); s_beta[a] = s_cand[a]; }
                 sn = sqrt(sn); Fcur = Fcand; i11 = I[PC + 1];
                 if (iter > 0 && sn_prev < 1e-4) conv = true;                          // the PREVIOUS step, model.py:477-479
+                if (conv || iter + 1 >= FIRTH_SLOW_ITERS) flags[v] |= firth_sensitive(iter + 1, sn_prev);
                 sn_prev = sn;
                 s_ctl = conv ? 2 : 1;
             }
@@ -2664,7 +2669,7 @@ __global__ __launch_bounds__(256) void k_glm_firth_pinv(const uint64_t *__restri
             if (!conv) failed = true;
             uint32_t fl = flags[v];
             if (failed) {
-                fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;
+                fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER | SH_FLAG_FIRTH_SENSITIVE;
                 out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
                 for (int j = 0; j < Q; ++j) out[(5 + j) * V + v] = NAN;
             } else {

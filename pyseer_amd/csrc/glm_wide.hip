@@ -171,9 +171,9 @@ __global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T,
     const int pc = q + 2, N = P.N, NB64 = P.NB64;
     const double nobs = (double)N;
     uint32_t fl = 0;
-    bool want_fit = true, to_firth = false, bad = false;
+    bool want_fit = true, to_firth = false, bad = false, cell1 = false;
     int m = 0;
-    double prep = glm_prefilter(T, Vpad, v, NB64, N, y1, y0, yc, P, &bad, &m);
+    double prep = glm_prefilter(T, Vpad, v, NB64, N, y1, y0, yc, P, &bad, &m, &cell1);
     if (P.af_on) {
         const double af = (double)m / (double)N;
         if (!(P.min_af <= af && af <= P.max_af)) { fl = SH_NOTE_AF_FILTER | SH_FLAG_PREFILTER; want_fit = false; prep = NAN; }
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64) void k_glm_wide(const uint64_t *__restrict__ T,
     if (want_fit) {
         if (bad) fl |= SH_NOTE_BAD_CHISQ;
         if (prep > P.pret || !isfinite(prep)) { fl |= SH_NOTE_PRE_FILTER | SH_FLAG_PREFILTER; want_fit = false; }   // model.py:266 (>)
+        else if (cell1) fl |= SH_FLAG_FIRTH_SENSITIVE;
     }
     out[v] = prep; out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
 #pragma unroll 1
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_firth_blk(const uint64_t *__re
             __syncthreads();
             sn = sqrt(sn); Fcur = Fcand; i11 = s_H[pc + 1];
             if (iter > 0 && sn_prev < 1e-4) conv = true;                               // the PREVIOUS step, model.py:477-479
+            if (tid == 0 && (conv || iter + 1 >= FIRTH_SLOW_ITERS)) flags[v] |= firth_sensitive(iter + 1, sn_prev);
             sn_prev = sn;
         }
         if (tid == 0) {
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(256) void k_glm_wide_firth_blk(const uint64_t *__re
                 if (!conv) failed = true;
                 uint32_t fl = flags[v];
                 if (failed) {
-                    fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                         // model.py:357-362
+                    fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER | SH_FLAG_FIRTH_SENSITIVE;                         // model.py:357-362
                     out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
                     for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = NAN;
                 } else {
@@ -759,12 +761,13 @@ __global__ __launch_bounds__(64) void k_glm_wide_firth(const uint64_t *__restric
         for (int a = 0; a < pc; ++a) { const double d = cand[a] - beta[a]; sn = fma(d, d, sn); beta[a] = cand[a]; }
         sn = sqrt(sn); Fcur = Fcand; i11 = I[pc + 1];
         if (iter > 0 && sn_prev < 1e-4) conv = true;                                   // tests the PREVIOUS step, model.py:477-479
+        if (conv || iter + 1 >= FIRTH_SLOW_ITERS) flags[v] |= firth_sensitive(iter + 1, sn_prev);
         sn_prev = sn;
     }
     if (!conv) failed = true;
     uint32_t fl = flags[v];
     if (failed) {
-        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER;                                     // model.py:357-362
+        fl |= SH_NOTE_FIRTH_FAIL | SH_FLAG_FILTER | SH_FLAG_FIRTH_SENSITIVE;                                     // model.py:357-362
         out[V + v] = NAN; out[2 * V + v] = NAN; out[3 * V + v] = NAN; out[4 * V + v] = NAN;
 #pragma unroll 1
         for (int j = 0; j < q; ++j) out[(5 + j) * V + v] = NAN;

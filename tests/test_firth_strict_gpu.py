@@ -111,7 +111,7 @@ def test_the_three_firth_modes_differ_only_where_documented(monkeypatch):
         both = (ff[na] == 0) & (ff[nb] == 0)
         for f in ("kbeta", "bse", "intercept"):
             assert _close(a[f][both], b[f][both], rtol=1e-6, atol=3e-7).all(), (na, nb, f)
-        assert ((a["flags"] ^ b["flags"]) & ~np.uint32((1 << 6) | (1 << 8) | (1 << 17)))[...].max() == 0
+        assert ((a["flags"] ^ b["flags"]) & ~np.uint32((1 << 6) | (1 << 8) | (1 << 17) | (1 << 18)))[...].max() == 0   # (bit 18: a firth-fail of this library marks the row order-sensitive)
     print("%d forced-Firth fits (N=%d): firth-fail default %d, literal %d, strict %d; max |dkbeta| literal vs strict %.2e"
           % (V, N, int(ff["default"].sum()), int(ff["literal"].sum()), int(ff["strict"].sum()),
              float(np.nanmax(np.abs(d["kbeta"] - s["kbeta"])[(ff["literal"] == 0) & (ff["strict"] == 0)]))))

@@ -85,6 +85,8 @@ def test_fixed_effects_golden(path):
             good, nt = golden_firth_rows_close(r["betas"][fr, c], d["betas"][fr, c], vc, "b", allr); needed += nt
             assert good.all(), ("betas", c, np.where(fr)[0][~good][:5])
     print("%s: %d Firth-routed rows, %d statistic values needed the tie detector" % (os.path.basename(path), int(fr.sum()), needed))
+    # (measured in round 5: 0 on every fixture but glm_N300_q10_filt (1) and glm_exit_highbse_N100_q1 (2: the row whose stop rule sits at 1.00003e-4))
+    assert needed <= 2, needed
     same = ~alt_row
     for v in np.where(alt_row)[0]:
         alt = [j for j in range(d["perm_notes"].shape[1]) if (fl[v] & 0x1FF) == d["perm_notes"][v, j]]
@@ -123,6 +125,7 @@ def test_forced_firth_golden(path):
         good, nt = golden_firth_rows_close(r["betas"][ok, c], d["firth_betas"][ok, c], vc, "b", allr); needed += nt
         assert good.all(), ("betas", c, np.where(ok)[0][~good][:5])
     print("%s: %d forced-Firth rows, %d statistic values needed the tie detector" % (os.path.basename(path), int(ok.sum()), needed))
+    assert needed <= 2, needed                                         # (measured: 0 everywhere but glm_exit_highbse_N100_q1: 2)
     # p-value from fitll: lrstat = -2 (null_firth - fitll)
     lr = -2 * (float(d["null_firth"]) - fm[ok, 3])
     want_p = np.array([orc.chi2_sf1(x) if x > 0 else 1.0 for x in lr])
@@ -199,6 +202,7 @@ def test_fixed_effects_vs_oracle_random(N, q, V, cont):
         needed += nt
         assert good.all(), (f, np.argwhere(~good)[:4].tolist(), r[f][firth][~good][:4], want[f][firth][~good][:4])
     print("N=%d q=%d: %d Firth-routed rows, %d statistic values needed the tie detector" % (N, q, int(firth.sum()), needed))
+    assert needed <= 1, needed                                         # (measured: 0 in all four configurations)
     close(r["betas"][~firth], want["betas"][~firth], atol=1e-12, what="betas")
     assert ((r["flags"] & 0x1FF) == want["notes"]).all()
 
@@ -875,3 +879,47 @@ def test_the_lanes_of_a_context_return_the_synchronous_rows(monkeypatch):
         e.glm_batch_dev_async(rows[0][:, :40].contiguous(), torch.zeros((8, rows[0].shape[0]), dtype=torch.float64, device="cuda"),
                               torch.zeros((rows[0].shape[0],), dtype=torch.int32, device="cuda"))
     e.close()
+
+
+def test_firth_sensitive_bit_marks_the_reference_firth_fails_and_little_else():
+    """SH_FLAG_FIRTH_SENSITIVE (include/seerhip.h, flags bit 18): set on a Firth-fitted row whose reference answer is fragile -- a variant that
+    all but separates the phenotype (a cell of its 2 x 2 table <= 1), >= 12 accepted steps, a stop rule met within 1e-8 of its limit, or a
+    firth-fail of this library.  Every row on which the reference itself returned `firth-fail` (glm_exit_firthfail_*.npz; it fits each of
+    them with the samples in another order, model.py:465-484) carries it, in the routed run and in the forced-Firth run; so does the row
+    whose stop rule sits at 1.00003e-4 (glm_exit_highbse_N100_q1.npz row 5); on a forced-Firth run over random k-mers fewer than 1e-3 of the
+    rows do, and no row that was not Firth-fitted ever does."""
+    from pyseer_amd.engine import Engine, pack_variants
+    from pyseer_amd.model import fit_null
+    from pyseer_amd.classes import FLAG_FIRTH_SENSITIVE
+    nref = 0
+    for path in sorted(glob.glob(os.path.join(G, "glm_exit_firthfail_*.npz"))):
+        d = np.load(path)
+        ff = (d["notes"] & 0x40) != 0
+        for force in (False, True):
+            fl = _run(d, force_firth=force)["flags"] if force else _run(d)["flags"]
+            sens = (fl & FLAG_FIRTH_SENSITIVE) != 0
+            print("%s force_firth=%d: reference firth-fail rows %d, of them marked %d; controls marked %d of %d"
+                  % (os.path.basename(path), force, int(ff.sum()), int((sens & ff).sum()), int((sens & ~ff).sum()), int((~ff).sum())))
+            assert sens[ff].all(), (path, force, np.where(ff & ~sens)[0])
+        nref += int(ff.sum())
+    assert nref == 13                                           # 9 rows at N <= 1000 and 4 at N = 5000
+    d = np.load(os.path.join(G, "glm_exit_highbse_N100_q1.npz"))
+    assert _run(d)["flags"][5] & FLAG_FIRTH_SENSITIVE          # 52 steps, the 52nd of norm 1.00003e-4 (DESIGN.md section 6, exception 2)
+    for path in sorted(glob.glob(os.path.join(G, "glm_N*.npz"))):   # ordinary runs: only rows the reference sent through fit_firth carry the bit
+        d = np.load(path); fl = _run(d)["flags"]
+        assert not ((fl & FLAG_FIRTH_SENSITIVE) != 0)[(d["notes"] & 0x7C) == 0].any(), path
+    # random k-mers, every variant through Firth (BASELINE config C4's kind of row)
+    N, q, V = 5000, 10, 32768
+    rng = np.random.default_rng(515)
+    W = rng.standard_normal((N, q)); W /= np.abs(W).max(axis=0)
+    y = (rng.random(N) < 1 / (1 + np.exp(-(-0.2 + 0.8 * W[:, 0])))).astype(float)
+    af = rng.uniform(0.01, 0.99, V)
+    bits = pack_variants((rng.random((V, N)) < af[:, None]).astype(np.uint8))
+    e0 = np.zeros((0, 0))
+    nl = fit_null(y, W, e0, False).llf; nf = fit_null(y, W, e0, False, firth=True)
+    e = Engine(N); e.set_af_filter(0.01, 0.99); e.glm_setup(y, W, False, nl, nf, force_firth=True)
+    fl = e.glm_batch(bits)["flags"]; e.close()
+    tested = (fl & 1) == 0
+    frac = float(((fl & FLAG_FIRTH_SENSITIVE) != 0)[tested].mean())
+    print("forced Firth on %d random k-mers: %.2e of the rows marked order-sensitive" % (int(tested.sum()), frac))
+    assert frac < 1e-3
