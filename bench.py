@@ -33,11 +33,12 @@ GLM_KERNELS = {False: "k_glm_fast<Q,true> (prefilter, routing) + k_glm_bitdot + 
                       "k_glm_dpass_pk + k_glm_finish (+ k_glm_slow_blk and the Firth kernels for routed rows)",
                True: "k_glm_fast<Q,true> + k_glm_bitdot + k_firth_init2 + passes of k_firth_fast (one sample pass per Firth iteration: eta / exp / log-likelihood / "
                      "exact score in fp64 on the vector ALU, the information matrix and the penalty's third-moment tensor as f16 hi/lo MFMAs with fp32 accumulation; "
-                     "the first pass, at the start vector, in single precision with one f16 product per tile; fits finished in the kernel) + k_firth_eval2 / "
+                     "the first pass, at the start vector, in single precision with one f16 product per tile at two wavefronts per SIMD: k_firth_fast32w + "
+                     "k_firth_fastw_fin; fits finished in the kernel) + k_firth_eval2 / "
                      "k_firth_step2 (exact two-pass rounds) for the fits that leave the fast passes"}
 FP64_FLOP_PER_TEST = 5.0e7         # 2*k*N + 6k fp64 flop of the reference formulation, k=4999
 ALGO_BYTES_PER_TEST = 673          # ceil(N/8) in + 48 out
-PROFILE_DIRS = ("r04", "r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
+PROFILE_DIRS = ("r05", "r04", "r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
 
 
 # ---------------------------------------------------------------------------------------------------------------

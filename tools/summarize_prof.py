@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Collapse the rocprofv3 outputs of tools/profile_r04.sh (gpurun_out/prof_r04/) into the small files kept under profiles/r04/:
+"""Collapse the rocprofv3 outputs of tools/profile_r05.sh (gpurun_out/prof_r05/; round 4: profile_r04.sh) into the small files kept under profiles/rNN/:
   bench_<cfg>.json                         the bench lines
   rocprofv3_kernel_stats_<cfg>.csv         --kernel-trace --stats of the same command
   rocprofv3_pmc_summary_<cfg>.csv          per pass / kernel / counter: dispatches, sum, mean per dispatch
@@ -51,14 +51,24 @@ def main(src, dst):
         if rows:                                              # a run with PMC=0 has no counter passes: bench line and kernel stats only
             with open(os.path.join(dst, "rocprofv3_pmc_summary_%s.csv" % cfg), "w") as f:
                 f.write("pass,kernel,counter,dispatches,sum,mean_per_dispatch\n")
-                for r in rows:
-                    f.write("%s,%s,%s,%d,%.6g,%.6g\n" % r)
+                for r in rows:                                # (kernel names hold commas: quoted since round 5)
+                    f.write('%s,"%s",%s,%d,%.6g,%.6g\n' % r)
+            # where the bytes go, per kernel (round-4 review item 6): FETCH_SIZE x 2 (gfx950) and WRITE_SIZE of one step
+            per = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for _, k, c, n, s_, _m in rows:
+                if c == "FETCH_SIZE": per[k][0] = n; per[k][1] = s_ * 2.0 * 1024.0
+                if c == "WRITE_SIZE": per[k][0] = n; per[k][2] = s_ * 1024.0
+            if per:
+                with open(os.path.join(dst, "traffic_per_kernel_%s.csv" % cfg), "w") as f:
+                    f.write("kernel,dispatches,fetch_bytes,write_bytes,bytes_per_variant\n")
+                    for k, (n, fb, wb) in sorted(per.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+                        f.write('"%s",%d,%.0f,%.0f,%.1f\n' % (k, n, fb, wb, (fb + wb) / V))
         tag = "lmm" if cfg == "C3" else cfg.lower()
         if "FETCH_SIZE" in tot:
             json.dump({"kernels": "k_lmm_quadform_i8w" if cfg == "C3" else "all k_glm_* / k_firth_* kernels of one step",
                        "variants_per_dispatch": V, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot.get("WRITE_SIZE"),
                        "fetch_correction": 2.0,
-                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r04.sh) on %s; gfx950: FETCH_SIZE "
+                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r05.sh) on %s; gfx950: FETCH_SIZE "
                                  "counts 64 B per 128-B request, hence x2 (MI355X_MICROARCH.md HBM section)"
                                  % ("bench.py --config %s --steps 1 --warmup 0 (the bench's own rows)" % cfg)},
                       open(os.path.join(dst, "traffic_%s.json" % tag), "w"), indent=1)
