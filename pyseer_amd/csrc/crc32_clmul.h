@@ -4,7 +4,10 @@
 // much host time as inflating it (the GPU boxes grant 16 CPUs: DESIGN.md section 5.5).  This is the folding scheme of Gopal et al., "Fast CRC
 // Computation for Generic Polynomials Using PCLMULQDQ Instruction" (Intel, 2009) for the reflected polynomial: four 128-bit lanes folded
 // across 64-byte blocks with x^(4*128 +- 32) mod P, folded together with x^(128 +- 32) mod P, reduced 128 -> 64 -> 32 bits with x^64 mod P
-// and a Barrett step.  Constants are the paper's for this polynomial.  Same value as zlib's crc32 for every input
+// and a Barrett step.  Constants are the paper's for this polynomial.  The fold body follows the widely published PCLMULQDQ routine for this
+// polynomial as it appears in Chromium's zlib (third_party/zlib/crc32_simd.c, crc32_sse42_simd_: the same x0..x8 / y5..y8 register
+// schedule and the same k1k2 / k3k4 / k5k0 / poly constants) -- third-party code this header is modelled on, not part of the reference
+// (pyseer reads gzip through Python's gzip module, input.py:271-276).  Same value as zlib's crc32 for every input
 // (tests/test_reader_cpu.py::test_clmul_crc32_equals_zlib); zlib's own routine where the CPU lacks PCLMULQDQ and for the last < 16 bytes.
 #pragma once
 #include <stdint.h>
