@@ -13,6 +13,8 @@ for c in $CFGS; do
   if [ "$c" = "C3" ]; then python $R/bench.py --steps 10 --warmup 2 > $O/bench_$c.json 2> $O/bench_$c.err
   else python $R/bench.py --config $c --steps 12 --warmup 6 > $O/bench_$c.json 2> $O/bench_$c.err; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$c -- python $R/bench.py --config $c --steps 6 --warmup 3 --no-cpu-baseline --no-extra --no-parity > $O/stats_$c.json 2> $O/stats_$c.err
+  # fixed effects: the same steps on ONE lane (no two batches on the device at once): per-kernel durations that are the kernels' own
+  [ "$c" != "C3" ] && SEERHIP_ROUTE=lanes=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1_$c -- python $R/bench.py --config $c --steps 6 --warmup 3 --no-cpu-baseline --no-extra --no-parity > $O/stats1_$c.json 2> $O/stats1_$c.err
 done
 pmc() {  # cfg group counters...
   local c=$1 g=$2; shift 2

@@ -6,7 +6,7 @@ set -e
 R="$(cd "$(dirname "$0")/.." && pwd)"
 C="$R/pyseer_amd/csrc"; AB="$R/pyseer_amd/ab"; mkdir -p "$AB"
 objs=""
-for o in api.o lmm_kernels.o glm_kernels.o firth_rounds.o firth_fast.o firth_fast32.o glm_wide.o bitdot_i8.o dedup_kernels.o sim_kernels.o; do objs="$objs $C/$o"; done
+for o in api.o lmm_kernels.o glm_kernels.o glm_firth_v1.o glm_ols.o glm_lineage.o firth_rounds.o firth_fast.o firth_fast32.o firth_fast_w.o glm_wide.o bitdot_i8.o job_kernels.o dedup_kernels.o sim_kernels.o; do objs="$objs $C/$o"; done
 gccdir=$(dirname "$(gcc -print-file-name=libasan.so)")
 run() {  # kind flags preload tests...
   local kind=$1 flags=$2 pre=$3; shift 3

@@ -83,19 +83,20 @@ def main(src, dst):
                                  "FMA = 2 flop; MFMA_MOPS_F32 in units of 512 flop) summed over every k_glm_* / k_firth_* dispatch of "
                                  "`bench.py --config %s --steps 1 --warmup 0`" % cfg},
                       open(os.path.join(dst, "flops_%s.json" % tag), "w"), indent=1)
-        st = glob.glob(os.path.join(src, "stats_%s" % cfg, "**", "*kernel_stats.csv"), recursive=True)
-        if st:                                                # this library's kernels in full; torch's (data generation, eigh) as one line
-            rows_in = list(csv.DictReader(open(st[0])))
-            with open(os.path.join(dst, "rocprofv3_kernel_stats_%s.csv" % cfg), "w") as f:
-                f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
-                oc, ot = 0, 0.0
-                for r in rows_in:
-                    nm = short(r["Name"])
-                    if nm.startswith("k_") or nm.startswith("__amd_rocclr"):
-                        f.write('"%s",%s,%s,%s,%s,%s,%s,%s\n' % (nm, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]))
-                    else:
-                        oc += int(r["Calls"]); ot += float(r["TotalDurationNs"])
-                f.write('"(torch / rocSOLVER kernels: synthetic data generation, eigendecomposition)",%d,%.0f,,,,,\n' % (oc, ot))
+        for sdir, suffix in (("stats_%s" % cfg, ""), ("stats1_%s" % cfg, "_one_lane")):
+            st = glob.glob(os.path.join(src, sdir, "**", "*kernel_stats.csv"), recursive=True)
+            if st:                                                # this library's kernels in full; torch's (data generation, eigh) as one line
+                rows_in = list(csv.DictReader(open(st[0])))
+                with open(os.path.join(dst, "rocprofv3_kernel_stats_%s%s.csv" % (cfg, suffix)), "w") as f:
+                    f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+                    oc, ot = 0, 0.0
+                    for r in rows_in:
+                        nm = short(r["Name"])
+                        if nm.startswith("k_") or nm.startswith("__amd_rocclr"):
+                            f.write('"%s",%s,%s,%s,%s,%s,%s,%s\n' % (nm, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]))
+                        else:
+                            oc += int(r["Calls"]); ot += float(r["TotalDurationNs"])
+                    f.write('"(torch / rocSOLVER kernels: synthetic data generation, eigendecomposition)",%d,%.0f,,,,,\n' % (oc, ot))
         b = os.path.join(src, "bench_%s.json" % cfg)
         if os.path.exists(b) and os.path.getsize(b):
             open(os.path.join(dst, "bench_%s.json" % cfg), "w").write(open(b).read())
