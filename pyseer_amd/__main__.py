@@ -424,10 +424,12 @@ def main(argv=None):
     job_path = ((native or bool(options.load_packed)) and not options.lineage and not options.print_samples and not options.output_patterns
                 and not options.python_sink and not options.serial_sink and _route.route("job", "1") != "0")
     job_block = options.block_size if (options.print_filtered or not job_path) else max(options.block_size, 1 << 16)
+    # the reader runs as far ahead as the job stream holds blocks in flight (fixed effects: 2 + lanes, include/seerhip.h sh_job_depth)
+    job_ahead = (2 + engs[0].get_lanes()) if (job_path and not options.lmm) else 2
     if options.load_packed:
         blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples,
-                                           raw=job_path, device=(engs[0].device if job_path else None))
+                                           raw=job_path, device=(engs[0].device if job_path else None), ahead=job_ahead)
     elif native and len(kmer_files) > 1:
         blocks = iter_packed_blocks_native_multi(p, kmer_files, options.min_af, options.max_af, job_block,
                                                  want_patterns=bool(options.output_patterns), want_samples=options.print_samples, raw=job_path)
@@ -825,7 +827,7 @@ def main(argv=None):
                 t_th = _time.thread_time()
                 blocks_i = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
                                                      want_patterns=bool(options.output_patterns), want_samples=options.print_samples, part=(i, G),
-                                                     raw=job_path, device=(engs[i].device if job_path else None))
+                                                     raw=job_path, device=(engs[i].device if job_path else None), ahead=job_ahead)
                 if job_path:
                     counts[i] = run_stream_job([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, tms[i], stop)
                 else:

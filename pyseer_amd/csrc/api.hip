@@ -64,6 +64,7 @@ struct GlmSetupArgs { std::vector<double> y, W; int q = 0, continuous = 0, force
 struct sh_ctx {
     int device = 0, N = 0;
     hipStream_t stream = nullptr;
+    int *h_rb = nullptr;                 // host-mapped pinned ints for readback_sync
     // ---- lanes (sh_glm_batch_dev_async, the job stream): worker threads with their own sub-context and stream, lanes_api.inc
     sh_lanes *lanes = nullptr; int n_lanes = 3; bool is_lane = false; GlmSetupArgs glm_args;
     double min_af = 0.0, max_af = 1.0; int af_on = 0;
@@ -131,6 +132,24 @@ struct sh_ctx {
     uint8_t *d_bits = nullptr; double *d_out = nullptr; uint32_t *d_flags = nullptr;
 };
 
+// ---- small device -> host read-backs (list lengths, counts) WITHOUT the copy engine ------------------------------------------------------------
+// hipMemcpyAsync(device -> host) of four bytes goes through the same SDMA queue as the job stream's uploads: behind a burst of four 166 MB
+// block copies (2.9 ms each) a lane's list-length read-back waited 11 ms (tools/gpu_e2e_job_copytrace.sh: the gaps inside a batch), and the
+// fixed-effects job ran at 26 M rows/s with the device idle a quarter of the time.  A one-thread kernel on the batch's own stream writes the
+// values into host-mapped pinned memory instead; the host reads them after the stream's (or an event's) wait.
+__global__ void k_readback4(const int *__restrict__ a, const int *__restrict__ b, const int *__restrict__ c2, const int *__restrict__ d, int *__restrict__ out)
+{
+    if (threadIdx.x == 0) { out[0] = *a; if (b) out[1] = *b; if (c2) out[2] = *c2; if (d) out[3] = *d; __threadfence_system(); }
+}
+static hipError_t readback_launch(hipStream_t st, const int *a, const int *b, const int *c2, const int *d, int *host_mapped)
+{
+    hipLaunchKernelGGL(k_readback4, dim3(1), dim3(64), 0, st, a, b, c2, d, host_mapped);
+    return hipGetLastError();
+}
+static int ensure_rb(sh_ctx *c);
+// values of up to four device ints, after everything queued on st: launches the kernel, waits for the stream
+static int readback_sync(sh_ctx *c, hipStream_t st, const int *a, const int *b, const int *c2, const int *d, int *dst);
+
 static void lanes_destroy(sh_ctx *c);
 static int lanes_wait(sh_ctx *c);
 static void lanes_set_timing(sh_ctx *c, int on);
@@ -145,6 +164,20 @@ static void free_ws(sh_ctx *c)
     c->d_T2 = nullptr; c->d_q2 = nullptr; c->d_keep = c->d_nkeep = nullptr; c->cap_keep = 0;
     hipFree(c->d_flip); hipFree(c->d_T3); hipFree(c->d_q3); hipFree(c->d_rlist);
     c->d_flip = nullptr; c->d_T3 = nullptr; c->d_q3 = nullptr; c->d_rlist = nullptr; c->cap_ref = 0;
+}
+
+static int ensure_rb(sh_ctx *c)
+{
+    if (!c->h_rb) HIPCHK(hipHostMalloc((void **)&c->h_rb, 16 * sizeof(int), hipHostMallocMapped));
+    return SH_OK;
+}
+static int readback_sync(sh_ctx *c, hipStream_t st, const int *a, const int *b, const int *c2, const int *d, int *dst)
+{
+    int rc = ensure_rb(c); if (rc) return rc;
+    HIPCHK(readback_launch(st, a, b, c2, d, c->h_rb));
+    HIPCHK(hipStreamSynchronize(st));
+    dst[0] = c->h_rb[0]; if (b) dst[1] = c->h_rb[1]; if (c2) dst[2] = c->h_rb[2]; if (d) dst[3] = c->h_rb[3];
+    return SH_OK;
 }
 
 static int ensure_ws(sh_ctx *c, int64_t Vpad)
@@ -344,8 +377,7 @@ static int dedup_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t 
     HIPCHK(shk_repack_bits(st, (const uint8_t *)d_bits, row_bytes, V, Vpad, c->N, c->NB64p, c->d_T, nullptr));
     HIPCHK(shk_dd_find(st, c->d_T, Vpad, V, c->NB64, c->dd_h, (uint64_t)c->dd_cap, c->dd_keys, c->dd_idx, c->dd_rep, c->dd_slot, c->dd_n));
     int nu = 0;
-    HIPCHK(hipMemcpyAsync(&nu, c->dd_n, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));                     // the number of distinct patterns sizes the launches below
+    { const int rcb = readback_sync(c, st, c->dd_n, nullptr, nullptr, nullptr, &nu); if (rcb) return rcb; }   // the number of distinct patterns sizes the launches below
     c->dd_last_unique = nu;
     HIPCHK(shk_dd_gather(st, (const uint8_t *)d_bits, row_bytes, V, c->dd_rep, c->dd_slot, c->dd_bits));
     rc = inner(c->dd_bits, (int64_t)nu, c->dd_out, c->dd_flags); if (rc) return rc;
@@ -388,7 +420,7 @@ static int af_wrap(sh_ctx *c, const void *d_bits, int64_t row_bytes, int64_t V, 
                                (uint32_t *)d_flags));
         else
             HIPCHK(shk_af_rows(st, 0, (const uint8_t *)d_bits, row_bytes, V, c->N, c->min_af, c->max_af, c->af_rep, c->af_slot, c->af_cnt));
-        HIPCHK(hipMemcpyAsync(c->h_af_cnt, c->af_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(readback_launch(st, c->af_cnt, c->af_cnt + 1, nullptr, nullptr, c->h_af_cnt));      // (h_af_cnt is pinned: written by the kernel, no copy engine)
         if (c->af_hint >= 0.10 || c->af_compact == 2) {
             HIPCHK(hipStreamSynchronize(st));
             nk = c->h_af_cnt[0]; R = c->h_af_cnt[1];
@@ -485,6 +517,7 @@ void sh_destroy(sh_ctx *c)
     lanes_destroy(c);
     free_ws(c);
     if (c->h_nkeep) hipHostFree(c->h_nkeep);
+    if (c->h_rb) hipHostFree(c->h_rb);
     if (c->h_af_cnt) hipHostFree(c->h_af_cnt);
     if (c->af_ev) hipEventDestroy(c->af_ev);
     hipFree(c->af_rep); hipFree(c->af_slot); hipFree(c->af_m); hipFree(c->af_cnt); hipFree(c->af_bits); hipFree(c->af_out); hipFree(c->af_flags);
@@ -917,7 +950,7 @@ static int lmm_batch_dev_inner(sh_ctx *c, const void *d_bits, int64_t row_bytes,
         if (!c->keep_pending) {
             HIPCHK(hipMemsetAsync(c->d_nkeep, 0, sizeof(int), st));
             HIPCHK(shk_af_compact(st, 0, V, lo, KP, c->d_keep, c->d_nkeep, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr));
-            HIPCHK(hipMemcpyAsync(c->h_nkeep, c->d_nkeep, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(readback_launch(st, c->d_nkeep, nullptr, nullptr, nullptr, c->h_nkeep));
             if (c->filtered_hint >= 0.03 || c->af_compact == 2) {                 // SEERHIP_ROUTE afcompact=2: always count (tests)
                 HIPCHK(hipStreamSynchronize(st));
                 nk = *c->h_nkeep; c->filtered_hint = 1.0 - (double)nk / (double)V;

@@ -659,9 +659,17 @@ class _DmaWindows(object):
     to the device by DMA, with no CPU copy (4 ns of CPU per 632-byte row against 21 for the copy into pinned staging:
     profiles/r05/host_feed_probe.txt).  Registering is cheap (1.2 ms per 160 MB, also with the device busy) but UNREGISTERING waits for the
     device to drain (28 ms per call under load, tools/gpu_probe_register.py): so a window spans several stored blocks (up to WINDOW bytes,
-    cut at block boundaries: windows never share a page), is unregistered once all its blocks have been collected, and by the READER thread
-    (which runs two blocks ahead of the device and can afford the wait) when it next registers -- never by the thread that feeds the device."""
+    cut at block boundaries: windows never share a page), is unregistered once all its blocks have been collected, and by a JANITOR thread of
+    its own -- never by the thread that feeds the device, and since the lanes (a fixed-effects device is never idle between blocks: the
+    reader thread, which did it until then, stood 0.33 of 1.2 s in hipHostUnregister) not by the reader either."""
     WINDOW = 1 << 30
+    # hipHostUnregister waits for the device to drain AND holds new work back while it does: every call is a hole in the device's timeline
+    # (16 windows of a 24 M-row fixed-effects job: 155 of 820 ms idle).  So finished windows stay registered (their pages pinned) until the
+    # stream ends, or until more than KEEP bytes of them have piled up -- a quarter of the machine's memory, at most 64 GB per stream.
+    try:
+        KEEP = min(64 << 30, os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") // 4)
+    except (ValueError, OSError, AttributeError):
+        KEEP = 8 << 30
 
     def __init__(self, device):
         import threading
@@ -673,6 +681,9 @@ class _DmaWindows(object):
         self._done = []                # windows whose blocks have all been collected, to unregister
         self._reader_done = False
         self.ok = True
+        self._wake = threading.Condition(self._lock)
+        self._janitor = None
+        self._stop = False
 
     def plan(self, base_addr, extents, lo_blk, hi_blk):
         j = lo_blk
@@ -693,13 +704,40 @@ class _DmaWindows(object):
         for w in todo:
             self._lib.sh_host_unregister(w["lo"])
 
+    def _janitor_loop(self):
+        while True:
+            with self._wake:
+                while not self._due() and not self._stop:
+                    self._wake.wait()
+                if not self._done and self._stop:
+                    return
+                todo = []
+                if self._reader_done or self._stop:
+                    todo, self._done = self._done, []
+                else:
+                    while self._done and sum(w["n"] for w in self._done) > self.KEEP:
+                        todo.append(self._done.pop(0))
+            for w in todo:
+                self._lib.sh_host_unregister(w["lo"])
+
+    def _due(self):
+        """(lock held) is there a window to unregister NOW: the stream has ended, or too many finished windows are still pinned"""
+        return bool(self._done) and (self._reader_done or sum(w["n"] for w in self._done) > self.KEEP)
+
+    def _kick(self):
+        """(lock held) a window is ready to be unregistered: wake the janitor, starting it at the first need"""
+        if self._janitor is None:
+            import threading
+            self._janitor = threading.Thread(target=self._janitor_loop, daemon=True)
+            self._janitor.start()
+        self._wake.notify()
+
     def take(self, j):
         """(dma, release) for stored block j, called on the reader thread just before the block is handed on."""
         w = self._win_of.get(j)
         if w is None or not self.ok:
             return False, None
         if w["state"] == 0:
-            self._unregister_done()
             if self._lib.sh_host_register(w["lo"], w["n"], self._device) != 0:
                 w["state"] = -1
                 self.ok = False        # (a file system whose pages cannot be pinned: the rows are staged through pinned memory from here on)
@@ -718,9 +756,7 @@ class _DmaWindows(object):
                 last = w["released"] == w["blocks"] or (self._reader_done and w["released"] == w["taken"])
                 if last:
                     self._done.append(w)
-                finish_here = last and self._reader_done
-            if finish_here:
-                self._unregister_done()    # (the reader has gone: the stream is draining, the device about to be idle)
+                    self._kick()
         return True, release
 
     def reader_done(self):
@@ -729,17 +765,19 @@ class _DmaWindows(object):
             for w in {id(x): x for x in self._win_of.values()}.values():
                 if w["state"] == 1 and w["released"] == w["taken"] and w not in self._done and w["released"] < w["blocks"]:
                     self._done.append(w)
-        self._unregister_done()
+            if self._done:
+                self._kick()
 
 
-def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, part=None, raw=False, device=None):
+def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, part=None, raw=False, device=None, ahead=2):
     """PackedBlock stream from a packed cache written by --save-packed; the samples (and their order) must be the run's own.
     Stored blocks are re-cut to about `block_size` variants (stored blocks are never split, only merged).
     part = (i, n): only range i of n contiguous ranges of the cache's rows (the multi-GPU job: one range per device,
     pyseer_amd/__main__.py).  Ranges are made of whole blocks of the single stream, so the n parts yield exactly its blocks; they are
     as equal as block_size allows (a cache of B blocks over n devices: ceil(B/n) against floor(B/n) blocks).
     raw: RawBlock objects for the job stream; with `device` given, a block that is one stored block (no merge) is handed on as a window of the
-    mapping registered for DMA (sh_host_register: the rows go from the page cache to the device with no CPU copy)."""
+    mapping registered for DMA (sh_host_register: the rows go from the page cache to the device with no CPU copy).
+    ahead: blocks the reader thread runs ahead of the consumer (the job stream of a fixed-effects model holds 2 + lanes blocks in flight)."""
     samples = [str(x) for x in p.index]
     order = sorted(range(len(samples)), key=lambda i: samples[i])
     n = len(samples)
@@ -868,5 +906,5 @@ def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns
             if windows is not None:
                 windows.reader_done()
 
-    for blk in prefetched(finished()):
+    for blk in prefetched(finished(), depth=max(2, int(ahead))):
         yield blk

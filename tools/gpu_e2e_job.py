@@ -14,6 +14,7 @@ from pyseer_amd.input import PackedCacheWriter
 from pyseer_amd.packing import row_bytes_for
 
 N = 5000; V = int(os.environ.get("V", 10_000_000)); BLK = int(os.environ.get("BLOCK", 262144))
+FIXED = os.environ.get("E2E_MODEL", "lmm") == "fixed"        # the fixed-effects job (logistic, 10 covariates: bench.py's C2N5000 workload) instead of --lmm
 d = os.environ.get("E2E_DIR", "/tmp/e2e_job"); os.makedirs(d, exist_ok=True)
 GPUS8 = os.environ.get("E2E_GPUS", "0,0,0,0,0,0,0,0")
 dev = torch.device("cuda", 0)
@@ -21,6 +22,12 @@ names = ["sample_%05d" % i for i in range(N)]
 t0 = time.time()
 U, S, h2, C, y, lin = bench.synth_lmm_inputs(N, 1003, dev)
 np.savez(d + "/lmm.npz", U, S, np.array([h2]))                 # pyseer --save-lmm layout (pyseer/lmm.py:66-70, 116-118)
+if FIXED:
+    y, Wc, _, _ = bench.synth_glm_inputs(N, 10)
+    with open(d + "/cov.tsv", "w") as f:
+        f.write("samples\t" + "\t".join("c%d" % j for j in range(10)) + "\n")
+        for i in range(N):
+            f.write(names[i] + "\t" + "\t".join(repr(float(x)) for x in Wc[i]) + "\n")
 with open(d + "/pheno.tsv", "w") as f:
     f.write("samples\tbinary\n")
     for i in range(N):
@@ -62,8 +69,9 @@ def run(name, extra, env_more):
     out = d + "/out_%s.tsv" % name
     env = dict(env0); env.update(env_more)
     t0 = time.time(); ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
-    r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv", "--lmm",
-                        "--load-lmm", d + "/lmm.npz", "--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + extra,
+    model = (["--no-distances", "--covariates", d + "/cov.tsv", "--use-covariates"] + ["%dq" % j for j in range(2, 12)]) if FIXED else ["--lmm", "--load-lmm", d + "/lmm.npz"]
+    r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv"] + model +
+                       ["--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + extra,
                        env=env, stdout=open(out, "w"), stderr=subprocess.PIPE)
     dt = time.time() - t0; ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     err = r.stderr.decode()
@@ -106,6 +114,8 @@ for lrt, tag in [x.split(":") for x in os.environ.get("E2E_LRT", "1e-3:lrt1e-3,1
             rt.append("wait=spin")
         if w_.endswith("_staged"):
             rt.append("dma=0")
+        if "_lanes1" in w_:
+            rt.append("lanes=1")
         env_more = {"SEERHIP_ROUTE": ",".join(rt)} if rt else {}
         md5.add(run(w_ + "_" + tag, extra, env_more)["md5"])
     res["identical_" + tag] = len(md5) == 1

@@ -155,12 +155,12 @@ int main()
     double *o; float *of; hipMalloc(&o, 8 << 20); hipMalloc(&of, 4 << 20);
     for (int w = 1; w <= 2; ++w) { runm<4, 0>(w, o); runm<0, 32>(w, o); runm<4, 32>(w, o); runm<4, 16>(w, o); runm<4, 64>(w, o); runm<1, 32>(w, o); runm<2, 32>(w, o); }
     if (getenv("UB_MFMA_ONLY")) return 0;
-    for (int w = 1; w <= 2; ++w) {
+    for (int w = 1; w <= 8; w *= 2) {
         run<0>("v_fma_f64", w, o, of, 2.4); run<6>("v_fma_f64 (SGPR operand)", w, o, of, 2.4); run<4>("v_mul_f64 / v_add_f64", w, o, of, 2.4);
         run<1>("v_fma_f32", w, o, of, 2.4); run<2>("v_pk_fma_f32", w, o, of, 2.4); run<3>("v_pk_fma_f32 op_sel_hi (broadcast)", w, o, of, 2.4);
         run<5>("v_rcp_f64", w, o, of, 2.4); run<7>("v_ldexp_f64 / v_rndne_f64", w, o, of, 2.4);
     }
-    for (int w = 1; w <= 2; ++w) { runc<1, 0>(w, o, 2.4); runc<2, 0>(w, o, 2.4); runc<4, 0>(w, o, 2.4); runc<8, 0>(w, o, 2.4); runc<1, 1>(w, o, 2.4); runc<2, 1>(w, o, 2.4); runc<4, 1>(w, o, 2.4); }
+    for (int w = 1; w <= 8; w *= 2) { runc<1, 0>(w, o, 2.4); runc<2, 0>(w, o, 2.4); runc<4, 0>(w, o, 2.4); runc<8, 0>(w, o, 2.4); runc<1, 1>(w, o, 2.4); runc<2, 1>(w, o, 2.4); runc<4, 1>(w, o, 2.4); }
     for (int w = 1; w <= 2; ++w) { runv<0>("v_cvt_f64_u32", w, o); runv<1>("v_cvt_f32_f64", w, o); runv<2>("v_cvt_f64_f32", w, o); runv<3>("v_cvt_i32_f64", w, o);
         runv<4>("v_bfe_u32", w, o); runv<5>("v_cndmask_b32", w, o); runv<6>("v_lshrrev_b64", w, o); runv<7>("v_cvt_f32_u32", w, o); runv<8>("v_max_f64", w, o); runv<9>("v_cmp_eq_u64", w, o); }
     return 0;
