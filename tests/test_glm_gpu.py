@@ -741,7 +741,8 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     out = {}
     # two: the exact rounds;  one: the one-pass kernels, their single-precision first pass at two wavefronts per SIMD (firth_fast_w.hip: 16-row
     # tiles, 16 variants per wavefront, sums handed to a per-fit kernel);  one_w0: that pass at one wavefront per SIMD (firth_fast.hip, round 4)
-    for mode, route in (("two", "firth_fast=0"), ("one", None), ("one_w0", "firth_w=0")):
+    # one_f64: every pass of the one-pass kernel in fp64, the first included (route key firth_first32)
+    for mode, route in (("two", "firth_fast=0"), ("one", None), ("one_w0", "firth_w=0"), ("one_f64", "firth_first32=0")):
         if route is None:
             monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
         else:
@@ -751,7 +752,7 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     a = out["two"]
     ok = np.isfinite(a["kbeta"])
     assert ok.sum() > V // 2
-    for mode in ("one", "one_w0"):
+    for mode in ("one", "one_w0", "one_f64"):
         b = out[mode]
         assert np.array_equal(a["flags"], b["flags"]), (mode, np.where(a["flags"] != b["flags"])[0][:10])
         assert np.array_equal(ok, np.isfinite(b["kbeta"])), mode

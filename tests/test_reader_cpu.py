@@ -279,6 +279,12 @@ def test_one_gzip_member_on_several_threads(tmp_path, monkeypatch):
                 assert got[3] > 0 or chunk == 8192, (name, chunk, threads)      # (a chunk smaller than a block may hold no block head)
                 seen_small = seen_small or (chunk == 8192 and got[3] > 0)
     assert seen_small
+    # the decoder's sizing keys (csrc/route.h): few decoding threads, one translating helper, a look-ahead of two slabs, regions sized for
+    # 200 KB of text -- other schedules of the same work, the same rows
+    path = str(tmp_path / "l6.gz")
+    want = read(path, "reader_slab=300000", "serial")
+    got = read(path, "reader_slab=300000,reader_chunk=40000,reader_workers=2,reader_helpers=1,reader_depth=2,reader_target=200000", None, "6")
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and got[3] > 0
     # corruption: a flipped bit early, in the middle, near the end, in the CRC; truncation
     good = files["l6.gz"]
     bad = [good[:k] + bytes([good[k] ^ 0x10]) + good[k + 1:] for k in (len(good) // 7, len(good) // 2, len(good) - 3000, len(good) - 6)]
