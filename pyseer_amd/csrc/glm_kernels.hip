@@ -359,6 +359,10 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
 {
     // hdl, part / nparts: as pass32_pk_f32 above
     constexpr int PC = Q + 2, NCB = FastCols<Q>::NCB, STRIDE = FastCols<Q>::STRIDE, NPART = DELTA ? 2 : 1;
+    // Round 5: the table's spare columns (STRIDE - NPROD: 9 at Q = 10) hold z_j itself, so the intercept row's entries sum (w) z_j come out of the
+    // same MFMAs as the block's (column NPROD + j), at the block's precision, instead of a packed fma per pair and entry on the vector ALU
+    // (72 of a group's 528 vector instructions at Q = 10).  Entries j >= NZ0 stay on the vector ALU.
+    constexpr int NPROD = FastCols<Q>::NPROD, NZ0 = (STRIDE - NPROD) < Q ? (STRIDE - NPROD) : Q;
     const int N = P.N;
     const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
     constexpr int RS = Q + 2;
@@ -406,7 +410,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         const v2f dx = xb * d;
         h00 += d; h10 += dx;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
+        for (int j = 0; j < Q; ++j) { if (j >= NZ0) hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
         stash(slot, d);
     };
     auto fetch_rec = [&](int pr, v2f (&rec)[RS]) {
@@ -485,8 +489,8 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
             h00 = v2f{0.0f, 0.0f}; h10 = v2f{0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
-                hdl[(2 + j) * 64 + lane] += (double)(hz0[j].x + hz0[j].y); hdl[(2 + Q + j) * 64 + lane] += (double)(hz1[j].x + hz1[j].y);
-                hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f};
+                if (j >= NZ0) { hdl[(2 + j) * 64 + lane] += (double)(hz0[j].x + hz0[j].y); hz0[j] = v2f{0.0f, 0.0f}; }
+                hdl[(2 + Q + j) * 64 + lane] += (double)(hz1[j].x + hz1[j].y); hz1[j] = v2f{0.0f, 0.0f};
             }
         }
     }
@@ -513,7 +517,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         const float dx = odd_x ? odd_d : 0.0f;
         h00.x += odd_d; h10.x += dx;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0[j].x = fmaf(odd_d, zj, hz0[j].x); hz1[j].x = fmaf(dx, zj, hz1[j].x); }
+        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; if (j >= NZ0) hz0[j].x = fmaf(odd_d, zj, hz0[j].x); hz1[j].x = fmaf(dx, zj, hz1[j].x); }
     }
     if (tail) {
         const int pend = nfull + (N & 1);                                     // pair slots in use, the odd sample's included
@@ -541,7 +545,8 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         h00s = (float)(hdl[lane] + (double)h00s); h10s = (float)(hdl[64 + lane] + (double)h10s);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            hz0s[j] = (float)(hdl[(2 + j) * 64 + lane] + (double)hz0s[j]); hz1s[j] = (float)(hdl[(2 + Q + j) * 64 + lane] + (double)hz1s[j]);
+            if (j >= NZ0) hz0s[j] = (float)(hdl[(2 + j) * 64 + lane] + (double)hz0s[j]);
+            hz1s[j] = (float)(hdl[(2 + Q + j) * 64 + lane] + (double)hz1s[j]);
         }
     }
     H[sidx(0, 0)] = h00s; H[sidx(1, 0)] = h10s; H[sidx(1, 1)] = h10s;
@@ -562,6 +567,8 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
             for (int j = 0; j < Q; ++j)
 #pragma unroll
                 for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = row[j * (j + 1) / 2 + k];
+#pragma unroll
+            for (int j = 0; j < NZ0; ++j) H[sidx(2 + j, 0)] = row[NPROD + j];
         }
     }
 }
@@ -1292,27 +1299,58 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
 #pragma unroll
     for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
     // y is 0/1 here (sh_glm_setup turns the finishing kernels off otherwise): ll_i = -softplus(a_i), a_i = (1 - 2 y_i) eta_i (= log mu_i for
-    // y = 1, log(1 - mu_i) for y = 0: SM Logit.loglike), and with t = exp(-|eta|):  softplus(a) = max(a, 0) + log(1 + t),  mu = 1 / (1 + t)
-    // or t / (1 + t).  The logs are not taken one by one: the factors 1 + t in (1, 2] are MULTIPLIED (one rounding each, like a sum's),
-    // renormalised once per 64-sample word, and one log at the end turns the product into the sum.  One exp (argument reduced, degree-13
-    // polynomial, v_ldexp) and one reciprocal per sample, no log.  The sample's record is fetched one sample ahead.
-    double maxdev = 0.0, apos = 0.0, prod = 1.0;
+    // y = 1, log(1 - mu_i) for y = 0: SM Logit.loglike), and with t = exp(-|eta|):  softplus(a) = max(a, 0) + log(1 + t).  The logs are not
+    // taken one by one: the factors 1 + t in (1, 2] are MULTIPLIED (one rounding each, like a sum's), renormalised once per 64-sample word,
+    // and one log at the end turns the product into the sum.  One exp (argument reduced, degree-11 polynomial: 6e-15 relative, v_ldexp) and
+    // one reciprocal per sample, no log.  The sample's record is fetched one sample ahead.
+    // Round 5, 68.5 -> 57.5 vector instructions per sample (the kernel runs at the fp64 issue rate, 4.8 cycles per instruction at four
+    // wavefronts per SIMD): the variant's bit enters as a double (v_bfe, v_cvt: eta and g_1 by one fma each instead of compare + two selects
+    // + add); max(s eta, 0) = (|eta| + s eta) / 2 summed as its two halves (an add with the |.| modifier and an fma); mu - 1/2 =
+    // sign(eta) (1 - t) / (2 (1 + t)) instead of a compare, a product and two selects; s = 1 - 2 y and y - 1/2 are made from y's bits on the
+    // scalar unit (the record is wave-uniform); the polynomial's leading coefficient sits in a register (two scalar operands in one fma
+    // cost a move).
+    double maxdev = 0.0, abs_eta = 0.0, s_eta = 0.0, prod = 1.0;
     int pexp = 0;
-    auto one = [&](const double (&rc)[RS], bool xb) {
-        double eta = beta[0] + (xb ? beta[1] : 0.0);
+    double ctop = 2.505210838544172e-08;                             // 1/11!
+    asm("" : "+v"(ctop));                                       // (not volatile: a volatile asm counts as a possible store, and the records' loads stop being scalar)
+    auto one = [&](const double (&rc)[RS], uint32_t bit) {
+        const double xd = (double)bit;
+        double eta = fma(beta[1], xd, beta[0]);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(beta[2 + j], rc[j], eta);
-        const double yi = rc[Q];
-        const double t = exp_neg(fabs(eta)), u = 1.0 + t;
+        // (wave-uniform: y = 1.0 is 0x3ff00000 in the high word -- bit 29 is its highest -- and y = 0 is 0)
+        const uint32_t shi = 0x3ff00000u | (((uint32_t)__double2hiint(rc[Q]) << 2) & 0x80000000u);
+        const double sg = __hiloint2double((int)shi, 0), ymh = __hiloint2double((int)(shi ^ 0x80100000u), 0);   // 1 - 2 y;  y - 1/2
+        double t;
+        {
+            const double u0 = -fmin(fabs(eta), 800.0);
+            const double kf = rint(u0 * 1.4426950408889634074);
+            double r = fma(kf, -6.93147180369123816490e-01, u0);
+            r = fma(kf, -1.90821492927058770002e-10, r);
+            double p = fma(ctop, r, 2.755731922398589e-07);          // 1/10!
+            p = fma(p, r, 2.7557319223985893e-06);                   // 1/9!
+            p = fma(p, r, 2.48015873015873e-05);                     // 1/8!
+            p = fma(p, r, 1.984126984126984e-04);                    // 1/7!
+            p = fma(p, r, 1.3888888888888889e-03);                   // 1/6!
+            p = fma(p, r, 8.333333333333333e-03);                    // 1/5!
+            p = fma(p, r, 4.1666666666666664e-02);                   // 1/4!
+            p = fma(p, r, 1.6666666666666666e-01);                   // 1/3!
+            p = fma(p, r, 0.5);
+            p = fma(p, r, 1.0);
+            p = fma(p, r, 1.0);
+            t = ldexp(p, (int)kf);
+        }
+        const double u = 1.0 + t;
         double inv = __builtin_amdgcn_rcp(u);                                      // two Newton steps: 1 / u to the last bit or two
         inv = fma(fma(-u, inv, 1.0), inv, inv);
         inv = fma(fma(-u, inv, 1.0), inv, inv);
-        const double mu = (eta >= 0.0) ? inv : t * inv;
-        const double r = yi - mu;
-        apos += fmax(fma(-2.0 * yi, eta, eta), 0.0);                              // a = (1 - 2 y) eta
+        const double hm = copysign(fma(-0.5, t, 0.5) * inv, eta);                  // mu - 1/2
+        const double r = ymh - hm;                                                 // y - mu
+        abs_eta += fabs(eta);
+        s_eta = fma(sg, eta, s_eta);
         prod *= u;
         maxdev = fmax(maxdev, fabs(r));
-        g[0] += r; g[1] += xb ? r : 0.0;
+        g[0] += r; g[1] = fma(xd, r, g[1]);
 #pragma unroll
         for (int j = 0; j < Q; ++j) g[2 + j] = fma(r, rc[j], g[2 + j]);
     };
@@ -1323,22 +1361,33 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
         const uint64_t w = T[(int64_t)wd * Vpad + v];
         const int lim = min(64, N - wd * 64);
         if (lim == 64) {
-            for (int b = 0; b < 64; b += 2) {
-                const int i = wd * 64 + b, i2 = min(i + 2, N - 1);
-                const int za = pipe_zero(ra[0]);
+#pragma unroll 1
+            for (int hf = 0; hf < 2; ++hf) {                         // (32-bit halves: the bit is one v_bfe_u32 with the position in a scalar register)
+                const uint32_t wh = hf ? (uint32_t)(w >> 32) : (uint32_t)w;
+#pragma unroll 1
+                for (int b = 0; b < 32; b += 2) {
+                    const int i = wd * 64 + hf * 32 + b, i2 = min(i + 2, N - 1);
+                    const int za = pipe_zero(ra[0]);
 #pragma unroll
-                for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
-                one(ra, (w >> b) & 1ull);
-                const int zb = pipe_zero(rb[0]);
+                    for (int k = 0; k < RS; ++k) rb[k] = R[(int64_t)(i + 1 + za) * RS + k];
+                    __builtin_amdgcn_sched_barrier(0);
+                    one(ra, __builtin_amdgcn_ubfe(wh, (uint32_t)b, 1u));
+                    // (the fences keep the two samples' instructions apart: interleaved, the odd sample's record is wanted five instructions
+                    // behind its load instead of a whole sample behind it -- measured 3.05 ms against 2.6)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int zb = pipe_zero(rb[0]);
 #pragma unroll
-                for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
-                one(rb, (w >> (b + 1)) & 1ull);
+                    for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(i2 + zb) * RS + k];
+                    __builtin_amdgcn_sched_barrier(0);
+                    one(rb, __builtin_amdgcn_ubfe(wh, (uint32_t)(b + 1), 1u));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
             for (int b = 0; b < lim; ++b) {
 #pragma unroll
                 for (int k = 0; k < RS; ++k) ra[k] = R[(int64_t)(wd * 64 + b) * RS + k];
-                one(ra, (w >> b) & 1ull);
+                one(ra, (uint32_t)(w >> b) & 1u);
             }
         }
         int e2; prod = frexp(prod, &e2); pexp += e2;
@@ -1346,7 +1395,7 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
     if (!on) return;
 #pragma unroll
     for (int a = 0; a < PC; ++a) P.ch_g[(int64_t)a * Vpad + v] = g[a];
-    P.ch_md[v] = maxdev; P.ch_ll[v] = -(apos + fma((double)pexp, 0.6931471805599453, log(prod)));
+    P.ch_md[v] = maxdev; P.ch_ll[v] = -(0.5 * (abs_eta + s_eta) + fma((double)pexp, 0.6931471805599453, log(prod)));
 }
 
 template <int Q>
