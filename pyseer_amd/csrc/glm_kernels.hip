@@ -352,6 +352,12 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define P32_ASCALE 1024.0f
+#ifndef P16_ABL
+#define P16_ABL 0
+#endif
+#ifndef P16_ABL_D
+#define P16_ABL_D 0
+#endif
 template <int Q, bool DELTA>
 __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
                                           const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
@@ -366,6 +372,9 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     const int N = P.N;
     const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
     constexpr int RS = Q + 2;
+    // timing ablations (results meaningless; profiles/r05/pass32_ablations.txt): 1 no MFMAs, 2 no table loads, 4 no transcendentals, 8 no score,
+    // 16 every record load reads record 0 (always a scalar-cache hit)
+    constexpr int ABL = DELTA ? P16_ABL_D : P16_ABL;
     const v2f *__restrict__ Rp = (const v2f *)P.wfp;
     const v4u *__restrict__ Z16 = (const v4u *)P.zz16;                        // [group][NCB][2 (hi, lo)][64 lanes] x 16 bytes
     v16f acc[NCB][2];
@@ -397,10 +406,11 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = pkfma(bf[2 + j], rec[j], eta);
         v2f mu;
-        mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y);
+        if (ABL & 4) mu = pkfma(eta, v2f{0.25f, 0.25f}, v2f{0.5f, 0.5f}); else { mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y); }
         const v2f wf = pkfma(-mu, mu, mu);
         v2f d = wf;
         if (DELTA) d = wf - rec[Q + 1];
+        else if (ABL & 8) { gf[0] += rec[Q] - mu; }
         else {
             const v2f r = rec[Q] - mu;
             gf[0] += r; gf[1] = pkfma(xb, r, gf[1]);
@@ -415,16 +425,17 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     };
     auto fetch_rec = [&](int pr, v2f (&rec)[RS]) {
 #pragma unroll
-        for (int k = 0; k < RS; ++k) rec[k] = Rp[(int64_t)pr * RS + k];
+        for (int k = 0; k < RS; ++k) rec[k] = Rp[(int64_t)((ABL & 16) ? 0 : pr) * RS + k];
     };
     auto fetch_bz = [&](int grp, v4u (&bz)[NCB][NPART]) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int q2 = 0; q2 < NPART; ++q2) bz[cb][q2] = Z16[(((int64_t)grp * NCB + cb) * 2 + q2) * 64 + lane];
+            for (int q2 = 0; q2 < NPART; ++q2) bz[cb][q2] = (ABL & 2) ? v4u{(uint32_t)grp, 0u, 0u, 0u} : Z16[(((int64_t)grp * NCB + cb) * 2 + q2) * 64 + lane];
     };
     // the 16 samples stashed in Ah / Al against the group's product columns
     auto flush = [&](const v4u (&bz)[NCB][NPART]) {
+        if (ABL & 1) { acc[0][0][0] += __builtin_bit_cast(float, Ah[0] ^ Ah[7] ^ bz[0][0][0] ^ bz[NCB - 1][NPART - 1][0]) + (DELTA ? __builtin_bit_cast(float, Al[0]) : 0.0f); return; }
         v4u a0, a1, l0, l1;
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
