@@ -375,7 +375,25 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     // timing ablations (results meaningless; profiles/r05/pass32_ablations.txt): 1 no MFMAs, 2 no table loads, 4 no transcendentals, 8 no score,
     // 16 every record load reads record 0 (always a scalar-cache hit)
     constexpr int ABL = DELTA ? P16_ABL_D : P16_ABL;
-    const v2f *__restrict__ Rp = (const v2f *)P.wfp;
+    // (constant address space: the touches below are volatile asm, which would otherwise take the "never clobbered" property from the records
+    // and turn their scalar loads into per-lane vector loads -- firth_rounds.hip)
+    typedef const __attribute__((address_space(4))) v2f *crec_t;
+    const crec_t Rp = (crec_t)P.wfp;
+    // Round 5: the pass waits for its record loads (1.85 ms against 1.35 with every load a scalar-cache hit, profiles/r05/pass32_ablations.txt):
+    // a miss outlasts a pair's arithmetic, and scalar loads return out of order, so only s_waitcnt lgkmcnt(0) exists for them and a load
+    // issued further ahead is waited for at the next pair anyway.  What CAN be taken off the pairs is the miss itself: once per 16-sample
+    // group the cache lines of the NEXT group's eight records (64 (Q + 2) bytes = Q + 2 lines) are touched by loads into a register nobody
+    // reads, all at once -- one exposed miss per group instead of one per pair, the records' own loads then hit.  (At most 15 scalar loads can
+    // be outstanding: 12 touches + a record's two.)
+    uint32_t touch_sink = 0;
+    auto touch_group = [&](int grp, int lo, int hi) {
+        // (the last group may be partial: the touched window is pulled back inside the table -- nfull >= 32 wherever the word loop runs)
+        const char *base = (const char *)P.wfp + min((int64_t)grp * (64 * RS), (int64_t)(N >> 1) * (RS * 8) - 64 * RS);
+#pragma unroll
+        for (int l = 0; l < RS; ++l)
+            if (l >= lo && l < hi) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch_sink) : "s"(base), "n"(64 * l));
+    };
+    constexpr int TOUCH_A = RS < 12 ? RS : 12;
     const v4u *__restrict__ Z16 = (const v4u *)P.zz16;                        // [group][NCB][2 (hi, lo)][64 lanes] x 16 bytes
     v16f acc[NCB][2];
 #pragma unroll
@@ -479,6 +497,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         for (int g4 = 0; g4 < 4; ++g4) {
             const int grp = wd * 4 + g4;
             fetch_bz(min(grp + 1, glast), zn);
+            if (!(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), 0, TOUCH_A);
             const uint32_t wbits = (uint32_t)(w >> (16 * g4)) & 0xFFFFu;
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
@@ -487,6 +506,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
                 pair(ra, k, (wbits >> (2 * k)) & 3u);
                 fetch_rec(min(pr + 2, plast) + pipe_zero(rb[0].x), ra);
                 pair(rb, k + 1, (wbits >> (2 * k + 2)) & 3u);
+                if (RS > TOUCH_A && k == 2 && !(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), TOUCH_A, RS);
             }
             flush(zc);
 #pragma unroll
@@ -563,6 +583,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     H[sidx(0, 0)] = h00s; H[sidx(1, 0)] = h10s; H[sidx(1, 1)] = h10s;
 #pragma unroll
     for (int j = 0; j < Q; ++j) { H[sidx(2 + j, 0)] = hz0s[j]; H[sidx(2 + j, 1)] = hz1s[j]; }
+    asm volatile("" ::"s"(touch_sink));                                   // (the touches' register stays reserved until here)
     const float unscale = DELTA ? 1.0f / P32_ASCALE : 1.0f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1306,6 +1327,8 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
     if (!__any(on)) return;
     const int N = P.N, NB64 = P.NB64;
     const double *__restrict__ R = P.rec;
+    // (touching the next samples' cache lines ahead, as pass32_pk_f16 does for its records, does not pay here: 2.72 -> 2.83 ms; four wavefronts per
+    // SIMD already cover the scalar loads' misses)
     double beta[PC], g[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { beta[a] = P.ch_bs[(int64_t)a * Vpad + v]; g[a] = 0.0; }
