@@ -369,6 +369,22 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     // same MFMAs as the block's (column NPROD + j), at the block's precision, instead of a packed fma per pair and entry on the vector ALU
     // (72 of a group's 528 vector instructions at Q = 10).  Entries j >= NZ0 stay on the vector ALU.
     constexpr int NPROD = FastCols<Q>::NPROD, NZ0 = (STRIDE - NPROD) < Q ? (STRIDE - NPROD) : Q;
+    // LIN (the Newton-steering pass only; round 5): the variant's row of the Hessian (sum w k, sum w k z_j) is a GEMM against (1, z) as
+    // well, and leaves the vector ALU: the group's w k as a second A operand against GlmParams.zl16 ((1, z) in columns 0..Q, B layout of the
+    // products table, halves without a lo part -- the block's own precision), one more 32 x 32 accumulator tile per 32 variants.  88 of the
+    // group's 455 vector instructions for 2 MFMAs, 8 conversions and 4 lane swaps.  The score stays on the vector ALU: through halves
+    // (2^-11 per term) it sent a quarter of the variants into a second chord round and moved final estimates by 1e-5 relative (measured);
+    // hi + lo operands for it would give back half of the gain.  The final information matrix (DELTA) keeps the variant's row on the
+    // vector ALU too: its entries are sums of same-signed differences that need the per-word fp64 accumulation described above.
+    constexpr bool LIN = !DELTA;
+    static_assert(Q + 1 <= 32, "the linear block holds (1, z) in one 32-column block");
+    const v4u *__restrict__ ZL = (const v4u *)P.zl16;                         // [group][64 lanes] x 16 bytes
+    v16f accl[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accl[h][r] = 0.0f;
+    uint32_t Xh[LIN ? 8 : 1];                                               // this group's w k, one half2 per pair
     const int N = P.N;
     const int lane = threadIdx.x & 63, lh = lane >> 5, l31 = lane & 31;
     constexpr int RS = Q + 2;
@@ -436,9 +452,11 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
             for (int j = 0; j < Q; ++j) gf[2 + j] = pkfma(r, rec[j], gf[2 + j]);
         }
         const v2f dx = xb * d;
-        h00 += d; h10 += dx;
+        h00 += d;
+        if constexpr (LIN) Xh[slot] = __builtin_bit_cast(uint32_t, __builtin_convertvector(dx, v2h));
+        else h10 += dx;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { if (j >= NZ0) hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
+        for (int j = 0; j < Q; ++j) { if (j >= NZ0) hz0[j] = pkfma(d, rec[j], hz0[j]); if constexpr (!LIN) hz1[j] = pkfma(dx, rec[j], hz1[j]); }
         stash(slot, d);
     };
     auto fetch_rec = [&](int pr, v2f (&rec)[RS]) {
@@ -450,6 +468,21 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int q2 = 0; q2 < NPART; ++q2) bz[cb][q2] = (ABL & 2) ? v4u{(uint32_t)grp, 0u, 0u, 0u} : Z16[(((int64_t)grp * NCB + cb) * 2 + q2) * 64 + lane];
+    };
+    auto fetch_bl = [&](int grp, v4u &bl) { if constexpr (LIN) bl = ZL[(int64_t)grp * 64 + lane]; };
+    // the group's w k against the linear block (operands swapped into place as the weights' are)
+    auto flush_lin = [&](const v4u &bl) {
+        if constexpr (LIN) {
+            v4u x0, x1;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(Xh[q2], Xh[4 + q2], false, false);
+                x0[q2] = sw[0]; x1[q2] = sw[1];
+            }
+            const v8h B = __builtin_bit_cast(v8h, bl);
+            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, x0), B, accl[0], 0, 0, 0);
+            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, x1), B, accl[1], 0, 0, 0);
+        }
     };
     // the 16 samples stashed in Ah / Al against the group's product columns
     auto flush = [&](const v4u (&bz)[NCB][NPART]) {
@@ -483,20 +516,20 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     // Records: two buffers in turn, pair p + 1 fetched while pair p is computed (scalar loads, ordered by pipe_zero).  The lane's B operands of
     // a 16-sample group come from L2 (the table is 1.3 MB at N = 5000) one group ahead.  A 64-sample word holds 32 pairs = 4 groups.
     v2f ra[RS], rb[RS];
-    v4u zc[NCB][NPART], zn[NCB][NPART];
+    v4u zc[NCB][NPART], zn[NCB][NPART], lc, ln2;
     const int nwords = nfull >> 5;                                            // whole words: pipelined
     const int plast = nfull > 0 ? nfull - 1 : 0;
     const int glast = (N + 15) / 16 - 1;
     const int wd0 = (int)((int64_t)nwords * part / nparts), wd1 = (int)((int64_t)nwords * (part + 1) / nparts);
     const bool tail = part == nparts - 1;
-    fetch_rec(min(wd0 * 32, plast), ra); fetch_bz(min(wd0 * 4, glast), zc);
+    fetch_rec(min(wd0 * 32, plast), ra); fetch_bz(min(wd0 * 4, glast), zc); fetch_bl(min(wd0 * 4, glast), lc);
     uint64_t w = T[(int64_t)min(wd0, (N - 1) >> 6) * Vpad + v];
     for (int wd = wd0; wd < wd1; ++wd) {
         const uint64_t wn = T[(int64_t)min(wd + 1, (N - 1) >> 6) * Vpad + v];
 #pragma unroll 1
         for (int g4 = 0; g4 < 4; ++g4) {
             const int grp = wd * 4 + g4;
-            fetch_bz(min(grp + 1, glast), zn);
+            fetch_bz(min(grp + 1, glast), zn); fetch_bl(min(grp + 1, glast), ln2);
             if (!(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), 0, TOUCH_A);
             const uint32_t wbits = (uint32_t)(w >> (16 * g4)) & 0xFFFFu;
 #pragma unroll
@@ -508,11 +541,12 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
                 pair(rb, k + 1, (wbits >> (2 * k + 2)) & 3u);
                 if (RS > TOUCH_A && k == 2 && !(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), TOUCH_A, RS);
             }
-            flush(zc);
+            flush(zc); flush_lin(lc);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int q2 = 0; q2 < NPART; ++q2) zc[cb][q2] = zn[cb][q2];
+            lc = ln2;
         }
         w = wn;
         if (DELTA && hdl) {
@@ -546,23 +580,26 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
             for (int j = 0; j < Q; ++j) gf[2 + j].x = fmaf(r, Wf[(int64_t)i * Q + j], gf[2 + j].x);
         }
         const float dx = odd_x ? odd_d : 0.0f;
-        h00.x += odd_d; h10.x += dx;
+        h00.x += odd_d; if constexpr (!LIN) h10.x += dx;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; if (j >= NZ0) hz0[j].x = fmaf(odd_d, zj, hz0[j].x); hz1[j].x = fmaf(dx, zj, hz1[j].x); }
+        for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; if (j >= NZ0) hz0[j].x = fmaf(odd_d, zj, hz0[j].x); if constexpr (!LIN) hz1[j].x = fmaf(dx, zj, hz1[j].x); }
     }
     if (tail) {
         const int pend = nfull + (N & 1);                                     // pair slots in use, the odd sample's included
         for (int p0 = nwords * 32; p0 < pend; p0 += 8) {
             if (p0 == nwords * 32) w = T[(int64_t)min(p0 >> 5, (N - 1) >> 6) * Vpad + v];
-            fetch_bz(min(p0 >> 3, glast), zc);
+            fetch_bz(min(p0 >> 3, glast), zc); fetch_bl(min(p0 >> 3, glast), lc);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int pr = p0 + k;
                 if (pr < nfull) { fetch_rec(pr, ra); pair(ra, k, (uint32_t)(w >> (2 * (pr & 31))) & 3u); }
-                else if (pr == nfull && (N & 1)) stash(k, v2f{odd_d, 0.0f});
-                else stash(k, v2f{0.0f, 0.0f});
+                else {
+                    const bool odd = pr == nfull && (N & 1);
+                    stash(k, v2f{odd ? odd_d : 0.0f, 0.0f});
+                    if constexpr (LIN) Xh[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{odd && odd_x ? odd_d : 0.0f, 0.0f}, v2h));
+                }
             }
-            flush(zc);
+            flush(zc); flush_lin(lc);
         }
     }
     h00s = h00.x + h00.y; h10s = h10.x + h10.y;
@@ -570,8 +607,6 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     for (int a = 0; a < PC; ++a) gs[a] = gf[a].x + gf[a].y;
 #pragma unroll
     for (int j = 0; j < Q; ++j) { hz0s[j] = hz0[j].x + hz0[j].y; hz1s[j] = hz1[j].x + hz1[j].y; }
-#pragma unroll
-    for (int a = 0; a < PC; ++a) g[a] = (double)gs[a];
     if (DELTA && hdl) {
         h00s = (float)(hdl[lane] + (double)h00s); h10s = (float)(hdl[64 + lane] + (double)h10s);
 #pragma unroll
@@ -603,6 +638,23 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
             for (int j = 0; j < NZ0; ++j) H[sidx(2 + j, 0)] = row[NPROD + j];
         }
     }
+    if constexpr (LIN) {                                                     // the linear tile: columns 0..Q = the variant's row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * (STRIDE + 1) + l31] = accl[h][r];
+            __syncthreads();
+            if (lh == h) {
+                const float *row = tr + l31 * (STRIDE + 1);
+                H[sidx(1, 0)] = row[0]; H[sidx(1, 1)] = row[0];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) H[sidx(2 + j, 1)] = row[1 + j];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < PC; ++a) g[a] = (double)gs[a];
 }
 
 #ifndef P32_F16

@@ -11,6 +11,7 @@ struct GlmParams {
     double min_af, max_af; int af_on;
     int newton_mode;              // 0 = fp32-Hessian fast path with fp64 fallback (default), 1 = all-fp64 (reference trajectory)
     const void *zz16;             // the same products as halves in the B layout of v_mfma_f32_32x32x16_f16, hi and lo parts (pass32_pk): [16-sample group][32-column block][hi, lo][64 lanes] x 16 bytes
+    const void *zl16;             // pass32_pk_f16 (Newton steering): (1, z_1 .. z_Q) as halves in the B layout of the products table: [16-sample group][64 lanes] x 16 bytes, lane (n = lane & 31, kg = lane >> 5) = column n of samples 16 g + 8 kg .. + 7
     const float *zz;              // per-sample products table for fast_pass_mfma (FastCols<Q>::STRIDE floats per sample), or null
     const double *ws;             // N x q covariates standardised per column (the fast Newton path iterates in these coordinates), or null
     const double *wstd;           // [2q] column means, then column scales, of that standardisation
