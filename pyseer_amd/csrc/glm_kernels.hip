@@ -400,7 +400,9 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     // issued further ahead is waited for at the next pair anyway.  What CAN be taken off the pairs is the miss itself: once per 16-sample
     // group the cache lines of the NEXT group's eight records (64 (Q + 2) bytes = Q + 2 lines) are touched by loads into a register nobody
     // reads, all at once -- one exposed miss per group instead of one per pair, the records' own loads then hit.  (At most 15 scalar loads can
-    // be outstanding: 12 touches + a record's two.)
+    // be outstanding: 12 touches + a record's two.)  The touched register must not be written by anything else while a touch can be in flight:
+    // it is a variable that lives from the first touch to the end of the loops, and `make check-touch` (tools/check_touch_regs.py) verifies on the
+    // device assembly of every instantiation that nothing else writes it inside that window.
     uint32_t touch_sink = 0;
     auto touch_group = [&](int grp, int lo, int hi) {
         // (the last group may be partial: the touched window is pulled back inside the table -- nfull >= 32 wherever the word loop runs)
