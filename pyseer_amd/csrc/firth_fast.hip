@@ -166,7 +166,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     RT bsr[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { nU[a] = 0; bsr[a] = (RT)bs[a]; }
-    double apos = 0.0, prod = 1.0;
+    double apos = 0.0, seta = 0.0, prod = 1.0;                              // (apos, seta: twice the sum of max(s eta, 0), as sum |eta| + sum s eta)
     int pexp = 0;
     // The run's tables reach the block through LDS: per 16-sample group the NTA x 2 fragment blocks of the monomial table (1 KB each: one
     // wave-wide LDS-DMA) and the group's 16 sample records (2 KB slot), double buffered; iteration g of the loop below reads records g and
@@ -221,7 +221,9 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     };
     // one sample: returns the scaled weights (w - w0, c) as floats.  (c k and (w - w0) k are not formed per sample: k is 0 / 1, so their
     // halves are the halves of c and w - w0 under the pair's presence bits -- pair_mask below; round 5: 14 -> 7 instructions per pair)
-    auto sample = [&](const RT (&rc)[RS], uint32_t bit, float &wf, float &cf) {
+    // (tail: the group may hold slots behind sample N -- only the last group does; everywhere else the masks `lv` are dropped.  Round 5)
+    auto sample = [&](const RT (&rc)[RS], uint32_t bit, float &wf, float &cf, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
         if constexpr (F32) {
             // the FIRST pass (at the start vector, some 1e-2 from the fit) in single precision: its step need not be better than the 1e-5 the
             // next point is from the fit anyway; no log-likelihood (nothing to compare F with yet)
@@ -230,17 +232,20 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
             for (int j = 0; j < Q; ++j) eta = fmaf(bsr[2 + j], rc[j], eta);
             const float lv = rc[Q + 1];
-            const float t = __builtin_amdgcn_exp2f(fabsf(eta) * -1.4426950408889634f) * lv, u = 1.0f + t;
+            float t = __builtin_amdgcn_exp2f(fabsf(eta) * -1.4426950408889634f);
+            if (TAIL) t *= lv;
+            const float u = 1.0f + t;
             float inv = __builtin_amdgcn_rcpf(u);
             inv = fmaf(fmaf(-u, inv, 1.0f), inv, inv);
             const float wgt = (t * inv) * inv;
             const float hm = copysignf(fmaf(-0.5f, t, 0.5f) * inv, eta);
-            const float r = fmaf(0.5f, rc[Q], hm) * lv;
+            float r = fmaf(0.5f, rc[Q], hm);
+            if (TAIL) r *= lv;
             nU[0] += r; nU[1] = fmaf(xd, r, nU[1]);
             Ik0 = fmaf(wgt, xd, Ik0);
 #pragma unroll
             for (int j = 0; j < Q; ++j) nU[2 + j] = fmaf(rc[j], r, nU[2 + j]);
-            wf = (wgt - rc[Q + 2]) * (float)FF_SCALE;
+            wf = fmaf(wgt, (float)FF_SCALE, rc[Q + 2]);                          // (the record holds -2^12 w0)
             cf = -(wgt * hm) * (float)FF_SCALE;
         } else {
         const double xd = (double)bit;
@@ -248,21 +253,26 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fma(bs[2 + j], rc[j], eta);
         const double lv = rc[Q + 1];
-        const double t = ff_exp_neg(fabs(eta)) * lv, u = 1.0 + t;
+        double t = ff_exp_neg(fabs(eta));
+        if (TAIL) t *= lv;
+        const double u = 1.0 + t;
         double inv = __builtin_amdgcn_rcp(u);
         inv = fma(fma(-u, inv, 1.0), inv, inv);
         inv = fma(fma(-u, inv, 1.0), inv, inv);
         const double wgt = (t * inv) * inv;                                     // mu (1 - mu) = t / (1 + t)^2   (0 behind sample N)
         const double hm = copysign(fma(-0.5, t, 0.5) * inv, eta);              // mu - 1/2
-        apos += fmax(rc[Q] * eta, 0.0);                                         // -log-likelihood term = max(s eta, 0) + log(1 + t);  s = 0 behind N
+        // -log-likelihood term = max(s eta, 0) + log(1 + t), and max(s eta, 0) = (|eta| + s eta) / 2 for s = +-1: two sums, halved at the end
+        // (an add with the |.| modifier and an fma instead of multiply, max, add).  s = 0 behind N: the tail keeps the max form.
+        if (TAIL) apos += 2.0 * fmax(rc[Q] * eta, 0.0);
+        else { apos += fabs(eta); seta = fma(rc[Q], eta, seta); }
         prod *= u;
-        const double r = fma(0.5, rc[Q], hm) * lv;                              // mu - y = (mu - 1/2) + s / 2
-        const double wx = wgt * xd;
+        double r = fma(0.5, rc[Q], hm);                                         // mu - y = (mu - 1/2) + s / 2
+        if (TAIL) r *= lv;
         nU[0] += r; nU[1] = fma(xd, r, nU[1]);
-        Ik0 += wx;                                                              // I11 = sum w k: the reference's bse^2, kept exact
+        Ik0 = fma(wgt, xd, Ik0);                                                // I11 = sum w k: the reference's bse^2, kept exact (k is 0 / 1: the product is)
 #pragma unroll
         for (int j = 0; j < Q; ++j) nU[2 + j] = fma(rc[j], r, nU[2 + j]);
-        wf = (float)((wgt - rc[Q + 2]) * FF_SCALE);                             // w - w0: I = I(null model) + sum (w - w0) m2, the sum an order of magnitude smaller than I
+        wf = (float)fma(wgt, FF_SCALE, rc[Q + 2]);                              // 2^12 (w - w0) (the record holds -2^12 w0: one rounding either way): I = I(null model) + sum (w - w0) m2, the sum an order of magnitude smaller than I
         cf = (float)(-(wgt * hm) * FF_SCALE);                                   // c = w (1/2 - mu)
         }
     };
@@ -323,8 +333,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     fetch_rec(lds, 0, ra);
     ff_v4u ah[PER], al[PER];                                                    // the slot's A fragments: [0] read a sample ahead of the rest
     slot_load(lds, 0, 0, 1, ah, al);
-#pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
+    auto group = [&](int g, auto tail) {
         if ((g & 3) == 0) {                                                     // the variant's next 64 presence bits, fetched four groups ahead
             w64 = wnext;
             wnext = T[(int64_t)min((g >> 2) + 1, P.NB64 - 1) * Vpad + v];
@@ -351,7 +360,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             slot_load(buf, pp, 1, PER, ah, al);
             __builtin_amdgcn_sched_barrier(0);
             if (FF_ABL & 4) { w0 = (float)ra[0]; c0 = (float)ra[1]; nU[pp] += ra[3]; }
-            else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0);
+            else sample(ra, (byte >> (2 * pp)) & 1u, w0, c0, tail);
             slot_mfma(pp, 0, 1, ah, al);
 #if FF_SCHED
 #pragma unroll
@@ -363,7 +372,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             // (the fences order instructions with side effects; plain arithmetic is placed wherever its operands allow.  Empty volatile asms that
             // "define" the even sample's results pin its arithmetic in front of the next fence, i.e. UNDER the LDS reads issued above)
             if constexpr (F32) asm volatile("" : "+v"(w0), "+v"(c0), "+v"(Ik0));
-            else asm volatile("" : "+v"(w0), "+v"(c0), "+v"(apos), "+v"(prod), "+v"(Ik0));
+            else asm volatile("" : "+v"(w0), "+v"(c0), "+v"(apos), "+v"(seta), "+v"(prod), "+v"(Ik0));
 #pragma unroll
             for (int a = 0; a < PC; ++a) asm volatile("" : "+v"(nU[a]));
             __builtin_amdgcn_sched_barrier(0);
@@ -371,7 +380,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             else { fetch_rec(bufn, 0, ra); slot_load(bufn, 0, 0, 1, ah, al); }
             __builtin_amdgcn_sched_barrier(0);
             if (FF_ABL & 4) { w1 = (float)rb[0]; c1 = (float)rb[1]; nU[pp] += rb[3]; }
-            else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1);
+            else sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1, tail);
             stash(Bw, pp, w0, w1); stash(Bc, pp, c0, c1);
             {
                 const uint32_t pm = pair_mask(byte, pp);
@@ -397,7 +406,10 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
         // this wavefront's share of the NEXT iteration's tables has landed (the one after it may still be in flight), then the bare barrier:
         // everyone's has, and everyone is done reading this iteration's buffer.  (__syncthreads() would add a vmcnt(0) and wait for both)
         if (!(FF_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
-    }
+    };
+#pragma unroll 1
+    for (int g = 0; g < NG - 1; ++g) group(g, std::false_type{});
+    group(NG - 1, std::true_type{});
     {                                                                           // the MFMAs of the last group (slot 0's first fragment is in hand)
         const char *const buf = lds + (NG % NRING) * STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -417,6 +429,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     if constexpr (!F32) {
         int e2; prod = frexp(prod, &e2); pexp += e2;
         double lp = fma((double)pexp, 0.6931471805599453, log(prod));
+        apos = 0.5 * (apos + seta);
         lp += ff_xor32(lp); apos += ff_xor32(apos);
         ll = -(apos + lp);
     }

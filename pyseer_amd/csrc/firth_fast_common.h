@@ -45,7 +45,7 @@ template <int Q> struct FFC {
     static constexpr int N2 = ff_tri(Z1), N3 = ff_tet(Z1);
     static constexpr int T2 = (N2 + 31) / 32, T3 = (N3 + 31) / 32, NTA = T2 + T3, NACC = 2 * T2 + T3 + 1, AWK = 2 * T2 + T3;   // (AWK: the k-row of I)
     static_assert(Z1 <= 32, "the k-row of I lives in tile 0 of the degree-2 table");
-    static constexpr int RS = (Q + 3 + 1) & ~1;           // doubles per sample record: z_s[Q], s = 1 - 2 y, live (1 / 0), w0 (the null model's weight), padding to 16 bytes
+    static constexpr int RS = (Q + 3 + 1) & ~1;           // doubles per sample record: z_s[Q], s = 1 - 2 y, live (1 / 0), -2^12 w0 (the null model's weight, scaled like the operands), padding to 16 bytes
 };
 
 // g_x += sum over the distinct arrangements of the multiset {A, B, C} of t V_yz: for every distinct element x, the other two (y, z) give

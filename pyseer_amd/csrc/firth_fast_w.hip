@@ -28,7 +28,7 @@ template <int Q> struct FFW {
     typedef FFC<Q> C;
     static constexpr int T2H = (C::N2 + 15) / 16, T3H = (C::N3 + 15) / 16, NTA = T2H + T3H;   // 16-row tiles of the degree-2 / degree-3 tables
     static constexpr int NACC = 2 * T2H + T3H + 1, AWK = 2 * T2H + T3H;                        // (w - w0).m2, c.m3, c k.m2, (w - w0) k.(1, z)
-    static constexpr int RS = (Q + 2 + 3) & ~3;            // floats per sample record: z_s[Q], s = 1 - 2 y (0 behind sample N), w0; padded to 16 bytes
+    static constexpr int RS = (Q + 2 + 3) & ~3;            // floats per sample record: z_s[Q], s = 1 - 2 y (0 behind sample N), -2^12 w0; padded to 16 bytes
     static constexpr int ROWS = NACC * 16 + 16;            // hand-over rows per fit: the accumulator tiles' rows, then -score[PC], I11
     static constexpr int REC_PIECES = (32 * RS * 4 + 1023) / 1024, NPIECE = NTA + REC_PIECES, STAGE = NPIECE * 1024;
     static constexpr int NPW = (NPIECE + 7) / 8;           // 1 KB LDS-DMA pieces per wavefront and stage (8 wavefronts; the last ones repeat the last piece)
@@ -140,23 +140,28 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
         const uint32_t ev = (uint32_t)((int32_t)(byte << (31 - 2 * pp)) >> 31), od = (uint32_t)((int32_t)(byte << (30 - 2 * pp)) >> 31);
         return (ev & 0xffffu) | (od & 0xffff0000u);
     };
-    auto sample = [&](const float (&rc)[RS], uint32_t bit, float &wf, float &cf) {
+    // (tail: only the last group can hold slots behind sample N; everywhere else the mask `lv` is dropped: 2 of a sample's 55 instructions)
+    auto sample = [&](const float (&rc)[RS], uint32_t bit, float &wf, float &cf, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
         const float xd = (float)bit;
         float eta = fmaf(bs[1], xd, bs[0]);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fmaf(bs[2 + j], rc[j], eta);
         const float sg = rc[Q], lv = fabsf(sg);                                 // s = +-1; 0 behind sample N
-        const float t = __builtin_amdgcn_exp2f(fabsf(eta) * -1.4426950408889634f) * lv, u = 1.0f + t;
+        float t = __builtin_amdgcn_exp2f(fabsf(eta) * -1.4426950408889634f);
+        if (TAIL) t *= lv;
+        const float u = 1.0f + t;
         float inv = __builtin_amdgcn_rcpf(u);
         inv = fmaf(fmaf(-u, inv, 1.0f), inv, inv);
         const float wgt = (t * inv) * inv;                                      // mu (1 - mu) = t / (1 + t)^2
         const float hm = copysignf(fmaf(-0.5f, t, 0.5f) * inv, eta);           // mu - 1/2
-        const float r = fmaf(0.5f, sg, hm) * lv;                               // mu - y
+        float r = fmaf(0.5f, sg, hm);                                          // mu - y
+        if (TAIL) r *= lv;
         nU[0] += r; nU[1] = fmaf(xd, r, nU[1]);
         Ik0 = fmaf(wgt, xd, Ik0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) nU[2 + j] = fmaf(rc[j], r, nU[2 + j]);
-        wf = (wgt - rc[Q + 1]) * (float)FF_SCALE;                               // w - w0 (firth_fast.hip: I = I(null model) + sum (w - w0) m2)
+        wf = fmaf(wgt, (float)FF_SCALE, rc[Q + 1]);                             // 2^12 (w - w0): the record holds -2^12 w0 (firth_fast.hip: I = I(null model) + sum (w - w0) m2)
         cf = -(wgt * hm) * (float)FF_SCALE;                                     // c = w (1/2 - mu)
     };
     auto fetch_rec = [&](const char *buf, int j, float (&rc)[RS]) {
@@ -181,8 +186,7 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
     auto bits_at = [&](int gi) { const int gc = min(gi, 2 * P.NB64 - 1); return T32 + (((int64_t)(gc >> 1) * Vpad + v) * 2 + (gc & 1)); };
     uint32_t wcur = *bits_at(0), wnext = *bits_at(1), wraw = 0;
     asm volatile("" : "+v"(wcur), "+v"(wnext));            // (the compiler's wait for these two loads sits HERE, not in the loop's header)
-#pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
+    auto group = [&](int g, auto tail) {
         {
             const uint32_t *wp = bits_at(g + 2);
             asm volatile("global_load_dword %0, %1, off" : "=&v"(wraw) : "v"(wp));
@@ -196,8 +200,8 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
             float ra[RS], rb[RS], w0, c0, w1, c1;
             fetch_rec(buf, 2 * pp, ra);
             fetch_rec(buf, 2 * pp + 1, rb);
-            sample(ra, (byte >> (2 * pp)) & 1u, w0, c0);
-            sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1);
+            sample(ra, (byte >> (2 * pp)) & 1u, w0, c0, tail);
+            sample(rb, (byte >> (2 * pp + 1)) & 1u, w1, c1, tail);
             Bw[pp] = pack(w0, w1); Bc[pp] = pack(c0, c1);
             tiles(buf, pp * TPP, min((pp + 1) * TPP, NTA));               // (the previous group's operands against the previous group's tiles)
         }
@@ -211,7 +215,10 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
         wcur = wnext;
         asm volatile("v_mov_b32 %0, %1" : "=v"(wnext) : "v"(wraw));
-    }
+    };
+#pragma unroll 1
+    for (int g = 0; g < NG - 1; ++g) group(g, std::false_type{});
+    group(NG - 1, std::true_type{});
     {                                                       // the MFMAs of the last group
         const char *const buf = lds + (NG % NRING) * STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
