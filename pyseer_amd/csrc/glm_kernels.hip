@@ -411,7 +411,9 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         for (int l = 0; l < RS; ++l)
             if (l >= lo && l < hi) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch_sink) : "s"(base), "n"(64 * l));
     };
-    constexpr int TOUCH_A = RS < 12 ? RS : 12;
+    // (Q <= 10 only: with more covariates the two record buffers take 2 x 2 (Q + 2) of the ~100 scalar registers, the compiler spills and MOVES
+    // the touched register -- `make check-touch` found that for Q = 14 -- and a touch in flight would land in whatever took its place)
+    constexpr bool TOUCH = RS <= 12;
     const v4u *__restrict__ Z16 = (const v4u *)P.zz16;                        // [group][NCB][2 (hi, lo)][64 lanes] x 16 bytes
     v16f acc[NCB][2];
 #pragma unroll
@@ -532,16 +534,17 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
         for (int g4 = 0; g4 < 4; ++g4) {
             const int grp = wd * 4 + g4;
             fetch_bz(min(grp + 1, glast), zn); fetch_bl(min(grp + 1, glast), ln2);
-            if (!(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), 0, TOUCH_A);
             const uint32_t wbits = (uint32_t)(w >> (16 * g4)) & 0xFFFFu;
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
                 const int pr = grp * 8 + k;
                 fetch_rec(pr + 1 + pipe_zero(ra[0].x), rb);
+                // (the touches go out BEHIND the wait for this pair's record and the request for the next one: issued in front of that wait
+                // they were waited for at once -- a whole miss exposed per group instead of a miss less a pair's arithmetic)
+                if (TOUCH && k == 0 && !(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), 0, RS);
                 pair(ra, k, (wbits >> (2 * k)) & 3u);
                 fetch_rec(min(pr + 2, plast) + pipe_zero(rb[0].x), ra);
                 pair(rb, k + 1, (wbits >> (2 * k + 2)) & 3u);
-                if (RS > TOUCH_A && k == 2 && !(ABL & 32)) touch_group(min(grp + 1, (plast >> 3)), TOUCH_A, RS);
             }
             flush(zc); flush_lin(lc);
 #pragma unroll
