@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
     // taken one by one: the factors 1 + t in (1, 2] are MULTIPLIED (one rounding each, like a sum's), renormalised once per 64-sample word,
     // and one log at the end turns the product into the sum.  One exp (argument reduced, degree-11 polynomial: 6e-15 relative, v_ldexp) and
     // one reciprocal per sample, no log.  The sample's record is fetched one sample ahead.
-    // Round 5, 68.5 -> 57.5 vector instructions per sample (the kernel runs at the fp64 issue rate, 4.8 cycles per instruction at four
+    // Round 5, 68.5 -> 54.5 vector instructions per sample (the kernel runs at the fp64 issue rate, 4.8 cycles per instruction at four
     // wavefronts per SIMD): the variant's bit enters as a double (v_bfe, v_cvt: eta and g_1 by one fma each instead of compare + two selects
     // + add); max(s eta, 0) = (|eta| + s eta) / 2 summed as its two halves (an add with the |.| modifier and an fma); mu - 1/2 =
     // sign(eta) (1 - t) / (2 (1 + t)) instead of a compare, a product and two selects; s = 1 - 2 y and y - 1/2 are made from y's bits on the
@@ -1415,7 +1415,10 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
         double t;
         {
             const double u0 = -fmin(fabs(eta), 800.0);
-            const double kf = rint(u0 * 1.4426950408889634074);
+            // (k = round(u0 log2 e) by the magic constant 1.5 x 2^52: the sum's low word IS k as an integer -- one fma and one subtraction
+            // instead of multiply, v_rndne, v_cvt_i32)
+            const double kfm = fma(u0, 1.4426950408889634074, 6755399441055744.0);
+            const double kf = kfm - 6755399441055744.0;
             double r = fma(kf, -6.93147180369123816490e-01, u0);
             r = fma(kf, -1.90821492927058770002e-10, r);
             double p = fma(ctop, r, 2.755731922398589e-07);          // 1/10!
@@ -1429,11 +1432,10 @@ __global__ __launch_bounds__(256, GLM_LL_BLOCKS) void k_glm_ll(const uint64_t *_
             p = fma(p, r, 0.5);
             p = fma(p, r, 1.0);
             p = fma(p, r, 1.0);
-            t = ldexp(p, (int)kf);
+            t = ldexp(p, __double2loint(kfm));
         }
         const double u = 1.0 + t;
-        double inv = __builtin_amdgcn_rcp(u);                                      // two Newton steps: 1 / u to the last bit or two
-        inv = fma(fma(-u, inv, 1.0), inv, inv);
+        double inv = __builtin_amdgcn_rcp(u);                                      // one Newton step: 2.2e-15 relative (tools/ubench/exp_rcp_acc.hip), against 6e-15 in t
         inv = fma(fma(-u, inv, 1.0), inv, inv);
         const double hm = copysign(fma(-0.5, t, 0.5) * inv, eta);                  // mu - 1/2
         const double r = ymh - hm;                                                 // y - mu
