@@ -737,10 +737,43 @@ __global__ __launch_bounds__(64 * SplitCfg<Q>::S) void k_glm_pass32_split(const 
     for (int a = 0; a < PC; ++a) { float t = part[(NH + a) * 64 + lane]; for (int s2 = 1; s2 < S; ++s2) t += part[(s2 * NV + NH + a) * 64 + lane]; P.ch_g[(int64_t)a * Vpad + v] = (double)t; }
 }
 
-template <int Q, bool PK>
+// One single-precision Newton step's solve for one variant (k_glm_solve32<Q, false>, and k_glm_pass32<Q, true> which runs it in its own epilogue:
+// the Hessian and the score then never leave the lane -- 408 bytes per variant less to write and read back, one launch less per round): factor
+// H / n - ridge, solve, beta += step, and where the variant goes next.
+template <int Q>
+__device__ __forceinline__ void solve32_lane(int64_t v, int64_t Vpad, const GlmParams &P, double (&A)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], int last_round,
+                                             bool &go_next, bool &go_chord, bool &go_slow)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    double det;
+    if (!ldl_factor<PC>(A, 1e-4, &det)) go_slow = true;                                          // fp32 cannot resolve this design
+    else {
+        ldl_solve<PC>(A, g);
+        double stp = 0.0; bool finite = true;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) {
+            const double b = P.ch_bs[(int64_t)a * Vpad + v] + g[a];
+            stp = fmax(stp, fabs(g[a])); finite = finite && isfinite(b);
+            P.ch_bs[(int64_t)a * Vpad + v] = b;
+        }
+        if (!finite) go_slow = true;
+        else if (stp <= P.chord_enter) {
+            go_chord = true;
+#pragma unroll
+            for (int a = 0; a < NH; ++a) P.ch_fac[(int64_t)a * Vpad + v] = A[a];
+            P.ch_rho[v] = (float)fmin(0.5, fmax(8.0 * stp, 1e-4));
+        }
+        else if (last_round) go_slow = true;
+        else go_next = true;
+    }
+}
+
+template <int Q, bool PK, bool FUSE = false>
 __global__ __launch_bounds__(64, PK ? 2 : 3) void k_glm_pass32(const uint64_t *__restrict__ T, int64_t Vpad, const double *__restrict__ y,
                                                       const float *__restrict__ Wf, GlmParams P, const int *__restrict__ list,
-                                                      const int *__restrict__ cnt)
+                                                      const int *__restrict__ cnt, GlmWork wk = GlmWork{}, int *__restrict__ next = nullptr,
+                                                      int *__restrict__ next_cnt = nullptr, int *__restrict__ chord = nullptr,
+                                                      int *__restrict__ chord_cnt = nullptr, int last_round = 0)
 {
     constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
     if ((int64_t)blockIdx.x * 64 >= *cnt) return;
@@ -753,6 +786,22 @@ __global__ __launch_bounds__(64, PK ? 2 : 3) void k_glm_pass32(const uint64_t *_
     __shared__ float tr[FastCols<Q>::LDS_FLOATS];
     if (PK) pass32_pk<Q, false>(T, Vpad, v, P, Wf, beta, Hf, g, tr);
     else fast_pass_mfma<Q, true>(T, Vpad, v, P.N, P.NB64, y, P.ws, Wf, P.zz, beta, Hf, g, maxdev, tr);
+    if constexpr (FUSE) {                                            // the round's solve, here (solve32_lane): H and g stay in the lane
+        bool go_next = false, go_chord = false, go_slow = false;
+        if (on) {
+            const double nobs = (double)P.N;
+            double A[NH];
+#pragma unroll
+            for (int a = 0; a < NH; ++a) A[a] = (double)Hf[a] / nobs;
+#pragma unroll
+            for (int a = 0; a < PC; ++a) { A[sidx(a, a)] -= 1e-10; g[a] = g[a] / nobs; }
+            solve32_lane<Q>(v, Vpad, P, A, g, last_round, go_next, go_chord, go_slow);
+        }
+        list_push(go_next, next, next_cnt, (int)v);
+        list_push(go_chord, chord, chord_cnt, (int)v);
+        list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
+        return;
+    }
     if (!on) return;
 #pragma unroll
     for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = Hf[a];
@@ -796,27 +845,7 @@ __global__ __launch_bounds__(256) void k_glm_solve32(int64_t Vpad, GlmParams P, 
 #pragma unroll
             for (int a = 0; a < PC; ++a) { A[sidx(a, a)] -= 1e-10; g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; }
         }
-        double det;
-        if (!ldl_factor<PC>(A, 1e-4, &det)) go_slow = true;                                          // fp32 cannot resolve this design
-        else {
-            ldl_solve<PC>(A, g);
-            double stp = 0.0; bool finite = true;
-#pragma unroll
-            for (int a = 0; a < PC; ++a) {
-                const double b = P.ch_bs[(int64_t)a * Vpad + v] + g[a];
-                stp = fmax(stp, fabs(g[a])); finite = finite && isfinite(b);
-                P.ch_bs[(int64_t)a * Vpad + v] = b;
-            }
-            if (!finite) go_slow = true;
-            else if (stp <= P.chord_enter) {
-                go_chord = true;
-#pragma unroll
-                for (int a = 0; a < NH; ++a) P.ch_fac[(int64_t)a * Vpad + v] = A[a];
-                P.ch_rho[v] = (float)fmin(0.5, fmax(8.0 * stp, 1e-4));
-            }
-            else if (last_round) go_slow = true;
-            else go_next = true;
-        }
+        solve32_lane<Q>(v, Vpad, P, A, g, last_round, go_next, go_chord, go_slow);
     }
     list_push_block(go_next, next, next_cnt, (int)v, push_lds);
     list_push_block(go_chord, chord, chord_cnt, (int)v, push_lds);
@@ -1715,7 +1744,12 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_glm_pass32_split<Q>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
                     hipLaunchKernelGGL(k_glm_pass32_split<Q>, grid, dim3(64 * SplitCfg<Q>::S), lds, st, T, Vpad, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
                 }
-                else if (P.wfp) hipLaunchKernelGGL((k_glm_pass32<Q, true>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
+                else if (P.wfp) {
+                    // (the round's solve in the pass' own epilogue: k_glm_pass32<Q, true, true>)
+                    hipLaunchKernelGGL((k_glm_pass32<Q, true, true>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r, wk,
+                                       P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1, P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
+                    continue;
+                }
                 else hipLaunchKernelGGL((k_glm_pass32<Q, false>), grid, blk, 0, st, T, Vpad, y, Wf, P, P.ch_list[r & 1], P.ch_cnt + r);
                 hipLaunchKernelGGL((k_glm_solve32<Q, false>), g256, b256, 0, st, Vpad, P, wk, P.ch_list[r & 1], P.ch_cnt + r, P.ch_list[(r + 1) & 1], P.ch_cnt + r + 1,
                                    P.ch_list[2], cc, r == n32 - 1 ? 1 : 0);
