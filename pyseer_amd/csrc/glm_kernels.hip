@@ -1612,44 +1612,15 @@ __global__ __launch_bounds__(64, 3) void k_glm_dpass(const uint64_t *__restrict_
     for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
 }
 
-template <int Q>
-__global__ __launch_bounds__(64, 2) void k_glm_dpass_pk(const uint64_t *__restrict__ T, int64_t Vpad, const float *__restrict__ Wf, GlmParams P,
-                                                        const int *__restrict__ list, const int *__restrict__ cnt)
+// What k_glm_finish does for one variant: assemble the information matrix (the null model's block and the carrier sums, exact, + the
+// single-precision differences hf(a) of k_glm_dpass), factor it, bse, the exact Newton step, the decisions and the output row.  Also run by
+// k_glm_dpass_pk<Q, FIN> in its own epilogue, where the differences never leave the lane (312 bytes per variant less to write and read back).
+template <int Q, bool DIRECT, class HF>
+__device__ __forceinline__ void finish_lane(int64_t v, int64_t Vpad, int64_t V, const GlmParams &P, HF hf, double *__restrict__ out, uint32_t *__restrict__ flags,
+                                            int *__restrict__ firth_list, int *__restrict__ firth_count, bool &go_slow)
 {
     constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
-    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
-    int64_t v;
-    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
-    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
-    __shared__ double hdl[(2 + 2 * Q) * 64];
-#pragma unroll
-    for (int k = 0; k < 2 + 2 * Q; ++k) hdl[k * 64 + threadIdx.x] = 0.0;     // a lane only ever touches its own column
-    double beta[PC], g[PC];
-#pragma unroll
-    for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
-    float H[NH];
-    pass32_pk<Q, true>(T, Vpad, v, P, Wf, beta, H, g, tr, 0, 1, hdl);
-    if (!on) return;
-#pragma unroll
-    for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
-}
-
-// DIRECT (GlmParams.ll_first): the score, log-likelihood and callback value on record were taken at ch_b0, one chord step in front of ch_bs (where
-// the information matrix was just evaluated): the result is the exact Newton step from ch_b0 with that matrix, beta = ch_b0 + H^-1 g (error
-// O(step^2), step <= 1e-4), its log-likelihood ll(ch_b0) + g . step / 2 (error O(N step^3)); the certificate is the distance of that beta from
-// the chord result (what the chord factor got wrong), <= 5e-7 as for the step of the plain form.
-template <int Q, bool DIRECT = false>
-__global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmParams P, GlmWork wk, const int *__restrict__ list,
-                                                   const int *__restrict__ cnt, double *__restrict__ out, uint32_t *__restrict__ flags,
-                                                   int *__restrict__ firth_list, int *__restrict__ firth_count)
-{
-    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
-    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
-    int64_t v;
-    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
     const double nobs = (double)P.N;
-    bool go_slow = false;
-    if (on) {
         double beta[PC];
 #pragma unroll
         for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
@@ -1668,7 +1639,7 @@ __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmP
                 for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = P.a0[j * (j + 1) / 2 + k];
             }
 #pragma unroll
-            for (int a = 0; a < NH; ++a) H[a] = (H[a] + (double)P.ch_hf[(int64_t)a * Vpad + v]) / nobs;
+            for (int a = 0; a < NH; ++a) H[a] = (H[a] + (double)hf(a)) / nobs;
             double det;
             if (!ldl_factor<PC>(H, 1.0e-5, &det)) {                  // (nearly) singular: the all-fp64 restart decides (an exactly singular design must be SEEN as such)
                 emit = false; go_slow = true;
@@ -1705,6 +1676,52 @@ __global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmP
         }
         if (emit) glm_emit<Q>(status, bse1, P.ch_ll[v] + llf_adj, beta, true, v, V, P, out, flags, firth_list, firth_count);
     }
+
+template <int Q, int FIN = 0>                                       // FIN: 1 = k_glm_finish<Q, true> in the epilogue, 2 = k_glm_finish<Q, false>
+__global__ __launch_bounds__(64, 2) void k_glm_dpass_pk(const uint64_t *__restrict__ T, int64_t Vpad, const float *__restrict__ Wf, GlmParams P,
+                                                        const int *__restrict__ list, const int *__restrict__ cnt, int64_t V = 0, GlmWork wk = GlmWork{},
+                                                        double *__restrict__ out = nullptr, uint32_t *__restrict__ flags = nullptr,
+                                                        int *__restrict__ firth_list = nullptr, int *__restrict__ firth_count = nullptr)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    __shared__ float tr[FastCols<Q>::LDS_FLOATS];
+    __shared__ double hdl[(2 + 2 * Q) * 64];
+#pragma unroll
+    for (int k = 0; k < 2 + 2 * Q; ++k) hdl[k * 64 + threadIdx.x] = 0.0;     // a lane only ever touches its own column
+    double beta[PC], g[PC];
+#pragma unroll
+    for (int a = 0; a < PC; ++a) beta[a] = P.ch_bs[(int64_t)a * Vpad + v];
+    float H[NH];
+    pass32_pk<Q, true>(T, Vpad, v, P, Wf, beta, H, g, tr, 0, 1, hdl);
+    if constexpr (FIN != 0) {
+        bool go_slow = false;
+        if (on) finish_lane<Q, FIN == 1>(v, Vpad, V, P, [&](int a) { return H[a]; }, out, flags, firth_list, firth_count, go_slow);
+        list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
+        return;
+    }
+    if (!on) return;
+#pragma unroll
+    for (int a = 0; a < NH; ++a) P.ch_hf[(int64_t)a * Vpad + v] = H[a];
+}
+
+// DIRECT (GlmParams.ll_first): the score, log-likelihood and callback value on record were taken at ch_b0, one chord step in front of ch_bs (where
+// the information matrix was just evaluated): the result is the exact Newton step from ch_b0 with that matrix, beta = ch_b0 + H^-1 g (error
+// O(step^2), step <= 1e-4), its log-likelihood ll(ch_b0) + g . step / 2 (error O(N step^3)); the certificate is the distance of that beta from
+// the chord result (what the chord factor got wrong), <= 5e-7 as for the step of the plain form.
+template <int Q, bool DIRECT = false>
+__global__ __launch_bounds__(64) void k_glm_finish(int64_t Vpad, int64_t V, GlmParams P, GlmWork wk, const int *__restrict__ list,
+                                                   const int *__restrict__ cnt, double *__restrict__ out, uint32_t *__restrict__ flags,
+                                                   int *__restrict__ firth_list, int *__restrict__ firth_count)
+{
+    constexpr int PC = Q + 2, NH = PC * (PC + 1) / 2;
+    if ((int64_t)blockIdx.x * 64 >= *cnt) return;
+    int64_t v;
+    const bool on = round_lane(list, cnt, (int64_t)blockIdx.x * 64 + threadIdx.x, v);
+    bool go_slow = false;
+    if (on) finish_lane<Q, DIRECT>(v, Vpad, V, P, [&](int a) { return P.ch_hf[(int64_t)a * Vpad + v]; }, out, flags, firth_list, firth_count, go_slow);
     list_push(go_slow, wk.slow_list, wk.slow_count, (int)v);
 }
 
@@ -1763,15 +1780,20 @@ static hipError_t launch_glm(hipStream_t st, int which, const uint64_t *T, int64
                                    r == nc - 1 ? 1 : 0, first_ll);
             }
             if (P.fin_rounds && P.ll_first) {                        // the variants the first chord round finished: no further likelihood pass
-                if (P.wfp) hipLaunchKernelGGL(k_glm_dpass_pk<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[5], P.ch_cnt + 29);
-                else hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[5], P.ch_cnt + 29);
-                hipLaunchKernelGGL((k_glm_finish<Q, true>), grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[5], P.ch_cnt + 29, out, flags, flist, fcount);
+                // (with the pair table the finishing runs in the pass' own epilogue: k_glm_dpass_pk<Q, 1>)
+                if (P.wfp) hipLaunchKernelGGL((k_glm_dpass_pk<Q, 1>), grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[5], P.ch_cnt + 29, V, wk, out, flags, flist, fcount);
+                else {
+                    hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[5], P.ch_cnt + 29);
+                    hipLaunchKernelGGL((k_glm_finish<Q, true>), grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[5], P.ch_cnt + 29, out, flags, flist, fcount);
+                }
             }
             if (P.fin_rounds) {
                 hipLaunchKernelGGL(k_glm_ll<Q>, g256, b256, 0, st, T, Vpad, y, P, P.ch_list[4], P.ch_cnt + 30);
-                if (P.wfp) hipLaunchKernelGGL(k_glm_dpass_pk<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
-                else hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
-                hipLaunchKernelGGL((k_glm_finish<Q, false>), grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[4], P.ch_cnt + 30, out, flags, flist, fcount);
+                if (P.wfp) hipLaunchKernelGGL((k_glm_dpass_pk<Q, 2>), grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30, V, wk, out, flags, flist, fcount);
+                else {
+                    hipLaunchKernelGGL(k_glm_dpass<Q>, grid, blk, 0, st, T, Vpad, Wf, P, P.ch_list[4], P.ch_cnt + 30);
+                    hipLaunchKernelGGL((k_glm_finish<Q, false>), grid, blk, 0, st, Vpad, V, P, wk, P.ch_list[4], P.ch_cnt + 30, out, flags, flist, fcount);
+                }
             }
         } else hipLaunchKernelGGL((k_glm_fast<Q, false>), grid, blk, 0, st, T, Vpad, V, y, W, Wf, y1, y0, yc, P, wk, out, flags, flist, fcount);
     }
