@@ -760,7 +760,7 @@ __device__ __forceinline__ void solve32_lane(int64_t v, int64_t Vpad, const GlmP
         else if (stp <= P.chord_enter) {
             go_chord = true;
 #pragma unroll
-            for (int a = 0; a < NH; ++a) P.ch_fac[(int64_t)a * Vpad + v] = A[a];
+            for (int a = 0; a < NH; ++a) ((float *)P.ch_fac)[(int64_t)a * Vpad + v] = (float)A[a];     // (single precision: the factor of a single-precision Hessian; half the chord rounds' traffic)
             P.ch_rho[v] = (float)fmin(0.5, fmax(8.0 * stp, 1e-4));
         }
         else if (last_round) go_slow = true;
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_glm_chord(int64_t Vpad, GlmParams P, Gl
     if (on) {
         double A[NH], g[PC], beta[PC], bin[PC];
 #pragma unroll
-        for (int a = 0; a < NH; ++a) A[a] = P.ch_fac[(int64_t)a * Vpad + v];
+        for (int a = 0; a < NH; ++a) A[a] = (double)((const float *)P.ch_fac)[(int64_t)a * Vpad + v];
 #pragma unroll
         for (int a = 0; a < PC; ++a) { g[a] = P.ch_g[(int64_t)a * Vpad + v] / nobs; beta[a] = bin[a] = P.ch_bs[(int64_t)a * Vpad + v]; }
         ldl_solve<PC>(A, g);

@@ -40,7 +40,7 @@ struct GlmParams {
     double fast_tol;              // largest step (any coordinate) at which the fast phase hands over to the final pass' exact Newton step
     // The fast phase as rounds of lean kernels over lists (glm_kernels.hip, "the fast phase as ROUNDS"): single-precision Newton rounds until a
     // lane's step is <= chord_enter, then chord rounds (fp64 score, the last single-precision Hessian factor kept) until rho * step <= chord_tol.
-    // Workspaces are SoA over the batch's padded variant count: ch_bs / ch_g [PC][Vpad], ch_fac [PC(PC+1)/2][Vpad] (double), ch_hf the same
+    // Workspaces are SoA over the batch's padded variant count: ch_bs / ch_g [PC][Vpad], ch_fac [PC(PC+1)/2][Vpad] (floats in the first half of a double array: the LDL^T factor of the single-precision Hessian), ch_hf the same
     // shape in float, ch_md / ch_rho [Vpad]; ch_list: two ping-pong lists for the Newton rounds, two for the chord rounds; ch_cnt their counters.
     // ch_list[4] + ch_cnt[30]: the converged variants, for the finishing kernels (fin_rounds; k_glm_ll / k_glm_dpass / k_glm_finish).
     // bd_tab: nibble tables of (w0, w0 z, r0) at the null model (k_glm_bitdot -> ch_bd [Q+2][Vpad]); null_h = (sum w0, sum w0 z_j),
