@@ -52,3 +52,24 @@ def test_writes_outside_the_window_do_not_count(tmp_path):
     # the prologue's and the epilogue's uses of s3 in KERNEL (before the first touch, behind the closing wait) are not failures
     r = run(tmp_path, "edge", "\ts_nop 0")
     assert r.returncode == 0, r.stdout
+
+
+CSRC = os.path.join(ROOT, "pyseer_amd", "csrc")
+
+
+def test_the_library_is_linked_only_behind_the_check_of_its_own_assembly():
+    """The product's own device assembly, not a hand-made kernel: `make` keeps glm_kernels.gfx950.s (same compiler, same flags as
+    glm_kernels.o) and links ../libseerhip.so only once tools/check_touch_regs.py passed on it (Makefile: glm_kernels.touch_ok is a
+    prerequisite of the library).  Here the checker runs again on that file -- rebuilt first if a source is newer -- and must see every
+    instantiation that holds touches (Q = 1 .. 10 of the two packed passes and their fused-epilogue variants)."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "../libseerhip.so: $(OBJS) glm_kernels.touch_ok" in mk, "the touch check no longer gates the link"
+    r = subprocess.run(["make", "-C", CSRC, "glm_kernels.touch_ok"], capture_output=True, text=True)      # a no-op when up to date (~3 min otherwise)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    s = os.path.join(CSRC, "glm_kernels.gfx950.s")
+    assert os.path.getmtime(s) >= os.path.getmtime(os.path.join(CSRC, "glm_kernels.hip"))
+    r = subprocess.run([sys.executable, TOOL, s], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    n = int(r.stdout.split(" kernels with touches checked")[0].split()[-1])
+    assert n >= 40, "only %d kernels with touches found in the built assembly: the check lost sight of the passes" % n
+    assert "0 failures" in r.stdout
