@@ -343,7 +343,7 @@ def glm_metric(cfg, N):
     force = cfg == "C4"
     return ("k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
             "f64 (eta, likelihood, score, solves) + f16 hi/lo MFMA with fp32 accumulation (information matrix, third-moment tensor of the penalty); f32 for the first of the ~3 passes (its step is 1e-5 from the fit at best); f64 throughout for the fits the exact kernels take" if force
-            else "f64 (score, likelihood, final information matrix) + f32 Hessian in the first Newton phase")
+            else "f64 (eta, score, likelihood, the last Newton step, solves); the final information matrix = the null model's matrix and the carrier sums in exact f64 / int8 limbs + the DIFFERENCES w - w0 summed in f32 (f16 hi/lo MFMA products, fp32 accumulation; the variant's row per 64-sample word in f32, across words in f64); f32 / f16-MFMA Hessians in the Newton steering passes")
 
 
 def glm_workload(cfg, Vs, N, q):
@@ -365,7 +365,7 @@ def glm_lanes_line(eng, cfg, bits, q, Vs, rb, steps=15, warmup=None, check=None)
     lanes = eng.get_lanes()
     warmup = 2 * lanes if warmup is None else warmup
     nb = len(bits)
-    nres = min(max(2 * lanes + 1, nb), steps)                          # result buffers in flight at most: 2 x lanes
+    nres = max(steps, 1)                                               # every timed step its own result buffers (lanes complete out of order)
     outs = [torch.empty((5 + q, Vs), dtype=torch.float64, device=dev) for _ in range(nres)]
     fls = [torch.empty((Vs,), dtype=torch.int32, device=dev) for _ in range(nres)]
     for i in range(warmup):
@@ -758,7 +758,7 @@ def main():
         # threads with their own stream and workspaces inside the library, csrc/lanes_api.inc); the timed region submits exactly K of them
         # and completes them (sh_wait) before the closing synchronisation.  Every batch in flight has its own result buffers.
         lanes = eng.get_lanes()
-        nres = min(2 * lanes + 1, nbuf)
+        nres = nbuf                                              # (lanes complete out of order: a buffer is never handed out twice)
         outs = [torch.empty((nrow, Vs), dtype=torch.float64, device=dev) for _ in range(nres)]
         fls = [torch.empty((Vs,), dtype=torch.int32, device=dev) for _ in range(nres)]
         step = lambda i: eng.glm_batch_dev_async(bits[i % ndist], outs[i % nres], fls[i % nres])
@@ -848,7 +848,7 @@ def main():
                     "C2N5000": fixed_effects_line("C2N5000", dev, local, cpu=cpu, parity=not args.no_parity),
                     "C4": fixed_effects_line("C4", dev, local, cpu=cpu, parity=not args.no_parity),
                     "C4_literal": fixed_effects_line("C4", dev, local, cpu=False, parity=not args.no_parity, env={"SEERHIP_ROUTE": "firth_literal=1"}),
-                    "C2": fixed_effects_line("C2", dev, local, steps=3, cpu=False, parity=False),
+                    "C2": fixed_effects_line("C2", dev, local, steps=3, cpu=cpu, parity=not args.no_parity),
                     "C3_five_limbs": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=5),
                     "C3_all_refined_56bit": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=0, tol=1e-300),
                     "C3_host_pointers_pcie_inclusive": lmm_host_pointer_line(U, S, y, C, h2, dev, local, bits[0], 4),

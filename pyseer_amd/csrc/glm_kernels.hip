@@ -160,6 +160,43 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // division (~12 instructions).  exp2 overflows to inf -> mu = 0, underflows to 0 -> mu = 1: the right limits.
 __device__ __forceinline__ float sigmoid_fast(float eta) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(eta * -1.4426950408889634f)); }
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// The final information matrix is the exact null-model matrix + sums of the DIFFERENCES w - w0 taken in single precision (the DELTA passes).
+// Two things put 1e-7 .. 3e-7 on bse where the variant's effect is strong (|beta_k| >= 2: tools/gpu_bse_probe.py, profiles/r06/bse_probe_before.txt;
+// 1e-8 elsewhere) and are taken out here (round 6):
+//  (a) beta rounded to float: the error of the intercept and of the variant's coefficient (2^-25 |beta|: 1.2e-7 at |beta| = 4) is the SAME for
+//      every carrier -- a shift of eta that does not average out over the samples as a sample's own rounding does.  The two constants of eta,
+//      c(k) = beta_0 + k beta_k, are split hi + lo against the value the loop's own fma produces (c0h + k dh), and the lo parts (lo0 + k dl)
+//      start the covariates' chain.  (The covariates' coefficients stay rounded: their part is 4e-9 on bse.)
+//  (b) w = mu - mu^2 cancels for mu -> 1 (the carriers of a strong positive effect: 1 - mu = 0.02 from a float mu is 3e-6 relative).  w is even
+//      in eta: t = exp(-|eta|) <= 1 cannot overflow, and w = a - a^2 with a = t / (1 + t) = min(mu, 1 - mu) is relatively exact on both sides.
+//  (c) the variant's own row (sum over the CARRIERS of d, d z_j) is accumulated in single precision within a 64-sample word and in double
+//      precision across words.  Where the carriers' eta has moved far from the null model's (beta_0 + beta_k - b0(null) = +3.5: w0 = 0.22,
+//      w = 0.05) the word's partial sums of d = w - w0 are 3..4 times those of w, and H_11 = base - |sum d| then cancels: 1e-7 on bse.
+//      Where |beta_0 + beta_k - b0(null)| >= GLM_DIRECT_ROW the row sums w ITSELF (no base from the carrier sums: finish_lane); below it
+//      the differences are the smaller terms and stay -- a variant carried by nearly everyone has a large beta_k but carriers whose eta
+//      hardly moved, and its Schur complement cancels against the intercept: there only the differences are accurate enough (measured:
+//      direct sums chosen by |beta_k| alone put 4e-6 on bse at allele frequency 0.985).  (Emulated in numpy before it was built:
+//      differences max 7e-8 / direct 1.5e-8 on 150 strong rows.)
+#define GLM_DIRECT_ROW 1.5
+struct EtaConst { float c0h, dh, lo0, dl; };
+__device__ __forceinline__ EtaConst eta_const(double b0, double b1)
+{
+    EtaConst c;
+    const double c1 = b0 + b1;
+    c.c0h = (float)b0;
+    c.dh = (float)(c1 - (double)c.c0h);
+    const float c1h = __builtin_fmaf(1.0f, c.dh, c.c0h);          // what pkfma(k = 1, dh, c0h) gives a carrier
+    c.lo0 = (float)(b0 - (double)c.c0h);
+    c.dl = (float)(c1 - (double)c1h) - c.lo0;
+    return c;
+}
+__device__ __forceinline__ float weight_even(float eta)
+{
+    const float t = __builtin_amdgcn_exp2f(__builtin_fabsf(eta) * -1.4426950408889634f);
+    const float m = __builtin_amdgcn_rcpf(1.0f + t);
+    const float a = t * m;                                            // = min(mu, 1 - mu) <= 1/2: a - a^2 does not cancel, and is as insensitive to the
+    return __builtin_fmaf(-a, a, a);                                  // error of the reciprocal near mu = 1/2 as mu - mu^2 is (most samples)
+}
 template <int Q, bool DELTA>
 __device__ __forceinline__ void pass32_pk_f32(const uint64_t *__restrict__ T, int64_t Vpad, int64_t v, const GlmParams &P, const float *__restrict__ Wf,
                                           const double (&beta)[Q + 2], float (&H)[(Q + 2) * (Q + 3) / 2], double (&g)[Q + 2], float *tr,
@@ -189,17 +226,20 @@ __device__ __forceinline__ void pass32_pk_f32(const uint64_t *__restrict__ T, in
     v2f bf[PC], gf[PC], h00 = {0.0f, 0.0f}, h10 = {0.0f, 0.0f}, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { const float b = (float)beta[a]; bf[a] = v2f{b, b}; gf[a] = v2f{0.0f, 0.0f}; }
+    const EtaConst ec = eta_const(beta[0], beta[1]);                        // (DELTA only: the constants of eta with their lo parts)
+    const float vsub = fabs(beta[0] + beta[1] - P.warm[0]) >= GLM_DIRECT_ROW ? 0.0f : -1.0f;      // (DELTA only: the variant's row sums w - w0, or w itself)
 #pragma unroll
     for (int j = 0; j < Q; ++j) { hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f}; }
     const int nfull = N >> 1;
     auto pair = [&](const v2f (&rec)[RS], const float (&bz)[NCB], uint32_t two) {
         const v2f xb = {(float)(two & 1u), (float)(two >> 1)};
-        v2f eta = pkfma(xb, bf[1], bf[0]);
+        v2f eta = DELTA ? pkfma(xb, v2f{ec.dl, ec.dl}, v2f{ec.lo0, ec.lo0}) : pkfma(xb, bf[1], bf[0]);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = pkfma(bf[2 + j], rec[j], eta);
-        v2f mu;
-        mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y);
-        const v2f wf = pkfma(-mu, mu, mu);
+        if (DELTA) eta = eta + pkfma(xb, v2f{ec.dh, ec.dh}, v2f{ec.c0h, ec.c0h});
+        v2f mu, wf;
+        if (DELTA) { wf.x = weight_even(eta.x); wf.y = weight_even(eta.y); }
+        else { mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y); wf = pkfma(-mu, mu, mu); }
         v2f d = wf;
         if (DELTA) d = wf - rec[Q + 1];
         else {
@@ -208,7 +248,7 @@ __device__ __forceinline__ void pass32_pk_f32(const uint64_t *__restrict__ T, in
 #pragma unroll
             for (int j = 0; j < Q; ++j) gf[2 + j] = pkfma(r, rec[j], gf[2 + j]);
         }
-        const v2f dx = xb * d;
+        const v2f dx = xb * (DELTA ? pkfma(v2f{vsub, vsub}, rec[Q + 1], wf) : d);
         h00 += d; h10 += dx;
 #pragma unroll
         for (int j = 0; j < Q; ++j) { hz0[j] = pkfma(d, rec[j], hz0[j]); hz1[j] = pkfma(dx, rec[j], hz1[j]); }
@@ -279,11 +319,12 @@ __device__ __forceinline__ void pass32_pk_f32(const uint64_t *__restrict__ T, in
         const int i = N - 1;
         const float *zrow = ZZ + (int64_t)i * STRIDE + l31;
         const bool xb = (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull;
-        float eta = bf[0].x + (xb ? bf[1].x : 0.0f);
+        float eta = DELTA ? ec.lo0 + (xb ? ec.dl : 0.0f) : bf[0].x + (xb ? bf[1].x : 0.0f);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j].x, Wf[(int64_t)i * Q + j], eta);
+        if (DELTA) eta += fmaf(xb ? 1.0f : 0.0f, ec.dh, ec.c0h);
         const float mu = sigmoid_fast(eta);
-        const float wf = mu * (1.0f - mu);
+        const float wf = DELTA ? weight_even(eta) : mu * (1.0f - mu);
         float d = wf;
         if (DELTA) d = wf - P.w0f[i];
         else {
@@ -292,7 +333,7 @@ __device__ __forceinline__ void pass32_pk_f32(const uint64_t *__restrict__ T, in
 #pragma unroll
             for (int j = 0; j < Q; ++j) gs[2 + j] = fmaf(r, Wf[(int64_t)i * Q + j], gs[2 + j]);
         }
-        const float dx = xb ? d : 0.0f;
+        const float dx = xb ? (DELTA ? fmaf(vsub, P.w0f[i], wf) : d) : 0.0f;
         h00s += d; h10s += dx;
 #pragma unroll
         for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0s[j] = fmaf(d, zj, hz0s[j]); hz1s[j] = fmaf(dx, zj, hz1s[j]); }
@@ -425,6 +466,8 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     v2f bf[PC], gf[PC], h00 = {0.0f, 0.0f}, h10 = {0.0f, 0.0f}, hz0[Q > 0 ? Q : 1], hz1[Q > 0 ? Q : 1];
 #pragma unroll
     for (int a = 0; a < PC; ++a) { const float b = (float)beta[a]; bf[a] = v2f{b, b}; gf[a] = v2f{0.0f, 0.0f}; }
+    const EtaConst ec = eta_const(beta[0], beta[1]);                        // (DELTA only: the constants of eta with their lo parts)
+    const float vsub = fabs(beta[0] + beta[1] - P.warm[0]) >= GLM_DIRECT_ROW ? 0.0f : -1.0f;      // (DELTA only: the variant's row sums w - w0, or w itself)
 #pragma unroll
     for (int j = 0; j < Q; ++j) { hz0[j] = v2f{0.0f, 0.0f}; hz1[j] = v2f{0.0f, 0.0f}; }
     const int nfull = N >> 1;
@@ -440,12 +483,14 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     };
     auto pair = [&](const v2f (&rec)[RS], int slot, uint32_t two) {
         const v2f xb = {(float)(two & 1u), (float)(two >> 1)};
-        v2f eta = pkfma(xb, bf[1], bf[0]);
+        v2f eta = DELTA ? pkfma(xb, v2f{ec.dl, ec.dl}, v2f{ec.lo0, ec.lo0}) : pkfma(xb, bf[1], bf[0]);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = pkfma(bf[2 + j], rec[j], eta);
-        v2f mu;
-        if (ABL & 4) mu = pkfma(eta, v2f{0.25f, 0.25f}, v2f{0.5f, 0.5f}); else { mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y); }
-        const v2f wf = pkfma(-mu, mu, mu);
+        if (DELTA) eta = eta + pkfma(xb, v2f{ec.dh, ec.dh}, v2f{ec.c0h, ec.c0h});
+        v2f mu, wf;
+        if (ABL & 4) { mu = pkfma(eta, v2f{0.25f, 0.25f}, v2f{0.5f, 0.5f}); wf = pkfma(-mu, mu, mu); }
+        else if (DELTA) { wf.x = weight_even(eta.x); wf.y = weight_even(eta.y); }
+        else { mu.x = sigmoid_fast(eta.x); mu.y = sigmoid_fast(eta.y); wf = pkfma(-mu, mu, mu); }
         v2f d = wf;
         if (DELTA) d = wf - rec[Q + 1];
         else if (ABL & 8) { gf[0] += rec[Q] - mu; }
@@ -455,7 +500,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
 #pragma unroll
             for (int j = 0; j < Q; ++j) gf[2 + j] = pkfma(r, rec[j], gf[2 + j]);
         }
-        const v2f dx = xb * d;
+        const v2f dx = xb * (DELTA ? pkfma(v2f{vsub, vsub}, rec[Q + 1], wf) : d);
         h00 += d;
         if constexpr (LIN) Xh[slot] = __builtin_bit_cast(uint32_t, __builtin_convertvector(dx, v2h));
         else h10 += dx;
@@ -572,11 +617,12 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
     if ((N & 1) && tail) {
         const int i = N - 1;
         odd_x = (T[(int64_t)(i >> 6) * Vpad + v] >> (i & 63)) & 1ull;
-        float eta = bf[0].x + (odd_x ? bf[1].x : 0.0f);
+        float eta = DELTA ? ec.lo0 + (odd_x ? ec.dl : 0.0f) : bf[0].x + (odd_x ? bf[1].x : 0.0f);
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j].x, Wf[(int64_t)i * Q + j], eta);
+        if (DELTA) eta += fmaf(odd_x ? 1.0f : 0.0f, ec.dh, ec.c0h);
         const float mu = sigmoid_fast(eta);
-        const float wf = mu * (1.0f - mu);
+        const float wf = DELTA ? weight_even(eta) : mu * (1.0f - mu);
         odd_d = DELTA ? wf - P.w0f[i] : wf;
         if (!DELTA) {
             const float r = P.yf[i] - mu;
@@ -584,7 +630,7 @@ __device__ __forceinline__ void pass32_pk_f16(const uint64_t *__restrict__ T, in
 #pragma unroll
             for (int j = 0; j < Q; ++j) gf[2 + j].x = fmaf(r, Wf[(int64_t)i * Q + j], gf[2 + j].x);
         }
-        const float dx = odd_x ? odd_d : 0.0f;
+        const float dx = odd_x ? (DELTA ? fmaf(vsub, P.w0f[i], wf) : odd_d) : 0.0f;
         h00.x += odd_d; if constexpr (!LIN) h10.x += dx;
 #pragma unroll
         for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; if (j >= NZ0) hz0[j].x = fmaf(odd_d, zj, hz0[j].x); if constexpr (!LIN) hz1[j].x = fmaf(dx, zj, hz1[j].x); }
@@ -1536,6 +1582,8 @@ __global__ __launch_bounds__(64, 3) void k_glm_dpass(const uint64_t *__restrict_
     float bf[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) bf[a] = (float)P.ch_bs[(int64_t)a * Vpad + v];
+    const EtaConst ec = eta_const(P.ch_bs[v], P.ch_bs[Vpad + v]);
+    const float vsub = fabs(P.ch_bs[v] + P.ch_bs[Vpad + v] - P.warm[0]) >= GLM_DIRECT_ROW ? 0.0f : -1.0f;
     v16f acc[NCB][2];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -1547,12 +1595,12 @@ __global__ __launch_bounds__(64, 3) void k_glm_dpass(const uint64_t *__restrict_
 #pragma unroll
     for (int j = 0; j < Q; ++j) { hz0[j] = 0.0f; hz1[j] = 0.0f; }
     auto sample = [&](int i, bool xb) -> float {
-        float eta = bf[0] + (xb ? bf[1] : 0.0f);
+        float eta = ec.lo0 + (xb ? ec.dl : 0.0f);                            // (eta_const / weight_even: as the packed pass)
 #pragma unroll
         for (int j = 0; j < Q; ++j) eta = fmaf(bf[2 + j], Wf[(int64_t)i * Q + j], eta);
-        const float mu = 1.0f / (1.0f + __expf(-eta));
-        const float d = mu * (1.0f - mu) - (float)w0[i];
-        const float dx = xb ? d : 0.0f;
+        eta += fmaf(xb ? 1.0f : 0.0f, ec.dh, ec.c0h);
+        const float wf = weight_even(eta), d = wf - (float)w0[i];
+        const float dx = xb ? fmaf(vsub, (float)w0[i], wf) : 0.0f;
         h00 += d; h10 += dx;
 #pragma unroll
         for (int j = 0; j < Q; ++j) { const float zj = Wf[(int64_t)i * Q + j]; hz0[j] = fmaf(d, zj, hz0[j]); hz1[j] = fmaf(dx, zj, hz1[j]); }
@@ -1631,10 +1679,13 @@ __device__ __forceinline__ void finish_lane(int64_t v, int64_t Vpad, int64_t V, 
         if (P.ch_md[v] <= 1e-8) status = 1;                                                       // callback after the last update
         else {
             double H[NH], g[PC];
-            H[sidx(0, 0)] = P.null_h[0]; H[sidx(1, 0)] = H[sidx(1, 1)] = P.ch_bd[v];
+            // (the variant's row: the carrier sums at the null model + the pass' differences -- or, for a strong effect, the pass' sums of w
+            // itself: GLM_DIRECT_ROW, decided from the same beta the pass read)
+            const bool direct = fabs(beta[0] + beta[1] - P.warm[0]) >= GLM_DIRECT_ROW;
+            H[sidx(0, 0)] = P.null_h[0]; H[sidx(1, 0)] = H[sidx(1, 1)] = direct ? 0.0 : P.ch_bd[v];
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
-                H[sidx(2 + j, 0)] = P.null_h[1 + j]; H[sidx(2 + j, 1)] = P.ch_bd[(int64_t)(1 + j) * Vpad + v];
+                H[sidx(2 + j, 0)] = P.null_h[1 + j]; H[sidx(2 + j, 1)] = direct ? 0.0 : P.ch_bd[(int64_t)(1 + j) * Vpad + v];
 #pragma unroll
                 for (int k = 0; k <= j; ++k) H[sidx(2 + j, 2 + k)] = P.a0[j * (j + 1) / 2 + k];
             }

@@ -147,11 +147,21 @@ def test_c4_forced_firth_bench_inputs_vs_oracle():
 
 def test_c2n5000_logistic_bench_inputs_vs_oracle():
     """The logistic half at N = 5000, q = 10 on the bench's own rows (incl. its 2 % rare variants, which route to Firth)."""
+    _logistic_bench_inputs(5000, 256, "C2N5000")
+
+
+def test_c2_logistic_bench_inputs_vs_oracle():
+    """BASELINE's configs[1] (C2: 1M 31-mers x 1000 samples, logistic, 10 MDS covariates) on the bench's own N = 1000 rows: the rows
+    `bench.py`'s C2 line times (fixed_effects_line("C2"): synth_glm_inputs(1000, 10), synth_bits(.., 4242 + i)), 2048 of them."""
+    _logistic_bench_inputs(1000, 2048, "C2")
+
+
+def _logistic_bench_inputs(N, V, name):
     import torch
     import bench
     from oracle import oracle as orc
     from pyseer_amd.engine import Engine, row_bytes_for
-    N, q, V = 5000, 10, 256
+    q = 10
     y, W, nl, nf = bench.synth_glm_inputs(N, q)
     bits = bench.synth_bits(V, N, row_bytes_for(N), 4242, torch.device("cuda", 0)).cpu().numpy()
     Kv = bench.unpack_rows(bits, N)
@@ -174,7 +184,7 @@ def test_c2n5000_logistic_bench_inputs_vs_oracle():
         good, nt = firth_rows_close(g, ws, f, firth)                # Firth-routed rows: 1e-6 relative, slack only where the tie detector fires
         needed += nt
         assert good.all(), (f, np.argwhere(~good)[:4].tolist())
-    print("C2N5000 inputs: %d Firth-routed rows, %d statistic values needed the tie detector" % (int(firth.sum()), needed))
+    print("%s inputs: %d rows, %d Firth-routed, %d statistic values needed the tie detector" % (name, int(keep.sum()), int(firth.sum()), needed))
     assert ((r["flags"][keep] & 0x1FF) == w["notes"]).all()
     assert (r["flags"][~keep] & 1).all()                           # af-filter note outside the window
 
