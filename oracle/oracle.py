@@ -148,6 +148,19 @@ def fit_firth(X, y, start, step_limit=1000, convergence_limit=1e-4):
     return beta, b1.value, fl.value
 
 
+def fit_firth_traced(X, y, start, step_limit=1000, convergence_limit=1e-4):
+    """fit_firth + what its step halvings saw (test-only): (result or None, dict(halvings, min_rise, max_rise, step_at_min_rise, iterations));
+    min_rise = the smallest rise above 1e-12 |F| -- i.e. above F's rounding noise -- that caused a halving (inf: none)."""
+    X = _d(X); y = _d(y); start = _d(start)
+    n, pc = X.shape
+    beta = np.zeros(pc); b1 = C.c_double(); fl = C.c_double(); tr = np.zeros(5)
+    f = lib().orc_fit_firth_traced
+    f.restype = C.c_int
+    st = f(_p(X), _p(y), n, pc, _p(start), int(step_limit), C.c_double(convergence_limit), _p(beta), C.byref(b1), C.byref(fl), _p(tr))
+    t = dict(halvings=int(tr[0]), min_rise=float(tr[1]), max_rise=float(tr[2]), step_at_min_rise=float(tr[3]), iterations=int(tr[4]))
+    return (None if st else (beta, b1.value, fl.value)), t
+
+
 def ols(X, y):
     X = _d(X); y = _d(y)
     n, pc = X.shape

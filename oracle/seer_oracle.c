@@ -439,9 +439,28 @@ static int firth_tiny_step(const double *nb, const double *cur, int pc)
     return m < g_firth_accept;
 }
 
+/* trace (test-only, may be NULL): [0] halvings taken, [1] the smallest rise F(new) - F(old) > 1e-12 |F| that caused one (INFINITY: none), [2] the
+ * largest rise, [3] the step's norm at [1], [4] iterations: lets the fixture search (tests/golden/make_subtau_golden.py) find fits on which the
+ * reference halves a step for a rise that is real (above the rounding noise of F) yet small. */
+static int fit_firth_impl(const double *X, const double *y, int n, int pc, const double *start,
+                          int step_limit, double convergence_limit,
+                          double *beta_out, double *bse1, double *fitll, double *trace);
 ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const double *start,
                           int step_limit, double convergence_limit,
                           double *beta_out, double *bse1, double *fitll)
+{
+    return fit_firth_impl(X, y, n, pc, start, step_limit, convergence_limit, beta_out, bse1, fitll, NULL);
+}
+ORC_API int orc_fit_firth_traced(const double *X, const double *y, int n, int pc, const double *start,
+                                 int step_limit, double convergence_limit,
+                                 double *beta_out, double *bse1, double *fitll, double *trace)
+{
+    trace[0] = 0; trace[1] = INFINITY; trace[2] = 0; trace[3] = 0; trace[4] = 0;
+    return fit_firth_impl(X, y, n, pc, start, step_limit, convergence_limit, beta_out, bse1, fitll, trace);
+}
+static int fit_firth_impl(const double *X, const double *y, int n, int pc, const double *start,
+                          int step_limit, double convergence_limit,
+                          double *beta_out, double *bse1, double *fitll, double *trace)
 {
     double I[64 * 64], V[64 * 64], sc[64], U[64];
     double *cur = (double *)malloc(sizeof(double) * pc), *prev = (double *)malloc(sizeof(double) * pc),
@@ -468,7 +487,15 @@ ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const
         /* step halving, model.py:465-474 (NaN comparison is False -> accept) */
         int j = 0;
         double fcur = firth_like(X, y, n, pc, cur);
-        while (!firth_tiny_step(nb, cur, pc) && firth_like(X, y, n, pc, nb) > fcur + (j == 0 ? g_firth_tie * fabs(fcur) : 0.0)) {
+        double fnew = 0;
+        while (!firth_tiny_step(nb, cur, pc) && (fnew = firth_like(X, y, n, pc, nb)) > fcur + (j == 0 ? g_firth_tie * fabs(fcur) : 0.0)) {
+            if (trace) {
+                double rise = fnew - fcur, sn = 0;
+                for (int a = 0; a < pc; a++) sn += (nb[a] - cur[a]) * (nb[a] - cur[a]);
+                trace[0] += 1;
+                if (rise > 1e-12 * fabs(fcur) && rise < trace[1]) { trace[1] = rise; trace[3] = sqrt(sn); }
+                if (rise > trace[2]) trace[2] = rise;
+            }
             for (int a = 0; a < pc; a++) nb[a] = cur[a] + 0.5 * (nb[a] - cur[a]);
             j++;
             if (j > step_limit) { free(cur); free(prev); free(nb); free(pi); return 1; }
@@ -477,6 +504,7 @@ ORC_API int orc_fit_firth(const double *X, const double *y, int n, int pc, const
         double nrm = 0;
         if (i > 0) { for (int a = 0; a < pc; a++) { double d = cur[a] - prev[a]; nrm += d * d; } nrm = sqrt(nrm); last_step_norm = nrm; }
         for (int a = 0; a < pc; a++) { prev[a] = cur[a]; cur[a] = nb[a]; }
+        if (trace) trace[4] = i + 1;
         if (i > 0 && nrm < convergence_limit) { ok = 1; break; }
     }
     /* after the loop model.py:482-484 re-tests ||beta_iterations[i]-beta_iterations[i-1]|| with the final i;

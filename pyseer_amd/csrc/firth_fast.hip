@@ -18,7 +18,7 @@
 // What stays exact: the iteration is the reference's own (same start vector as the rounds: k_firth_init2; same accepted steps; same stop
 // rule: one step after a step below 1e-4).  Every fit is FINISHED by the exact kernels: the candidate that meets the stop rule goes to
 // k_firth_eval2, which evaluates F and I11 there in fp64 and writes the outputs.  A fit that is not an ordinary one -- F rises by more than
-// FF_TAU (a real step halving), a pivot of I fails, FF_MAXIT passes -- leaves for the exact rounds at its last accepted beta.
+// FF_TAU (a rise of F above its evaluation noise), a pivot of I fails, FF_MAXIT passes -- leaves for the exact rounds at its last accepted beta.
 //
 // Layout: a wavefront owns 32 variants; lane (n = lane & 31, h = lane >> 5) takes samples 16 g + 8 h + j (j = 0..7) of every 16-sample group g of
 // variant n: exactly the B operand of the MFMA (column n, k = 8 h + j), so a lane's eight weights go to the matrix core as they are.  The A
