@@ -288,6 +288,7 @@ static void produce_gzip_parallel(sh_reader *r)
     std::atomic<bool> give_up{false};                                 // the searched heads keep being wrong (stored / fixed blocks, an alphabet the text test does not know):
                                                                       // the searching threads stop searching and the producer decodes alone, as produce_gzip does
     int64_t ns_await = 0, ns_redo = 0, ns_trans = 0, ns_put = 0;
+    uint32_t vhist = 0; int nhist = 0, serial_since = 0;               // (the producer's own: verdicts of the last regions, 1 = decoded again)
     auto now_ns = [] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const int64_t t_begin = now_ns();
     std::vector<std::thread> workers;
@@ -384,10 +385,18 @@ static void produce_gzip_parallel(sh_reader *r)
         ParChunk *c = &t->c;
         const int64_t ta1 = dbg ? now_ns() : 0;
         ns_await += ta1 - ta0;
-        if (c->ok && c->start_bit == pos_bit) { ++r->par_accepted; ++n_acc; }
+        // the verdicts of the last 16 regions decide whether searching is worth its threads (a sliding window: an atypical head of the file
+        // must not turn the search off for the rest of it -- ADVICE r05); turned off, it is tried again after 32 regions decoded alone
+        const bool accepted = c->ok && c->start_bit == pos_bit;
+        if (give_up.load(std::memory_order_relaxed)) {
+            if (++serial_since >= 32) { give_up.store(false); vhist = 0; nhist = 0; serial_since = 0; }
+        } else {
+            vhist = ((vhist << 1) | (accepted ? 0u : 1u)) & 0xFFFFu; nhist = std::min(nhist + 1, 16);
+            if (nhist >= 8 && __builtin_popcount(vhist & ((1u << nhist) - 1u)) * 4 > nhist * 3) { give_up.store(true); serial_since = 0; }
+        }
+        if (accepted) { ++r->par_accepted; ++n_acc; }
         else {
             ++n_redo;
-            if (n_redo.load() + n_acc.load() >= 8 && n_redo.load() * 4 > (n_redo.load() + n_acc.load()) * 3) give_up.store(true);
             redo.start_bit = pos_bit; redo.stop_bit = t->to_bit;
             if (redo.sym.size() < PAR_WIN + 65536) redo.sym.resize(PAR_WIN + 65536);
             for (uint32_t k = 0; k < PAR_WIN; ++k) redo.sym[k] = (uint16_t)(0x8000u | k);

@@ -298,22 +298,37 @@ class Job(object):
         self._held.append((bits, counts, nb, name_off, keep))
         rc = self._lib.sh_job_submit(self._h, bits.ctypes.data, rb, V, counts.ctypes.data, nb.ctypes.data, name_off.ctypes.data, int(bool(rows_are_dma)))
         if rc:
-            self._held.pop()
+            # (the failure may come from the PREVIOUS block's compute, after this block's upload was queued: the library's own count of blocks in
+            # flight decides whether this block's buffers are still referred to; anything dropped from the list here stays alive until close())
+            self._resync()
             _abi.check(rc)
 
     def collect(self):
         """-> (memoryview of the oldest block's text, valid until this thread's next collect; (pre-filtered, tested, printed), its keep object)"""
-        _abi.check(self._lib.sh_job_collect(self._h, C.byref(self._text), C.byref(self._n), self._cnt))
+        rc = self._lib.sh_job_collect(self._h, C.byref(self._text), C.byref(self._n), self._cnt)
+        if rc:
+            self._resync()
+            _abi.check(rc)
         held = self._held.pop(0)
         n = self._n.value
         text = (C.c_char * n).from_address(self._text.value) if n else b""
         return memoryview(text), (self._cnt[0], self._cnt[1], self._cnt[2]), held[4]
+
+    def _resync(self):
+        """After an error: pending() follows sh_job_pending (the C side's submitted - collected); blocks it no longer counts move to a list
+        that is only dropped at close(), behind the drain of the copy stream (an upload in flight may still read them)."""
+        n = int(self._lib.sh_job_pending(self._h))
+        if 0 <= n < len(self._held):
+            drop = len(self._held) - n
+            self._zombies = getattr(self, "_zombies", []) + self._held[:drop]
+            self._held = self._held[drop:]
 
     def close(self):
         if getattr(self, "_h", None):
             self._lib.sh_job_close(self._h)
             self._h = None
             self._held = []
+            self._zombies = []
 
     def __del__(self):
         try:

@@ -666,14 +666,27 @@ class _DmaWindows(object):
     # hipHostUnregister waits for the device to drain AND holds new work back while it does: every call is a hole in the device's timeline
     # (16 windows of a 24 M-row fixed-effects job: 155 of 820 ms idle).  So finished windows stay registered (their pages pinned) until the
     # stream ends, or until more than KEEP bytes of them have piled up -- a quarter of the machine's memory, at most 64 GB per stream.
+    # KEEP is the PROCESS's budget: a `--gpus G` job runs G streams, each with its own windows, and G x a quarter of the memory would be
+    # twice the machine at G = 8: a stream's share is KEEP / (streams alive).
     try:
         KEEP = min(64 << 30, os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") // 4)
     except (ValueError, OSError, AttributeError):
         KEEP = 8 << 30
+    PAGE = 4096                        # sh_host_register rounds a window out to whole pages
+    _live = 0                          # streams with windows, process-wide
+    _live_lock = None
+
+    def _keep(self):
+        return self.KEEP // max(1, _DmaWindows._live)
 
     def __init__(self, device):
         import threading
         from . import _abi
+        if _DmaWindows._live_lock is None:
+            _DmaWindows._live_lock = threading.Lock()
+        with _DmaWindows._live_lock:
+            _DmaWindows._live += 1
+        self._counted = True
         self._lib = _abi.load()
         self._device = int(device)
         self._lock = threading.Lock()
@@ -686,8 +699,14 @@ class _DmaWindows(object):
         self._stop = False
 
     def plan(self, base_addr, extents, lo_blk, hi_blk):
-        j = lo_blk
+        # Windows are registered rounded out to whole pages and must not overlap (registering a page twice fails): where less than a page
+        # of metadata lies between two stored blocks (small blocks), the block that starts on the previous window's last page belongs to no
+        # window -- its rows are staged -- and the next window starts at the first block on a page of its own.
+        j, prev_end = lo_blk, 0
         while j < hi_blk:
+            if ((base_addr + extents[j][0]) & ~(self.PAGE - 1)) < prev_end:
+                j += 1
+                continue
             k, lo = j, base_addr + extents[j][0]
             hi = lo + extents[j][1]
             while k + 1 < hi_blk and base_addr + extents[k + 1][0] + extents[k + 1][1] - lo <= self.WINDOW:
@@ -696,6 +715,7 @@ class _DmaWindows(object):
             w = {"lo": lo, "n": hi - lo, "blocks": k - j + 1, "taken": 0, "released": 0, "state": 0}     # state 0 new, 1 registered, -1 refused
             for b in range(j, k + 1):
                 self._win_of[b] = w
+            prev_end = (hi + self.PAGE - 1) & ~(self.PAGE - 1)
             j = k + 1
 
     def _unregister_done(self):
@@ -715,14 +735,14 @@ class _DmaWindows(object):
                 if self._reader_done or self._stop:
                     todo, self._done = self._done, []
                 else:
-                    while self._done and sum(w["n"] for w in self._done) > self.KEEP:
+                    while self._done and sum(w["n"] for w in self._done) > self._keep():
                         todo.append(self._done.pop(0))
             for w in todo:
                 self._lib.sh_host_unregister(w["lo"])
 
     def _due(self):
         """(lock held) is there a window to unregister NOW: the stream has ended, or too many finished windows are still pinned"""
-        return bool(self._done) and (self._reader_done or sum(w["n"] for w in self._done) > self.KEEP)
+        return bool(self._done) and (self._reader_done or sum(w["n"] for w in self._done) > self._keep())
 
     def _kick(self):
         """(lock held) a window is ready to be unregistered: wake the janitor, starting it at the first need"""
@@ -740,10 +760,9 @@ class _DmaWindows(object):
         if w["state"] == 0:
             if self._lib.sh_host_register(w["lo"], w["n"], self._device) != 0:
                 w["state"] = -1
-                self.ok = False        # (a file system whose pages cannot be pinned: the rows are staged through pinned memory from here on)
-                if _route.debug("cli"):
-                    sys.stderr.write("[cli timing] the packed-cache mapping cannot be registered for DMA (%s): rows are staged through pinned memory\n"
-                                     % self._lib.sh_last_error().decode())
+                self.ok = False        # (a file system whose pages cannot be pinned, or the pinning limit: the rows are staged through pinned memory from here on)
+                sys.stderr.write("pyseer_amd: the packed-cache mapping cannot be registered for DMA (%s): this stream's rows are staged through pinned "
+                                 "memory from here on (slower on the host, same results)\n" % self._lib.sh_last_error().decode())
                 return False, None
             w["state"] = 1
         if w["state"] != 1:
@@ -760,6 +779,10 @@ class _DmaWindows(object):
         return True, release
 
     def reader_done(self):
+        if self._counted:                                              # (this stream pins nothing new from here on: its share goes back)
+            self._counted = False
+            with _DmaWindows._live_lock:
+                _DmaWindows._live -= 1
         with self._lock:
             self._reader_done = True
             for w in {id(x): x for x in self._win_of.values()}.values():

@@ -555,3 +555,23 @@ def test_an_unknown_route_key_is_refused(tmp_path, monkeypatch):
         NativeKmerReader(str(p), ["s0", "s1"])
     monkeypatch.setenv("SEERHIP_ROUTE", "reader_slab=70000,reader_pad=32768")
     r = NativeKmerReader(str(p), ["s0", "s1"]); r.close()
+
+
+def test_dma_windows_are_page_disjoint_and_share_one_pinning_budget(monkeypatch):
+    """pyseer_amd/input.py _DmaWindows: windows of the packed-cache mapping are registered rounded out to pages, so two of them
+    must never share one (a block that starts on the previous window's last page is staged instead); and the bytes of finished windows
+    that stay pinned are ONE budget for the process: with G streams alive each keeps KEEP / G."""
+    from pyseer_amd import input as I
+    monkeypatch.setattr(I._DmaWindows, "WINDOW", 6000)
+    w = I._DmaWindows.__new__(I._DmaWindows); w._win_of = {}
+    ext = [(100, 5000), (5200, 300), (5600, 9000), (14700, 100), (20000, 4000)]          # (offset of the rows, bytes) of five stored blocks
+    w.plan(0x10000, ext, 0, 5)
+    wins = sorted({id(x): x for x in w._win_of.values()}.values(), key=lambda x: x["lo"])
+    assert [(x["lo"] - 0x10000, x["n"], x["blocks"]) for x in wins] == [(100, 5400, 2), (14700, 100, 1), (20000, 4000, 1)]
+    assert sorted(w._win_of) == [0, 1, 3, 4]                                             # block 2 starts on window 0's last page: staged
+    pages = [(x["lo"] & ~4095, (x["lo"] + x["n"] + 4095) & ~4095) for x in wins]
+    assert all(a[1] <= b[0] for a, b in zip(pages, pages[1:]))
+    monkeypatch.setattr(I._DmaWindows, "_live", 8)
+    assert w._keep() == I._DmaWindows.KEEP // 8
+    monkeypatch.setattr(I._DmaWindows, "_live", 0)
+    assert w._keep() == I._DmaWindows.KEEP
