@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SH_ABI_VERSION 1
+#define SH_ABI_VERSION 2
 
 #define SH_OK          0
 #define SH_EINVAL     -1   /* bad argument / call order */
@@ -273,7 +273,12 @@ int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t
  *   rows_are_dma != 0: `bits` lies in pinned or registered host memory (sh_host_register) and is read by the device where it lies;
  *   otherwise the rows are copied through a pinned slab by the calling thread and the process-wide host pool.
  *   counters[0..2] of sh_job_collect: pre-filtered, tested, printed variants of the block (the reference's stderr summary, __main__.py:595-599).
- * Lineage labels, sample lists and pattern output are not part of the stream (the caller keeps its per-variant path for those options).
+ * sh_job_set_lineage (round 6; before the first block): fit_lineage_effect (pyseer/model.py:151-199) inside the stream, on the design of
+ *   sh_lineage_setup, for the rows the run PRINTS, its label (labels[index], or NA) in the reference's column (pyseer/utils.py:88-95).  Fixed
+ *   effects: every printed row the reference reaches the fit with (model.py:379-382: not pre-filtered, no firth-fail).  LMM: ONE fit per block
+ *   -- of the block's LAST variant -- given to every row that passed, which is what pyseer/lmm.py:209-213 computes (it calls the fit with the
+ *   stale `k` of its loading loop), so blocks must be the reference's (--block_size); per_variant != 0 fits each passing row's own variant.
+ * Sample lists and pattern output are not part of the stream yet (the caller keeps its per-variant path for those options).
  * --------------------------------------------------------------------------------------------- */
 typedef struct sh_job sh_job;
 sh_job *sh_job_open(sh_ctx *ctx, int lmm, int print_filtered);
@@ -283,12 +288,14 @@ int     sh_job_submit(sh_job *job, const uint8_t *bits, int64_t row_bytes, int64
 int     sh_job_collect(sh_job *job, const char **text, int64_t *nbytes, int64_t *counters);
 int64_t sh_job_pending(sh_job *job);
 int     sh_job_depth(sh_job *job);     /* blocks that may be submitted and not yet collected: 3 (LMM), 2 + lanes (fixed effects) */
+int     sh_job_set_lineage(sh_job *job, const char *const *labels, int n_labels, int per_variant);
 /* the formatter behind sh_job_collect, callable on its own (tests): nsel compacted records -- idx[r] = the variant's index into names / counts,
  * flags[r], cols[c][r] (c < ncol), slopes betas[j * betas_stride + r] printed where betas_valid[r] -- as
- *   name \t counts[idx]/n_samples \t cols... [\t betas...] \t notes \n ; *text is owned by the calling thread (valid until its next call). */
+ *   name \t counts[idx]/n_samples \t cols... [\t betas...] [\t lineage label] \t notes \n ; lineage[r] = index into lineage_labels or -1 (NA), NULL =
+ *   no lineage column; *text is owned by the calling thread (valid until its next call). */
 int64_t sh_format_records(const char *names, const int64_t *name_off, const int32_t *counts, int n_samples, const int32_t *idx, int64_t nsel,
                           const double *const *cols, int ncol, const double *betas, int64_t betas_stride, int q, const uint8_t *betas_valid,
-                          const uint32_t *flags, const char **text);
+                          const int32_t *lineage, const char *const *lineage_labels, int n_labels, const uint32_t *flags, const char **text);
 /* Make [p, p + nbytes) (e.g. a window of a read-only file mapping: the packed cache) readable by the device where it lies, so that the rows
  * cross PCIe by DMA with no CPU copy (hipHostRegister on the enclosing pages; measured 4 ns of CPU per 632-byte row against 21 for the
  * copy into pinned staging, profiles/r05/host_feed_probe.txt).  `device`: the device whose stream will read it (the registration itself is portable).

@@ -417,13 +417,16 @@ def main(argv=None):
                 cache_stamp = (side + ".stamp", stamp)
             else:
                 sys.stderr.write("Cannot write a packed cache next to %s; continuing without\n" % var_file)
-    # ---- the job stream (round 5; include/seerhip.h sh_job_*): when nothing per variant is asked of the host (no lineage fit, no sample lists,
-    # no pattern file, not the cross-check sinks) a block goes to the library as parsed and comes back as the text of its printed rows: the AF
+    # ---- the job stream (round 5; include/seerhip.h sh_job_*): when nothing per variant is asked of the host (no sample lists, no pattern file,
+    # not the cross-check sinks) a block goes to the library as parsed and comes back as the text of its printed rows: the AF
     # window, the NaN masks, the counters and the choice of rows run on the device, the host formats printed rows only.  Output without
     # --print-filtered does not depend on where blocks end, so short blocks are coalesced (a 3000-row block is 90 us of GPU time).
-    job_path = ((native or bool(options.load_packed)) and not options.lineage and not options.print_samples and not options.output_patterns
+    job_path = ((native or bool(options.load_packed)) and not options.print_samples and not options.output_patterns
                 and not options.python_sink and not options.serial_sink and _route.route("job", "1") != "0")
-    job_block = options.block_size if (options.print_filtered or not job_path) else max(options.block_size, 1 << 16)
+    # (--lineage, round 6: fit_lineage_effect runs inside the stream, for printed rows -- sh_job_set_lineage.  The LMM's lineage is that of each
+    # block's LAST variant (pyseer/lmm.py:209-213, the stale `k`), so its blocks must end where the reference's do: no coalescing)
+    lmm_block_lineage = bool(options.lineage and options.lmm and not options.lmm_lineage_per_variant)
+    job_block = options.block_size if (options.print_filtered or lmm_block_lineage or not job_path) else max(options.block_size, 1 << 16)
     # the reader runs as far ahead as the job stream holds blocks in flight (fixed effects: 2 + lanes, include/seerhip.h sh_job_depth)
     job_ahead = (2 + engs[0].get_lanes()) if (job_path and not options.lmm) else 2
     if options.load_packed:
@@ -462,7 +465,8 @@ def main(argv=None):
         the rows of its next block cross PCIe while the block before runs its kernels and the one before that is written out here).
         Returns (pre-filtered, tested, printed)."""
         from .engine import Job
-        jobs = [Job(e_, options.lmm, options.print_filtered) for e_ in engs]
+        jobs = [Job(e_, options.lmm, options.print_filtered, lineage_labels=(lineage_dict if options.lineage else None),
+                    lineage_per_variant=options.lmm_lineage_per_variant) for e_ in engs]
         prefilter = tested = printed = 0
         order = collections.deque()                           # the job each block in flight went to, in input order
 

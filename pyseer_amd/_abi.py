@@ -80,7 +80,8 @@ SIGNATURES = {
     "sh_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "sh_get_lanes": (C.c_int, [C.c_void_p]),
     "sh_format_records": (C.c_int64, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int64, C.POINTER(c_dp),
-                                      C.c_int, c_dp, C.c_int64, C.c_int, c_u8p, c_u32p, C.POINTER(C.c_void_p)]),
+                                      C.c_int, c_dp, C.c_int64, C.c_int, c_u8p, C.c_void_p, C.c_void_p, C.c_int, c_u32p, C.POINTER(C.c_void_p)]),
+    "sh_job_set_lineage": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]),
     "sh_host_register": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "sh_host_unregister": (C.c_int, [C.c_void_p]),
     "sh_host_cpus": (C.c_int, []),
@@ -119,7 +120,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.sh_abi_version() != 1:
+        if lib.sh_abi_version() != 2:
             raise ImportError("libseerhip ABI version mismatch")
         _lib = lib
     return _lib

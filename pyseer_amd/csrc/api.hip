@@ -44,9 +44,9 @@ hipError_t shk_pf_rows(hipStream_t, const uint8_t *, int64_t, int64_t, int, cons
                        double, int, int *, int *, int *, int *, int *, int *, double *, uint32_t *);
 hipError_t shk_dd_gather(hipStream_t, const uint8_t *, int64_t, int64_t, const int *, const int *, uint8_t *);
 hipError_t shk_dd_scatter(hipStream_t, int64_t, int64_t, int, const int *, const int *, const double *, const uint32_t *, double *, uint32_t *);
-hipError_t shk_job_select(hipStream_t, const uint32_t *, const double *, int64_t, int, int, int, int *, long long *, long long *, int32_t *, uint32_t *, double *, int64_t);
+hipError_t shk_job_select(hipStream_t, const uint32_t *, const double *, int64_t, int, int, int, int *, long long *, long long *, int32_t *, uint32_t *, double *, int64_t, int32_t *);
 int64_t sh_format_records(const char *, const int64_t *, const int32_t *, int, const int32_t *, int64_t, const double *const *, int, const double *, int64_t, int,
-                          const uint8_t *, const uint32_t *, const char **);
+                          const uint8_t *, const int32_t *, const char *const *, int, const uint32_t *, const char **);
 #define JOB_ROWS_PER_BLOCK_HOST 1024
 }
 #include "glm_api.inc"

@@ -48,4 +48,3 @@ __device__ __forceinline__ uint32_t firth_sensitive(int accepted_steps, double t
 {
     return (accepted_steps >= FIRTH_SLOW_ITERS || fabs(tested_step_norm - 1e-4) <= 1e-8) ? SH_FLAG_FIRTH_SENSITIVE : 0u;
 }
-

@@ -7,19 +7,32 @@
 // PerfectSeparationError / LinAlgError.  Here the whole design row is wave-uniform and the response is the per-lane bit.
 // X: N x PC row-major with the intercept in column 0.
 // =====================================================================================================================
+// LinList (the job stream, job_api.inc): fit only the rows a compacted list names -- the PRINTED rows of a block, list[p] = the row's index in
+// the block, *cnt of them -- and of those only the ones the reference reaches fit_lineage_effect with (mode 1, fixed effects: not
+// pre-filtered, no firth-fail, model.py:355-382; mode 2, LMM per variant: not pre-filtered, not lrt-filtered, lmm.py:200-213); out[p] in list
+// order, -1 for the others.  list == nullptr: rows 0 .. V-1, out[v] (sh_lineage_batch).
 template <int PC>
 __global__ __launch_bounds__(256) void k_glm_lineage(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int N, int NB64,
-                                                    const double *__restrict__ X, int nlin, int *__restrict__ out)
+                                                    const double *__restrict__ X, int nlin, int *__restrict__ out, LinList L)
 {
     const XWave xw = xwave();                                        // up to four wavefronts share the 64 variants of a block
-    const int64_t v = (int64_t)blockIdx.x * 64 + xw.lane;
-    const bool live = v < V;
+    int64_t v = (int64_t)blockIdx.x * 64 + xw.lane;
+    bool live = v < V;
+    const int64_t slot = v;                                          // where the answer goes
+    bool wanted = true;
+    if (L.list) {
+        const long long n = *L.cnt;
+        if ((int64_t)blockIdx.x * 64 >= n) return;                   // (the whole block: the launch is sized for every row of the block)
+        live = slot < n;
+        v = live ? (int64_t)L.list[slot] : 0;
+        wanted = live && lin_wanted(L.flags[v], L.mode);
+    }
     const int64_t vr = live ? v : 0;
     double beta[PC];
 #pragma unroll
     for (int a = 0; a < PC; ++a) beta[a] = 0.0;
     int it = 0, status = 0, best = -1;
-    bool fin = false, active = live;
+    bool fin = false, active = live && wanted;
     const double nobs = (double)N;
     while (__any(active)) {                                          // `active` is kept identical in all the waves of a block
         double H[PC * (PC + 1) / 2], g[PC], maxdev = 0.0, unused = 0.0;
@@ -95,15 +108,15 @@ __global__ __launch_bounds__(256) void k_glm_lineage(const uint64_t *__restrict_
         }
         xw_bcast(xw, beta, active);
     }
-    if (live && xw.w == 0) out[v] = (status == 0) ? best : -1;
+    if (live && xw.w == 0) out[slot] = (status == 0 && wanted) ? best : -1;
 }
 
 extern "C" hipError_t shk_glm_lineage(hipStream_t st, int PC, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64,
-                                      const double *X, int nlin, int *out)
+                                      const double *X, int nlin, int *out, LinList L)
 {
     const int S = std::min(4, glm_split_waves(NB64));
     const dim3 grid((unsigned)((V + 63) / 64)), blk(64 * S);
-#define LIN_CASE(p) case p: hipLaunchKernelGGL(k_glm_lineage<p>, grid, blk, glm_split_lds(S), st, T, Vpad, V, N, NB64, X, nlin, out); break;
+#define LIN_CASE(p) case p: hipLaunchKernelGGL(k_glm_lineage<p>, grid, blk, glm_split_lds(S), st, T, Vpad, V, N, NB64, X, nlin, out, L); break;
     switch (PC) {
         LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(5) LIN_CASE(6) LIN_CASE(7) LIN_CASE(8) LIN_CASE(9) LIN_CASE(10)
         LIN_CASE(11) LIN_CASE(12) LIN_CASE(13) LIN_CASE(14) LIN_CASE(15) LIN_CASE(16)

@@ -82,3 +82,12 @@ struct GlmParams {
 #define FIRTH_F_NOISE 8.9e-16      /* default of GlmParams.firth_noise: four ulp of F */
 #define FIRTH_ACCEPT_BELOW 1e-10   /* default of GlmParams.firth_accept */
 #define FIRTH_WARM_LIMIT 7         /* accepted steps after which a warm-started Firth fit is restarted from the reference's start vector */
+
+// fit_lineage_effect over a compacted list of rows (glm_lineage.hip, glm_wide.hip; the job stream of csrc/job_api.inc)
+struct LinList { const int *list; const long long *cnt; const uint32_t *flags; int mode; };
+__host__ __device__ inline bool lin_wanted(uint32_t f, int mode)
+{
+    if (f & SH_FLAG_PREFILTER) return false;
+    return mode == 2 ? (f & SH_FLAG_FILTER) == 0 : (f & SH_NOTE_FIRTH_FAIL) == 0;
+}
+

@@ -981,7 +981,7 @@ __global__ __launch_bounds__(64) void k_glm_wide_lineage(const uint64_t *__restr
 // the design row comes from X).  One lane per variant in scratch memory ran at 1.8 k variants/s for 30 lineage clusters at N = 5000.
 #define WL_XS 53
 __global__ __launch_bounds__(256) void k_glm_wide_lineage_blk(const uint64_t *__restrict__ T, int64_t Vpad, int64_t V, int N,
-                                                              const double *__restrict__ X, int pc, int nlin, int *__restrict__ out)
+                                                              const double *__restrict__ X, int pc, int nlin, int *__restrict__ out, LinList L)
 {
     __shared__ double xs[WB_CH * WL_XS], wch[WB_CH], rch[WB_CH], s_beta[WIDE_LIN_PM + 2], s_g[WIDE_LIN_PM + 2];
     __shared__ double s_H[WIDE_LIN_PM * WIDE_LIN_PM], s_red[256 * 9], s_sc[8], s_wald[WIDE_LIN_PM];
@@ -989,7 +989,10 @@ __global__ __launch_bounds__(256) void k_glm_wide_lineage_blk(const uint64_t *__
     const int tid = threadIdx.x;
     const int NT = (pc + 2) / 3, NTT = NT * (NT + 1) / 2, G = 256 / NTT > 0 ? 256 / NTT : 1;
     const double nobs = (double)N;
-    for (int64_t v = blockIdx.x; v < V; v += gridDim.x) {
+    const int64_t nrows = L.list ? (int64_t)*L.cnt : V;             // (LinList: the compacted rows of the job stream, glm_lineage.hip)
+    for (int64_t slot = blockIdx.x; slot < nrows; slot += gridDim.x) {
+        const int64_t v = L.list ? (int64_t)L.list[slot] : slot;
+        if (L.list && !lin_wanted(L.flags[v], L.mode)) { if (threadIdx.x == 0) out[slot] = -1; continue; }
         int it = 0, status = 0, best = -1;                          // kept identical in every thread
         __syncthreads();
         if (tid < WIDE_LIN_PM + 2) s_beta[tid] = 0.0;               // statsmodels' default start
@@ -1101,16 +1104,16 @@ __global__ __launch_bounds__(256) void k_glm_wide_lineage_blk(const uint64_t *__
             if (tid == 0 && (!moving || it >= 35)) s_ctl = 1;
             __syncthreads();
         }
-        if (tid == 0) out[v] = (status == 0) ? best : -1;
+        if (tid == 0) out[slot] = (status == 0) ? best : -1;
     }
 }
 
 extern "C" hipError_t shk_glm_wide_lineage(hipStream_t st, const uint64_t *T, int64_t Vpad, int64_t V, int N, int NB64, const double *X,
-                                           int pc, int nlin, int *out)
+                                           int pc, int nlin, int *out, LinList L)
 {
     if (pc > WIDE_LIN_PM) return hipErrorInvalidValue;
     const int blk = 1;
-    if (blk) hipLaunchKernelGGL(k_glm_wide_lineage_blk, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, N, X, pc, nlin, out);
+    if (blk || L.list) hipLaunchKernelGGL(k_glm_wide_lineage_blk, dim3((unsigned)std::min<int64_t>(V, 2048)), dim3(256), 0, st, T, Vpad, V, N, X, pc, nlin, out, L);
     else hipLaunchKernelGGL(k_glm_wide_lineage, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, T, Vpad, V, N, NB64, X, pc, nlin, out);
     return hipGetLastError();
 }

@@ -57,7 +57,7 @@ extern "C" __global__ void __launch_bounds__(256) k_job_count(const uint32_t *__
 extern "C" __global__ void __launch_bounds__(256) k_job_scatter(const uint32_t *__restrict__ flags, const double *__restrict__ out, int64_t V, int nrow,
                                                                  int pred, int lmm, const int *__restrict__ bcount, const long long *__restrict__ base_from,
                                                                  long long *__restrict__ total_out, int32_t *__restrict__ r_idx, uint32_t *__restrict__ r_flags,
-                                                                 double *__restrict__ r_cols, int64_t cap)
+                                                                 double *__restrict__ r_cols, int64_t cap, int32_t *__restrict__ d_sel)
 {
     __shared__ long long s_base; __shared__ int s_part[256]; __shared__ int s_w[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -84,6 +84,7 @@ extern "C" __global__ void __launch_bounds__(256) k_job_scatter(const uint32_t *
         if (take) {
             p += __popcll(m & ((1ull << lane) - 1ull));
             r_idx[p] = (int32_t)v; r_flags[p] = f;
+            if (d_sel) d_sel[p] = (int32_t)v;                           // (a device copy of the list: the lineage fits of the printed rows)
             const bool pre = (f & SH_FLAG_PREFILTER) != 0, af = (f & SH_NOTE_AF_FILTER) != 0, lrt = (f & SH_NOTE_LRT_FILTER) != 0;
             for (int a = 0; a < nrow; ++a) {
                 double x = out[(size_t)a * (size_t)V + (size_t)v];
@@ -101,7 +102,7 @@ extern "C" __global__ void __launch_bounds__(256) k_job_scatter(const uint32_t *
 }
 
 extern "C" hipError_t shk_job_select(hipStream_t st, const uint32_t *flags, const double *out, int64_t V, int nrow, int lmm, int print_filtered,
-                                     int *bcount, long long *hdr_dev, long long *hdr, int32_t *r_idx, uint32_t *r_flags, double *r_cols, int64_t cap)
+                                     int *bcount, long long *hdr_dev, long long *hdr, int32_t *r_idx, uint32_t *r_flags, double *r_cols, int64_t cap, int32_t *d_sel)
 {
     if (V <= 0) return hipSuccess;
     const unsigned nb = (unsigned)((V + JOB_ROWS_PER_BLOCK - 1) / JOB_ROWS_PER_BLOCK);
@@ -111,7 +112,7 @@ extern "C" hipError_t shk_job_select(hipStream_t st, const uint32_t *flags, cons
         const int pred = !print_filtered ? 0 : (!lmm ? 1 : (ps == 0 ? 2 : 3));
         hipLaunchKernelGGL(k_job_count, dim3(nb), dim3(256), 0, st, flags, V, pred, ps == 0 ? 1 : 0, bcount, hdr_dev);
         hipLaunchKernelGGL(k_job_scatter, dim3(nb), dim3(256), 0, st, flags, out, V, nrow, pred, lmm, bcount, ps == 0 ? (const long long *)nullptr : hdr_dev + 2,
-                           ps == npass - 1 ? hdr_dev : hdr_dev + 2, r_idx, r_flags, r_cols, cap);
+                           ps == npass - 1 ? hdr_dev : hdr_dev + 2, r_idx, r_flags, r_cols, cap, d_sel);
     }
     e = hipGetLastError(); if (e != hipSuccess) return e;
     // the two counts go to the host-mapped header last (a plain copy on the stream: the host reads them after the block's event)

@@ -208,10 +208,10 @@ extern "C" int64_t sh_format_rows(const char *names, const int64_t *name_off, co
 // calling thread (valid until its next call).  Returns the number of bytes.
 int64_t sh_format_records(const char *names, const int64_t *name_off, const int32_t *counts, int n_samples, const int32_t *idx, int64_t nsel,
                           const double *const *cols, int ncol, const double *betas, int64_t betas_stride, int q, const uint8_t *betas_valid,
-                          const uint32_t *flags, const char **text)
+                          const int32_t *lineage, const char *const *lineage_labels, int n_labels, const uint32_t *flags, const char **text)
 {
-    return format_core(names, name_off, nullptr, idx, nsel, counts, n_samples, cols, ncol, betas_stride, betas, q, betas_valid, nullptr, nullptr, 0, flags,
-                       nullptr, 0, text);
+    return format_core(names, name_off, nullptr, idx, nsel, counts, n_samples, cols, ncol, betas_stride, betas, q, betas_valid, lineage, lineage_labels,
+                       n_labels, flags, nullptr, 0, text);
 }
 
 extern "C" int sh_format_concurrency_max(int reset)

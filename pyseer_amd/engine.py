@@ -275,13 +275,22 @@ class Job(object):
     prints and the block's (pre-filtered, tested, printed) counts.  Up to self.depth blocks may be in flight; collect() returns them in order.
     Everything a submitted block points at (rows, counts, names) is kept alive here until it has been collected."""
 
-    def __init__(self, engine, lmm, print_filtered=False):
+    def __init__(self, engine, lmm, print_filtered=False, lineage_labels=None, lineage_per_variant=False):
+        """lineage_labels: the lineage column of the output (sh_job_set_lineage; the engine's lineage_setup must have run): fixed effects fit
+        every printed row, the LMM one variant per block -- its last -- as pyseer/lmm.py:209-213 does, unless lineage_per_variant."""
         self._lib = engine._lib
         self._eng = engine
         h = self._lib.sh_job_open(engine._h, int(bool(lmm)), int(bool(print_filtered)))
         if not h:
             raise _abi.SeerHipError(_abi.SH_EINVAL, self._lib.sh_last_error().decode())
         self._h = C.c_void_p(h)
+        if lineage_labels is not None:
+            enc = [str(x).encode() for x in lineage_labels]
+            arr = (C.c_char_p * max(len(enc), 1))(*enc)
+            rc = self._lib.sh_job_set_lineage(self._h, arr, len(enc), int(bool(lineage_per_variant)))
+            if rc:
+                self._lib.sh_job_close(self._h); self._h = None
+                _abi.check(rc)
         self.depth = int(self._lib.sh_job_depth(self._h))      # blocks in flight at most: 3 (LMM), 2 + lanes (fixed effects)
         self._held = []                       # per block in flight: the objects its pointers refer to
         self._text = C.c_void_p(); self._n = C.c_int64(); self._cnt = (C.c_int64 * 4)()

@@ -20,7 +20,7 @@ def test_header_symbols_are_exported():
     lib = _abi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.sh_abi_version() == 1
+    assert lib.sh_abi_version() == 2
 
 
 def test_no_cpu_fallback():

@@ -200,3 +200,64 @@ def test_two_contexts_two_jobs_concurrently():
     for tag in (0, 1):
         assert [x[1] for x in res[tag]] == [w[1] for w in want]
         assert [x[0] for x in res[tag]] == [w[0] for w in want]
+
+
+@pytest.mark.parametrize("lmm,per_variant,nlin", [(False, False, 4), (False, False, 18), (True, False, 4), (True, True, 4), (True, False, 18)])
+@pytest.mark.parametrize("print_filtered", [False, True])
+def test_job_stream_lineage_column_equals_the_host_path(lmm, per_variant, nlin, print_filtered):
+    """sh_job_set_lineage (round 6): fit_lineage_effect (pyseer/model.py:151-199) inside the stream.  Against what pyseer_amd/__main__.py
+    run_stream.sink_block does with sh_lineage_batch on the host's side of the block: fixed effects -- every fitted row (model.py:379-382);
+    LMM -- the fit of the block's LAST row for every row that passed (pyseer/lmm.py:209-213, the stale `k`), or each passing row's own with
+    the per-variant extension.  nlin = 18: 1 + lineages + covariates > 16, the workgroup-per-variant kernel."""
+    from pyseer_amd.engine import Job
+    from pyseer_amd.sink import RowFormatter
+    from pyseer_amd.lmm import mask_like_fit_lmm
+    N = 300
+    pret, lrtt = (0.6, 0.3)
+    e = _setup(lmm, N, pret=pret, lrtt=lrtt)
+    rng = np.random.default_rng(9)
+    lin = (rng.integers(0, nlin + 1, N)[:, None] == np.arange(1, nlin + 1)[None, :]).astype(float)      # cluster indicators, one class dropped
+    cov = rng.standard_normal((N, 2))
+    e.lineage_setup(lin, cov)
+    labels = ["L%d" % i for i in range(nlin)]
+    sizes = [1500, 1, 1030, 2047]
+    blocks = [_rows(N, v, 300 + i) for i, v in enumerate(sizes)]
+    want = []
+    for bits, counts, blob, off in blocks:
+        r = e.lmm_batch(bits) if lmm else e.glm_batch(bits)
+        if lmm:
+            r = mask_like_fit_lmm(r)
+        afs = counts.astype(np.float64) / N
+        on = (afs >= 0.01) & (afs <= 0.99)
+        keys = ("prep", "pvalue", "beta", "bse", "frac_h2") if lmm else ("prep", "pvalue", "kbeta", "bse", "intercept")
+        cols = [afs] + [np.where(on, r[k], np.nan) for k in keys]
+        flags = np.where(on, r["flags"], np.uint32(1 | (1 << 16))).astype(np.uint32)
+        betas = valid = None
+        if not lmm:
+            betas = r["betas"]; valid = (on & (np.isfinite(r["kbeta"]) | np.isfinite(r["pvalue"]))).astype(np.uint8)
+        pf = (flags & (1 << 16)) != 0; ft = (flags & (1 << 17)) != 0
+        lineage = np.full(len(on), -1, np.int32)
+        if lmm and not per_variant:
+            lineage[~pf & ~ft] = int(e.lineage_batch(bits[-1:])[0])
+        else:
+            need = on & ~pf & (~ft if lmm else ((flags & (1 << 6)) == 0))
+            if need.any():
+                lineage[need] = e.lineage_batch(bits[need])
+        order = np.arange(len(on))
+        if lmm:
+            order = np.concatenate([order[pf], order[~pf]])
+        show = np.ones(len(on), bool) if print_filtered else (~pf & ~ft)
+        sel = order[show[order]]
+        want.append(RowFormatter(labels).format(blob, off, sel, cols, flags, betas, valid, lineage) if len(sel) else b"")
+    job = Job(e, lmm, print_filtered, lineage_labels=labels, lineage_per_variant=per_variant)
+    got = []
+    for bits, counts, blob, off in blocks:
+        job.submit(bits, counts, blob, off)
+        while job.pending() > 2:
+            got.append(bytes(job.collect()[0]))
+    while job.pending():
+        got.append(bytes(job.collect()[0]))
+    job.close(); e.close()
+    assert got == want
+    text = b"".join(got)
+    assert sum(text.count(b"\t" + l.encode() + b"\t") for l in labels) > 20, "no lineage label was printed"

@@ -181,8 +181,16 @@ def test_format_records_equals_format_rows():
     text = C.c_void_p()
     n = lib.sh_format_records(blob, off.ctypes.data_as(C.POINTER(C.c_int64)), counts.ctypes.data_as(C.POINTER(C.c_int32)), n_samples,
                               idx.ctypes.data_as(C.POINTER(C.c_int32)), nsel, cp, 5, cols[5].ctypes.data_as(_abi.c_dp), cap, q,
-                              valid.ctypes.data_as(_abi.c_u8p), flags.ctypes.data_as(_abi.c_u32p), C.byref(text))
+                              valid.ctypes.data_as(_abi.c_u8p), None, None, 0, flags.ctypes.data_as(_abi.c_u32p), C.byref(text))
     got = C.string_at(text.value, n)
+    # ... and with the lineage column (round 6: sh_job_set_lineage): labels by index, NA for -1
+    labels = ["MDS3", "cluster_B", "x"]
+    lin = rng.integers(-1, 3, nsel).astype(np.int32)
+    lab = (C.c_char_p * 3)(*[x.encode() for x in labels])
+    n2 = lib.sh_format_records(blob, off.ctypes.data_as(C.POINTER(C.c_int64)), counts.ctypes.data_as(C.POINTER(C.c_int32)), n_samples,
+                               idx.ctypes.data_as(C.POINTER(C.c_int32)), nsel, cp, 5, cols[5].ctypes.data_as(_abi.c_dp), cap, q,
+                               valid.ctypes.data_as(_abi.c_u8p), lin.ctypes.data, C.cast(lab, C.c_void_p), 3, flags.ctypes.data_as(_abi.c_u32p), C.byref(text))
+    got_lin = C.string_at(text.value, n2)
     # the same through sh_format_rows: values scattered back to variant positions
     full = [np.full(nv, np.nan) for _ in range(6)]
     full[0] = counts.astype(np.float64) / n_samples
@@ -193,3 +201,6 @@ def test_format_records_equals_format_rows():
     ff = np.zeros(nv, np.uint32); ff[idx] = flags
     want = RowFormatter().format(blob, off, idx.astype(np.int64), full, ff, fb, fv)
     assert got == want
+    fl = np.full(nv, -1, np.int32); fl[idx] = lin
+    assert got_lin == RowFormatter(labels).format(blob, off, idx.astype(np.int64), full, ff, fb, fv, fl)
+    assert got_lin != got and got_lin.count(b"\tNA\t") >= int((lin < 0).sum())
