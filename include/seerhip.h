@@ -278,7 +278,13 @@ int64_t sh_format_rows(const char *names, const int64_t *name_off, const int64_t
  *   effects: every printed row the reference reaches the fit with (model.py:379-382: not pre-filtered, no firth-fail).  LMM: ONE fit per block
  *   -- of the block's LAST variant -- given to every row that passed, which is what pyseer/lmm.py:209-213 computes (it calls the fit with the
  *   stale `k` of its loading loop), so blocks must be the reference's (--block_size); per_variant != 0 fits each passing row's own variant.
- * Sample lists and pattern output are not part of the stream yet (the caller keeps its per-variant path for those options).
+ * sh_job_set_patterns (--output-patterns): hash_pattern (pyseer/input.py:710-723) -- base64(md5(the presence vector as int64)) + "\n" -- of every
+ *   TESTED variant of a block (not pre-filtered; print loops pyseer/__main__.py:584-585, 794-795, 818-819), computed on the device (one lane
+ *   per variant; the md5 of 8 N bytes is 60 us of a CPU core per variant at N = 5000); sh_job_patterns returns the text of the block last
+ *   collected (25 bytes per tested variant, in input order), valid until the next sh_job_collect.
+ * sh_job_set_samples (--print-samples): the two sample lists of pyseer/utils.py:96-98 (carriers, then the others, comma-joined) in front of
+ *   the notes of every PRINTED row, read from the row's bits on the host: names / name_off = the n_samples sample names (concatenated, n + 1
+ *   offsets) in the context's sample order, order[i] = the sample printed i-th (the reference sorts the names).
  * --------------------------------------------------------------------------------------------- */
 typedef struct sh_job sh_job;
 sh_job *sh_job_open(sh_ctx *ctx, int lmm, int print_filtered);
@@ -289,6 +295,9 @@ int     sh_job_collect(sh_job *job, const char **text, int64_t *nbytes, int64_t 
 int64_t sh_job_pending(sh_job *job);
 int     sh_job_depth(sh_job *job);     /* blocks that may be submitted and not yet collected: 3 (LMM), 2 + lanes (fixed effects) */
 int     sh_job_set_lineage(sh_job *job, const char *const *labels, int n_labels, int per_variant);
+int     sh_job_set_patterns(sh_job *job, int on);
+int     sh_job_patterns(sh_job *job, const char **text, int64_t *nbytes);
+int     sh_job_set_samples(sh_job *job, const char *names, const int64_t *name_off, const int32_t *order, int n);
 /* the formatter behind sh_job_collect, callable on its own (tests): nsel compacted records -- idx[r] = the variant's index into names / counts,
  * flags[r], cols[c][r] (c < ncol), slopes betas[j * betas_stride + r] printed where betas_valid[r] -- as
  *   name \t counts[idx]/n_samples \t cols... [\t betas...] [\t lineage label] \t notes \n ; lineage[r] = index into lineage_labels or -1 (NA), NULL =

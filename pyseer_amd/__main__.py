@@ -417,12 +417,11 @@ def main(argv=None):
                 cache_stamp = (side + ".stamp", stamp)
             else:
                 sys.stderr.write("Cannot write a packed cache next to %s; continuing without\n" % var_file)
-    # ---- the job stream (round 5; include/seerhip.h sh_job_*): when nothing per variant is asked of the host (no sample lists, no pattern file,
-    # not the cross-check sinks) a block goes to the library as parsed and comes back as the text of its printed rows: the AF
+    # ---- the job stream (round 5; include/seerhip.h sh_job_*): unless a cross-check sink is asked for (round 6: --lineage, --output-patterns and --print-samples
+    # run inside the stream too: sh_job_set_lineage / _patterns / _samples) a block goes to the library as parsed and comes back as the text of its printed rows: the AF
     # window, the NaN masks, the counters and the choice of rows run on the device, the host formats printed rows only.  Output without
     # --print-filtered does not depend on where blocks end, so short blocks are coalesced (a 3000-row block is 90 us of GPU time).
-    job_path = ((native or bool(options.load_packed)) and not options.print_samples and not options.output_patterns
-                and not options.python_sink and not options.serial_sink and _route.route("job", "1") != "0")
+    job_path = ((native or bool(options.load_packed)) and not options.python_sink and not options.serial_sink and _route.route("job", "1") != "0")
     # (--lineage, round 6: fit_lineage_effect runs inside the stream, for printed rows -- sh_job_set_lineage.  The LMM's lineage is that of each
     # block's LAST variant (pyseer/lmm.py:209-213, the stale `k`), so its blocks must end where the reference's do: no coalescing)
     lmm_block_lineage = bool(options.lineage and options.lmm and not options.lmm_lineage_per_variant)
@@ -460,13 +459,14 @@ def main(argv=None):
         return {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0,
                 "t0w": _time.time(), "rows": 0}
 
-    def run_stream_job(engs, blocks, write_text, tm, stop=None):
+    def run_stream_job(engs, blocks, write_text, tm, stop=None, write_patterns=None):
         """One stream of RawBlocks through the library's job stream, block k on context k % len(engs) (each context pipelined Job.depth deep:
         the rows of its next block cross PCIe while the block before runs its kernels and the one before that is written out here).
         Returns (pre-filtered, tested, printed)."""
         from .engine import Job
         jobs = [Job(e_, options.lmm, options.print_filtered, lineage_labels=(lineage_dict if options.lineage else None),
-                    lineage_per_variant=options.lmm_lineage_per_variant) for e_ in engs]
+                    lineage_per_variant=options.lmm_lineage_per_variant, patterns=write_patterns is not None,
+                    sample_names=([str(x) for x in p.index] if options.print_samples else None)) for e_ in engs]
         prefilter = tested = printed = 0
         order = collections.deque()                           # the job each block in flight went to, in input order
 
@@ -477,6 +477,8 @@ def main(argv=None):
             text, cnt, release = jb.collect()
             tm["engine"] += _time.perf_counter() - t_c
             prefilter += cnt[0]; tested += cnt[1]; printed += cnt[2]
+            if write_patterns is not None and cnt[1]:
+                write_patterns(jb.patterns())                 # (hash_pattern of the block's tested variants, made on the device)
             if len(text):
                 t_w = _time.perf_counter()
                 write_text(text)
@@ -832,10 +834,10 @@ def main(argv=None):
                 blocks_i = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
                                                      want_patterns=bool(options.output_patterns), want_samples=options.print_samples, part=(i, G),
                                                      raw=job_path, device=(engs[i].device if job_path else None), ahead=job_ahead)
+                wp = None if patterns is None else (patterns.write if i == 0 else pouts[i].write)
                 if job_path:
-                    counts[i] = run_stream_job([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, tms[i], stop)
+                    counts[i] = run_stream_job([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, tms[i], stop, wp)
                 else:
-                    wp = None if patterns is None else (patterns.write if i == 0 else pouts[i].write)
                     counts[i] = run_stream([engs[i]], blocks_i, write_stdout if i == 0 else outs[i].write, wp, tms[i])
                 thread_cpu["stream %d loop thread" % i] = _time.thread_time() - t_th
             except BaseException as ex:                    # re-raised below, on the main thread
@@ -864,7 +866,7 @@ def main(argv=None):
         prefilter, tested, printed = (sum(c[j] for c in counts) for j in range(3))
     elif job_path:
         t_th = _time.thread_time()
-        prefilter, tested, printed = run_stream_job(engs, blocks, write_stdout, tms[0])
+        prefilter, tested, printed = run_stream_job(engs, blocks, write_stdout, tms[0], None, None if patterns is None else patterns.write)
         thread_cpu["stream 0 loop thread"] = _time.thread_time() - t_th
     else:
         prefilter, tested, printed = run_stream(engs, blocks, write_stdout, None if patterns is None else patterns.write, tms[0])

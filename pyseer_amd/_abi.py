@@ -82,6 +82,9 @@ SIGNATURES = {
     "sh_format_records": (C.c_int64, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int64, C.POINTER(c_dp),
                                       C.c_int, c_dp, C.c_int64, C.c_int, c_u8p, C.c_void_p, C.c_void_p, C.c_int, c_u32p, C.POINTER(C.c_void_p)]),
     "sh_job_set_lineage": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]),
+    "sh_job_set_patterns": (C.c_int, [C.c_void_p, C.c_int]),
+    "sh_job_patterns": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "sh_job_set_samples": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sh_host_register": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "sh_host_unregister": (C.c_int, [C.c_void_p]),
     "sh_host_cpus": (C.c_int, []),

@@ -47,6 +47,11 @@ hipError_t shk_dd_scatter(hipStream_t, int64_t, int64_t, int, const int *, const
 hipError_t shk_job_select(hipStream_t, const uint32_t *, const double *, int64_t, int, int, int, int *, long long *, long long *, int32_t *, uint32_t *, double *, int64_t, int32_t *);
 int64_t sh_format_records(const char *, const int64_t *, const int32_t *, int, const int32_t *, int64_t, const double *const *, int, const double *, int64_t, int,
                           const uint8_t *, const int32_t *, const char *const *, int, const uint32_t *, const char **);
+// (writer.cpp: sh_format_records + the two sample lists of --print-samples from the printed rows' host bits)
+int64_t format_records_samples(const char *, const int64_t *, const int32_t *, int, const int32_t *, int64_t, const double *const *, int, const double *, int64_t, int,
+                               const uint8_t *, const int32_t *, const char *const *, int, const uint32_t *, const char **, const uint8_t *, int64_t, const char *,
+                               const int64_t *, const int32_t *);
+hipError_t shk_job_patterns(hipStream_t, const uint64_t *, int64_t, int64_t, int, const uint32_t *, int *, long long *, uint32_t *, char *, char *);
 #define JOB_ROWS_PER_BLOCK_HOST 1024
 }
 #include "glm_api.inc"

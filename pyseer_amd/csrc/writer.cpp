@@ -128,7 +128,9 @@ struct Inside { Inside() { const int n = ++g_inside; int m = g_inside_max.load()
 static int64_t format_core(const char *names, const int64_t *name_off, const int64_t *sel, const int32_t *name_idx, int64_t nsel,
                            const int32_t *af_counts, int n_samples, const double *const *cols, int ncol, int64_t betas_stride,
                            const double *betas, int q, const uint8_t *betas_valid, const int32_t *lineage, const char *const *lineage_labels,
-                           int n_labels, const uint32_t *flags, char *out, int64_t cap, const char **own_text)
+                           int n_labels, const uint32_t *flags, char *out, int64_t cap, const char **own_text,
+                           const uint8_t *smp_bits = nullptr, int64_t smp_row_bytes = 0, const char *smp_names = nullptr, const int64_t *smp_off = nullptr,
+                           const int32_t *smp_order = nullptr)
 {
     Inside in_;
     int nth = std::min(shost::host_cpus(), kMaxParts);
@@ -136,7 +138,10 @@ static int64_t format_core(const char *names, const int64_t *name_off, const int
     size_t lab_max = 2;                                                    // "NA"
     std::vector<size_t> lab_len((size_t)std::max(n_labels, 0));
     for (int l = 0; l < n_labels; ++l) { lab_len[(size_t)l] = strlen(lineage_labels[l]); lab_max = std::max(lab_max, lab_len[(size_t)l]); }
-    const size_t fixed = (size_t)(ncol + 1 + std::max(q, 0)) * 13 + lab_max + 1 + 160 + 2 + 8;  // all but the name: numbers <= 12 + tab (put_num stores 8 bytes at its tail), notes <= 149
+    // --print-samples (utils.py:96-98): the carriers' names, then the others', comma-joined, in the reference's (sorted) order, from the row's bits
+    size_t smp_room = 0;
+    if (smp_bits) smp_room = (size_t)smp_off[n_samples] + (size_t)n_samples + 4;
+    const size_t fixed = (size_t)(ncol + 1 + std::max(q, 0)) * 13 + lab_max + 1 + 160 + 2 + 8 + smp_room;  // all but the name: numbers <= 12 + tab (put_num stores 8 bytes at its tail), notes <= 149
     Part *const parts = my_parts().a;
     const std::function<void(int64_t)> body = [&](int64_t part) {
         const int64_t lo = nsel * part / nth, hi = nsel * (part + 1) / nth;
@@ -158,6 +163,20 @@ static int64_t format_core(const char *names, const int64_t *name_off, const int
                 const int32_t l = lineage[v];
                 if (l >= 0 && l < n_labels) { memcpy(w, lineage_labels[l], lab_len[(size_t)l]); w += lab_len[(size_t)l]; }
                 else { *w++ = 'N'; *w++ = 'A'; }
+            }
+            if (smp_bits) {
+                const uint8_t *row = smp_bits + (size_t)nv * (size_t)smp_row_bytes;
+                for (int pass = 1; pass >= 0; --pass) {                   // carriers first (kstrains), then the rest (nkstrains)
+                    *w++ = '\t';
+                    bool first = true;
+                    for (int i = 0; i < n_samples; ++i) {
+                        const int32_t sidx = smp_order[i];
+                        if ((int)((row[sidx >> 3] >> (sidx & 7)) & 1u) != pass) continue;
+                        if (!first) *w++ = ',';
+                        const size_t k = (size_t)(smp_off[sidx + 1] - smp_off[sidx]);
+                        memcpy(w, smp_names + smp_off[sidx], k); w += k; first = false;
+                    }
+                }
             }
             *w++ = '\t';
             const uint32_t f = flags[v] & 0x1ffu;
@@ -212,6 +231,16 @@ int64_t sh_format_records(const char *names, const int64_t *name_off, const int3
 {
     return format_core(names, name_off, nullptr, idx, nsel, counts, n_samples, cols, ncol, betas_stride, betas, q, betas_valid, lineage, lineage_labels,
                        n_labels, flags, nullptr, 0, text);
+}
+
+// sh_format_records with the two sample lists of --print-samples (the job stream: csrc/job_api.inc sh_job_set_samples)
+extern "C" int64_t format_records_samples(const char *names, const int64_t *name_off, const int32_t *counts, int n_samples, const int32_t *idx, int64_t nsel,
+                                          const double *const *cols, int ncol, const double *betas, int64_t betas_stride, int q, const uint8_t *betas_valid,
+                                          const int32_t *lineage, const char *const *lineage_labels, int n_labels, const uint32_t *flags, const char **text,
+                                          const uint8_t *smp_bits, int64_t smp_row_bytes, const char *smp_names, const int64_t *smp_off, const int32_t *smp_order)
+{
+    return format_core(names, name_off, nullptr, idx, nsel, counts, n_samples, cols, ncol, betas_stride, betas, q, betas_valid, lineage, lineage_labels,
+                       n_labels, flags, nullptr, 0, text, smp_bits, smp_row_bytes, smp_names, smp_off, smp_order);
 }
 
 extern "C" int sh_format_concurrency_max(int reset)

@@ -275,9 +275,11 @@ class Job(object):
     prints and the block's (pre-filtered, tested, printed) counts.  Up to self.depth blocks may be in flight; collect() returns them in order.
     Everything a submitted block points at (rows, counts, names) is kept alive here until it has been collected."""
 
-    def __init__(self, engine, lmm, print_filtered=False, lineage_labels=None, lineage_per_variant=False):
+    def __init__(self, engine, lmm, print_filtered=False, lineage_labels=None, lineage_per_variant=False, patterns=False, sample_names=None):
         """lineage_labels: the lineage column of the output (sh_job_set_lineage; the engine's lineage_setup must have run): fixed effects fit
-        every printed row, the LMM one variant per block -- its last -- as pyseer/lmm.py:209-213 does, unless lineage_per_variant."""
+        every printed row, the LMM one variant per block -- its last -- as pyseer/lmm.py:209-213 does, unless lineage_per_variant.
+        patterns: hash_pattern of every tested variant, on the device (patterns() after each collect).  sample_names: the run's samples in the
+        engine's order -- printed rows carry their two sample lists (--print-samples), names sorted as the reference sorts them."""
         self._lib = engine._lib
         self._eng = engine
         h = self._lib.sh_job_open(engine._h, int(bool(lmm)), int(bool(print_filtered)))
@@ -291,6 +293,16 @@ class Job(object):
             if rc:
                 self._lib.sh_job_close(self._h); self._h = None
                 _abi.check(rc)
+        self._pat = bool(patterns)
+        if patterns:
+            _abi.check(self._lib.sh_job_set_patterns(self._h, 1))
+        if sample_names is not None:
+            enc = [str(x).encode() for x in sample_names]
+            off = np.zeros(len(enc) + 1, dtype=np.int64)
+            np.cumsum([len(x) for x in enc], out=off[1:])
+            order = np.array(sorted(range(len(enc)), key=lambda i: str(sample_names[i])), dtype=np.int32)
+            _abi.check(self._lib.sh_job_set_samples(self._h, b"".join(enc), off.ctypes.data, order.ctypes.data, len(enc)))
+        self._ptext = C.c_void_p(); self._pn = C.c_int64()
         self.depth = int(self._lib.sh_job_depth(self._h))      # blocks in flight at most: 3 (LMM), 2 + lanes (fixed effects)
         self._held = []                       # per block in flight: the objects its pointers refer to
         self._text = C.c_void_p(); self._n = C.c_int64(); self._cnt = (C.c_int64 * 4)()
@@ -331,6 +343,12 @@ class Job(object):
             drop = len(self._held) - n
             self._zombies = getattr(self, "_zombies", []) + self._held[:drop]
             self._held = self._held[drop:]
+
+    def patterns(self):
+        """The pattern text (25 bytes per tested variant) of the block last collected; valid until the next collect."""
+        _abi.check(self._lib.sh_job_patterns(self._h, C.byref(self._ptext), C.byref(self._pn)))
+        n = self._pn.value
+        return memoryview((C.c_char * n).from_address(self._ptext.value)) if n else b""
 
     def close(self):
         if getattr(self, "_h", None):

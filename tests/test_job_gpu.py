@@ -261,3 +261,54 @@ def test_job_stream_lineage_column_equals_the_host_path(lmm, per_variant, nlin, 
     assert got == want
     text = b"".join(got)
     assert sum(text.count(b"\t" + l.encode() + b"\t") for l in labels) > 20, "no lineage label was printed"
+
+
+@pytest.mark.parametrize("lmm", [True, False])
+@pytest.mark.parametrize("N", [300, 303, 311])
+def test_job_stream_patterns_and_sample_lists(lmm, N):
+    """sh_job_set_patterns / sh_job_set_samples (round 6).  Patterns: base64(md5(int64 presence vector)) + newline of every TESTED row of a
+    block, in input order, from the device's md5 (csrc/job_kernels.hip k_job_md5) against hashlib through pyseer_amd.input.hash_pattern
+    (= the reference's, pyseer/input.py:710-723).  N = 300 / 303 / 311: the tail of the message holds 4 / 7 / 7 samples -- with 7 the length
+    goes into a block of its own.  Sample lists (utils.py:96-98): carriers, then the others, names sorted, in front of the notes."""
+    import hashlib, binascii
+    from pyseer_amd.engine import Engine, Job, pack_variants
+    from pyseer_amd.input import hash_pattern
+    from pyseer_amd.model import fit_null
+    rng = np.random.default_rng(N)
+    e = Engine(N); e.set_af_filter(0.01, 0.99)
+    y = (rng.random(N) < 0.4).astype(float)
+    if lmm:
+        from pyseer_amd.lmm import initialise_lmm_arrays
+        G_ = (rng.random((400, N)) < 0.3).astype(float)
+        U, S, h2, nll, Cc = initialise_lmm_arrays(G_.T @ G_, y)
+        e.lmm_setup(U, S, y, Cc, h2, filter_pvalue=0.7, lrt_pvalue=0.5)
+    else:
+        W = rng.standard_normal((N, 2))
+        e0 = np.zeros((0, 0))
+        e.glm_setup(y, W, False, fit_null(y, W, e0, False).llf, fit_null(y, W, e0, False, firth=True), 0.7, 0.5)
+    names = ["s%03d" % int(x) for x in rng.permutation(N)]                       # (not in sorted order)
+    order = sorted(range(N), key=lambda i: names[i])
+    sizes = [1300, 1, 2050]
+    job = Job(e, lmm, False, patterns=True, sample_names=names)
+    got_text, got_pat, blocks = [], [], []
+    for i, v in enumerate(sizes):
+        b = _rows(N, v, 500 + i); blocks.append(b)
+        job.submit(*b)
+    while job.pending():
+        t, c, _ = job.collect(); got_text.append(bytes(t)); got_pat.append((bytes(job.patterns()), c))
+    job.close()
+    for (bits, counts, blob, off), text, (pat, c) in zip(blocks, got_text, got_pat):
+        K = np.unpackbits(bits, axis=1, bitorder="little")[:, :N]
+        r = e.lmm_batch(bits) if lmm else e.glm_batch(bits)
+        afs = counts / N
+        pf = ~((afs >= 0.01) & (afs <= 0.99)) | ((r["flags"] & (1 << 16)) != 0)
+        want = b"".join(hash_pattern(K[v].astype(np.int64)) for v in np.flatnonzero(~pf))
+        assert c[1] == int((~pf).sum()) and len(pat) == 25 * c[1]
+        assert pat == want
+        for line in text.splitlines():
+            f = line.split(b"\t")
+            v = int(f[0][1:7])
+            ks = ",".join(names[i] for i in order if K[v, i]); nks = ",".join(names[i] for i in order if not K[v, i])
+            assert f[-3].decode() == ks and f[-2].decode() == nks, (v, f[-3][:60], ks[:60])
+    e.close()
+    assert sum(len(t) for t in got_text) > 0
