@@ -28,6 +28,12 @@ if FIXED:
         f.write("samples\t" + "\t".join("c%d" % j for j in range(10)) + "\n")
         for i in range(N):
             f.write(names[i] + "\t" + "\t".join(repr(float(x)) for x in Wc[i]) + "\n")
+# (round 6: --lineage / --output-patterns / --print-samples inside the job stream -- E2E_EXTRA="--lineage --lineage-clusters {d}/clusters.txt
+# --lineage-file {d}/lin.txt --output-patterns {d}/patterns.txt"; clusters = the lineages the synthetic kinship was built from, 8 of them)
+with open(d + "/clusters.txt", "w") as f:
+    for i in range(N):
+        f.write("%s\tcl%d\n" % (names[i], int(lin[i]) % 8))
+EXTRA = [x.replace("{d}", d) for x in os.environ.get("E2E_EXTRA", "").split()]
 with open(d + "/pheno.tsv", "w") as f:
     f.write("samples\tbinary\n")
     for i in range(N):
@@ -71,7 +77,7 @@ def run(name, extra, env_more):
     t0 = time.time(); ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     model = (["--no-distances", "--covariates", d + "/cov.tsv", "--use-covariates"] + ["%dq" % j for j in range(2, 12)]) if FIXED else ["--lmm", "--load-lmm", d + "/lmm.npz"]
     r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv"] + model +
-                       ["--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + extra,
+                       ["--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + EXTRA + extra,
                        env=env, stdout=open(out, "w"), stderr=subprocess.PIPE)
     dt = time.time() - t0; ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     err = r.stderr.decode()
@@ -120,5 +126,5 @@ for lrt, tag in [x.split(":") for x in os.environ.get("E2E_LRT", "1e-3:lrt1e-3,1
         md5.add(run(w_ + "_" + tag, extra, env_more)["md5"])
     res["identical_" + tag] = len(md5) == 1
     print("outputs identical (%s): %s" % (tag, res["identical_" + tag]), flush=True)
-o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "r05"); os.makedirs(o, exist_ok=True)
+o = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", os.environ.get("E2E_ROUND", "r06")); os.makedirs(o, exist_ok=True)
 json.dump(res, open(o + "/" + os.environ.get("E2E_OUT", "host_budget.json"), "w"), indent=1)
