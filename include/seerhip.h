@@ -298,6 +298,15 @@ int     sh_job_set_lineage(sh_job *job, const char *const *labels, int n_labels,
 int     sh_job_set_patterns(sh_job *job, int on);
 int     sh_job_patterns(sh_job *job, const char **text, int64_t *nbytes);
 int     sh_job_set_samples(sh_job *job, const char *names, const int64_t *name_off, const int32_t *order, int n);
+/* The whole block loop of one stream of a packed cache (pyseer_amd/input.py PackedCacheWriter: the `--save-packed` / `--load-packed` file) in
+ * one call -- the loop over load_var_block / fit / print of pyseer/__main__.py:541-593, 777-827 for part `part_i` of `part_n` contiguous ranges
+ * of the cache's rows (the reference's `--cpu N`; one part per device).  Stored blocks are merged to at least block_rows rows (never split)
+ * exactly as the single stream would cut them; rows go to the device by DMA from registered windows of the file's mapping (use_dma != 0) or
+ * through pinned slabs; the text of the printed rows is written to out_fd, the pattern text (sh_job_set_patterns) to pat_fd, in input order.
+ * counters[0..3] += pre-filtered, tested, printed variants and blocks.  *stop != 0 (may be NULL) ends the stream at the next block.  The
+ * calling thread holds no interpreter lock: streams of several contexts run side by side on threads of one process. */
+int     sh_job_run_packed(sh_job *job, const char *path, int part_i, int part_n, int64_t block_rows, int use_dma, int out_fd, int pat_fd,
+                          int64_t *counters, const volatile int *stop);
 /* the formatter behind sh_job_collect, callable on its own (tests): nsel compacted records -- idx[r] = the variant's index into names / counts,
  * flags[r], cols[c][r] (c < ncol), slopes betas[j * betas_stride + r] printed where betas_valid[r] -- as
  *   name \t counts[idx]/n_samples \t cols... [\t betas...] [\t lineage label] \t notes \n ; lineage[r] = index into lineage_labels or -1 (NA), NULL =

@@ -84,7 +84,7 @@ import pandas as pd
 
 from . import __version__
 from .classes import Seer, LMM, FLAG_FILTER, FLAG_PREFILTER, notes_from_flags
-from .input import (load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
+from .input import (check_packed_cache, load_phenotypes, load_structure, load_covariates, load_lineage, open_variant_file,
                     iter_packed_blocks, iter_packed_blocks_native, iter_packed_blocks_native_multi, iter_packed_blocks_cached,
                     PackedCacheWriter, packed_cache_complete)
 from .lmm import initialise_lmm, mask_like_fit_lmm
@@ -513,6 +513,33 @@ def main(argv=None):
         tm["rows"] = prefilter + tested; tm["loop"] = _time.perf_counter() - tm["t0"]; tm["overlap"] = True; tm["job"] = True
         return prefilter, tested, printed
 
+    def run_stream_packed(eng_, part, out_file, pat_file, tm, stop_c=None):
+        """One stream of a packed cache entirely inside the library (round 6: sh_job_run_packed -- csrc/job_run.inc): the block loop, the DMA
+        windows, the writes to the two descriptors; this thread holds no interpreter lock while it runs."""
+        from .engine import Job
+        sys.stdout.flush()                                     # (the header line sits in the text layer's buffer)
+        out_file.flush()
+        if pat_file is not None:
+            pat_file.flush()
+        job = Job(eng_, options.lmm, options.print_filtered, lineage_labels=(lineage_dict if options.lineage else None),
+                  lineage_per_variant=options.lmm_lineage_per_variant, patterns=pat_file is not None,
+                  sample_names=([str(x) for x in p.index] if options.print_samples else None))
+        try:
+            pf_, te_, pr_, nb_ = job.run_packed(options.load_packed, part, job_block, use_dma=_route.route("dma", "1") != "0", out_fd=out_file.fileno(),
+                                                pat_fd=(pat_file.fileno() if pat_file is not None else -1), stop=stop_c)
+        finally:
+            job.close()
+        tm["blocks"] = nb_; tm["rows"] = pf_ + te_; tm["loop"] = _time.perf_counter() - tm["t0"]; tm["overlap"] = True; tm["job"] = True
+        tm["engine"] = tm["loop"]
+        return pf_, te_, pr_
+
+    def has_fd(f):
+        try:
+            f.fileno()
+            return True
+        except Exception:
+            return False
+
     def run_stream(engs, blocks, write_text, write_patterns, tm):
         """One stream of blocks, in order: reader (its own thread inside `blocks`) -> engine calls, block k on engs[k % len(engs)], each engine
         pipelined -> one ordered sink writing through write_text / write_patterns.  Returns (pre-filtered, tested, printed).  The job runs one
@@ -813,6 +840,12 @@ def main(argv=None):
     _lib = _abi_mod.load()
     ru_loop0 = _res.getrusage(_res.RUSAGE_SELF); cpu_stage0 = _abi_mod.host_cpu_seconds(); t_loop0 = _time.perf_counter()
     thread_cpu = {}                                        # CPU seconds of the Python threads of the block loop, by role (time.thread_time)
+    # a packed cache through the job stream: the block loop runs inside the library, one call per device (SEERHIP_ROUTE job=py: the loop in
+    # Python, as round 5 had it and as text input still has it)
+    packed_c_loop = bool(job_path and options.load_packed and _route.route("job", "1") != "py" and has_fd(sys.stdout)
+                         and (patterns is None or has_fd(patterns)))
+    if packed_c_loop:
+        check_packed_cache(p, options.load_packed)
     if len(engs) > 1 and options.load_packed:
         import shutil
         import tempfile
@@ -827,10 +860,17 @@ def main(argv=None):
         counts = [None] * G
         errs = [None] * G
         stop = _th.Event()
+        import ctypes as _ct
+        stop_c = _ct.c_int(0)
 
         def stream_worker(i):
             try:
                 t_th = _time.thread_time()
+                if packed_c_loop:
+                    counts[i] = run_stream_packed(engs[i], (i, G), (sys.stdout.buffer if (i == 0 and hasattr(sys.stdout, "buffer")) else sys.stdout) if i == 0 else outs[i],
+                                                  None if patterns is None else (patterns if i == 0 else pouts[i]), tms[i], stop_c)
+                    thread_cpu["stream %d loop thread" % i] = _time.thread_time() - t_th
+                    return
                 blocks_i = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
                                                      want_patterns=bool(options.output_patterns), want_samples=options.print_samples, part=(i, G),
                                                      raw=job_path, device=(engs[i].device if job_path else None), ahead=job_ahead)
@@ -843,6 +883,7 @@ def main(argv=None):
             except BaseException as ex:                    # re-raised below, on the main thread
                 errs[i] = ex
                 stop.set()
+                stop_c.value = 1
         workers = [_th.Thread(target=stream_worker, args=(i,)) for i in range(G)]
         for w_ in workers:
             w_.start()
@@ -864,6 +905,10 @@ def main(argv=None):
                 shutil.copyfileobj(pouts[i], patterns, 1 << 22)
                 pouts[i].close()
         prefilter, tested, printed = (sum(c[j] for c in counts) for j in range(3))
+    elif packed_c_loop:
+        t_th = _time.thread_time()
+        prefilter, tested, printed = run_stream_packed(engs[0], (0, 1), sys.stdout.buffer if hasattr(sys.stdout, "buffer") else sys.stdout, patterns, tms[0])
+        thread_cpu["stream 0 loop thread"] = _time.thread_time() - t_th
     elif job_path:
         t_th = _time.thread_time()
         prefilter, tested, printed = run_stream_job(engs, blocks, write_stdout, tms[0], None, None if patterns is None else patterns.write)

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sh_job_set_patterns": (C.c_int, [C.c_void_p, C.c_int]),
     "sh_job_patterns": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "sh_job_set_samples": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "sh_job_run_packed": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
     "sh_host_register": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "sh_host_unregister": (C.c_int, [C.c_void_p]),
     "sh_host_cpus": (C.c_int, []),

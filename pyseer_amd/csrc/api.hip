@@ -1093,5 +1093,6 @@ int sh_sim_finish(sh_ctx *c, double *K)
 #include "glm_api_impl.inc"
 #include "lanes_api.inc"
 #include "job_api.inc"
+#include "job_run.inc"
 
 }  // extern "C"

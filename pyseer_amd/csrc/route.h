@@ -34,7 +34,7 @@
 //   qf=V             [4]  LMM contraction kernel: 0 = k_lmm_quadform_i8 (two wavefronts per SIMD), 3x = timing ablations
 //   lanes=n          [3]  lanes of a fixed-effects context (sh_set_lanes overrides)
 //   reader=serial|zlib [par] container decoder of the native reader;  reader_threads=T  its parser workers
-//   wait=spin        [sleep], job=0 [1], dma=0 [1]   command line (pyseer_amd/__main__.py, input.py): host threads spin on the device; the
+//   wait=spin        [sleep], job=0 / py [1], dma=0 [1]   command line (pyseer_amd/__main__.py, input.py): host threads spin on the device; the
 //                    Python block loop instead of the job stream; rows through pinned slabs instead of DMA from the registered cache mapping
 //   reader_chunk=B   [4 MB] most compressed bytes per region of the parallel gzip decoder (regions are sized for ~12 MB of text; small values:
 //                    many regions in a small file);  reader_workers=W  its decoding threads [2/3 of the reader's threads, at most 32]

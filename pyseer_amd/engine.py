@@ -344,6 +344,14 @@ class Job(object):
             self._zombies = getattr(self, "_zombies", []) + self._held[:drop]
             self._held = self._held[drop:]
 
+    def run_packed(self, path, part=(0, 1), block_rows=1 << 16, use_dma=True, out_fd=1, pat_fd=-1, stop=None):
+        """The whole stream of part i of n of a packed cache inside the library (sh_job_run_packed): text to out_fd, patterns to pat_fd.
+        stop: a ctypes.c_int another thread may set to end the stream.  -> (pre-filtered, tested, printed, blocks)."""
+        cnt = (C.c_int64 * 4)()
+        _abi.check(self._lib.sh_job_run_packed(self._h, str(path).encode(), int(part[0]), int(part[1]), int(block_rows), int(bool(use_dma)), int(out_fd),
+                                               int(pat_fd), cnt, C.addressof(stop) if stop is not None else None))
+        return int(cnt[0]), int(cnt[1]), int(cnt[2]), int(cnt[3])
+
     def patterns(self):
         """The pattern text (25 bytes per tested variant) of the block last collected; valid until the next collect."""
         _abi.check(self._lib.sh_job_patterns(self._h, C.byref(self._ptext), C.byref(self._pn)))

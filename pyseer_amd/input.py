@@ -792,6 +792,26 @@ class _DmaWindows(object):
                 self._kick()
 
 
+def check_packed_cache(p, path):
+    """The header checks of iter_packed_blocks_cached without reading a block (the library's own block loop, sh_job_run_packed, walks the file
+    itself): magic, sample list and order, row width.  Raises what the iterator raises."""
+    samples = [str(x) for x in p.index]
+    with open(path, "rb") as f:
+        head = f.read(24)
+        if len(head) < 24 or head[:8] != _PK_MAGIC:
+            raise IOError("%s is not a packed k-mer cache" % path)
+        ns, rb = np.frombuffer(head, dtype="<u4", count=2, offset=8)
+        (ln,) = np.frombuffer(head, dtype="<u8", count=1, offset=16)
+        names = f.read(int(ln))
+        if len(names) < int(ln):
+            raise IOError("truncated packed cache %s (delete it, or run without --load-packed)" % path)
+    stored = names.decode().split("\n")
+    if stored != samples:
+        raise ValueError("packed cache was written for a different sample list / order (%d vs %d samples)" % (len(stored), len(samples)))
+    if int(rb) != row_bytes_for(len(samples)):
+        raise IOError("packed cache row width mismatch")
+
+
 def iter_packed_blocks_cached(p, path, min_af, max_af, block_size, want_patterns=False, want_samples=False, part=None, raw=False, device=None, ahead=2):
     """PackedBlock stream from a packed cache written by --save-packed; the samples (and their order) must be the run's own.
     Stored blocks are re-cut to about `block_size` variants (stored blocks are never split, only merged).

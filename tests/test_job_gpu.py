@@ -312,3 +312,73 @@ def test_job_stream_patterns_and_sample_lists(lmm, N):
             assert f[-3].decode() == ks and f[-2].decode() == nks, (v, f[-3][:60], ks[:60])
     e.close()
     assert sum(len(t) for t in got_text) > 0
+
+
+@pytest.mark.parametrize("lmm", [True, False])
+def test_the_librarys_own_block_loop_over_a_packed_cache(lmm, tmp_path):
+    """sh_job_run_packed (round 6, csrc/job_run.inc): the block loop of a `--load-packed` stream inside the library -- index pass, merging of
+    stored blocks to block_rows, ranges of the rows for `part_n` devices, DMA windows of the mapping (registered page-disjoint, let go by a
+    janitor thread), submit / collect, writes to descriptors.  Against the same blocks pushed through Job.submit / collect from Python:
+    same text, same pattern text, same counters; the parts of a three-way split concatenate to the single stream; a zero-carrier row is
+    announced on stderr as read_variant does (pyseer/input.py:441-443); a truncated file is refused with the iterator's message."""
+    from pyseer_amd.engine import Job
+    from pyseer_amd.input import PackedCacheWriter
+    from pyseer_amd import _abi
+    N = 300
+    e = _setup(lmm, N, pret=0.6, lrtt=0.4)
+    names = ["s%d" % i for i in range(N)]
+    sizes = [700, 40, 2100, 1, 300, 5000, 64, 1200]                  # small stored blocks: several share a page of the mapping
+    blocks = [_rows(N, v, 700 + i) for i, v in enumerate(sizes)]
+    path = str(tmp_path / "k.seerpack")
+    w = PackedCacheWriter(path, names)
+    for bits, counts, blob, off in blocks:
+        w.write_block(blob, off, counts, bits)
+    w.close()
+
+    def by_python(block_rows):
+        job = Job(e, lmm, False, patterns=True)
+        text, pat, cnt = [], [], [0, 0, 0]
+        acc, rows = [], 0
+        groups = []
+        for b in blocks:
+            acc.append(b); rows += b[1].shape[0]
+            if rows >= block_rows:
+                groups.append(acc); acc, rows = [], 0
+        if acc:
+            groups.append(acc)
+        for g in groups:
+            bits = np.concatenate([x[0] for x in g]); counts = np.concatenate([x[1] for x in g]); blob = b"".join(bytes(x[2]) for x in g)
+            base = np.cumsum([0] + [len(x[2]) for x in g[:-1]])
+            off = np.concatenate([x[3][:-1] + bb for x, bb in zip(g, base)] + [np.array([len(blob)], dtype=np.int64)])
+            job.submit(bits, counts, blob, off)
+            t, c, _ = job.collect(); text.append(bytes(t)); pat.append(bytes(job.patterns()))
+            for a in range(3):
+                cnt[a] += c[a]
+        job.close()
+        return b"".join(text), b"".join(pat), tuple(cnt), len(groups)
+
+    def by_library(block_rows, part=(0, 1), dma=True):
+        job = Job(e, lmm, False, patterns=True)
+        fo, fp = str(tmp_path / "o.tsv"), str(tmp_path / "p.txt")
+        with open(fo, "wb") as a, open(fp, "wb") as b:
+            c = job.run_packed(path, part, block_rows, use_dma=dma, out_fd=a.fileno(), pat_fd=b.fileno())
+        job.close()
+        return open(fo, "rb").read(), open(fp, "rb").read(), c[:3], c[3]
+
+    for block_rows in (1, 1000, 4000):
+        want = by_python(block_rows)
+        for dma in (True, False):
+            got = by_library(block_rows, dma=dma)
+            assert got == want, (block_rows, dma, got[2:], want[2:])
+        parts = [by_library(block_rows, (i, 3)) for i in range(3)]
+        assert b"".join(x[0] for x in parts) == want[0] and b"".join(x[1] for x in parts) == want[1]
+        assert tuple(sum(x[2][a] for x in parts) for a in range(3)) == want[2] and sum(x[3] for x in parts) == want[3]
+    assert len(want[0]) > 1000 and len(want[1]) == 25 * want[2][1]
+    # a truncated cache: refused, with the iterator's message
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw[:len(raw) - 5000])
+    job = Job(e, lmm, False)
+    with pytest.raises(_abi.SeerHipError) as ei:
+        job.run_packed(path, (0, 1), 1000, out_fd=os.open(os.devnull, os.O_WRONLY))
+    assert "truncated packed cache" in str(ei.value)
+    job.close(); e.close()

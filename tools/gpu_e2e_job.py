@@ -120,6 +120,8 @@ for lrt, tag in [x.split(":") for x in os.environ.get("E2E_LRT", "1e-3:lrt1e-3,1
             rt.append("wait=spin")
         if w_.endswith("_staged"):
             rt.append("dma=0")
+        if "_py" in w_:                                    # round 5's loop: the job stream driven block by block from Python
+            rt.append("job=py")
         if "_lanes1" in w_:
             rt.append("lanes=1")
         env_more = {"SEERHIP_ROUTE": ",".join(rt)} if rt else {}
