@@ -161,6 +161,9 @@ def get_options(argv=None):
                     help='Format every output row in Python (one result tuple per variant) instead of the native block sink')
     ot.add_argument('--serial-sink', action='store_true', default=False,
                     help='Format and write each block before the next one is tested [Default: on a worker thread, while the next block is on the GPU]')
+    ot.add_argument('--packed-part', default=None, metavar='I/N',
+                    help='With --load-packed: run only range I of N contiguous ranges of the cache (one process per device: run N processes, '
+                         'each with its own --gpu, and concatenate their outputs in order)')
     ot.add_argument('--lmm-lineage-per-variant', action='store_true', default=False,
                     help='With --lmm --lineage, fit the lineage effect of each variant itself. [Default: reproduce the reference, '
                          'which fits the LAST variant of each block for every variant of that block]')
@@ -310,6 +313,19 @@ def main(argv=None):
             since_start = float(fh.read().split()[0]) - int(st_[st_.rindex(")") + 2:].split()[19]) / os.sysconf("SC_CLK_TCK")
     except (OSError, ValueError, IndexError):
         pass
+    # One PROCESS per device for a `--gpus` job over a packed cache (round 6; pyseer_amd/_packed_child.py): this process does the host set-up
+    # and joins the parts, every device's process runs the library's own block loop over its range of the cache.  SEERHIP_ROUTE procs=0: the
+    # devices' streams as threads of this process (round 5).
+    devs_ = None
+    if options.gpus is not None:
+        devs_ = [int(x) for x in options.gpus.split(",")] if "," in options.gpus else list(range(int(options.gpus)))
+    proc_mode = bool(devs_ and len(devs_) > 1 and options.load_packed and not options.save_packed and not options.python_sink and not options.serial_sink
+                     and not options.packed_part and _route.route("job", "1") not in ("0", "py") and _route.route("procs", "1") != "0")
+    if proc_mode:
+        try:
+            sys.stdout.fileno()
+        except Exception:
+            proc_mode = False
     if options.lmm:
         sys.stderr.write("Setting up LMM\n")
         # lineage_samples = p.index as the reference passes it (__main__.py:403, 455-456): a similarity matrix over another set of
@@ -318,14 +334,15 @@ def main(argv=None):
                                     lineage_samples=(p.index if options.lineage else None),
                                     use_gpu=not options.cpu_eigh, device=options.gpu)
         sys.stderr.write("h^2 = " + '{0:.2f}'.format(h2) + "\n")
-        engs = make_engines(len(p))
+        engs = [] if proc_mode else make_engines(len(p))
         # the first context builds the per-run state (M = U~ diag(1/Sd) U~^T, limbs, tables); the others receive it device to device
         # (sh_lmm_share: 94 MB at N = 5000) instead of each re-deriving it from the host copy of U
-        engs[0].lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)
+        if engs:
+            engs[0].lmm_setup(lmm.U, lmm.S, lmm.Y, lmm.X, h2, options.continuous, options.filter_pvalue, options.lrt_pvalue)
         for e_ in engs[1:]:
             e_.lmm_share_from(engs[0])
     else:
-        engs = make_engines(len(p))
+        engs = [] if proc_mode else make_engines(len(p))
         for e_ in engs:
             e_.glm_setup(p.values, covariate_block(len(p), m, cov), options.continuous,
                          np.nan if options.continuous else null_fit.llf, None if options.continuous else firth_null,
@@ -427,11 +444,11 @@ def main(argv=None):
     lmm_block_lineage = bool(options.lineage and options.lmm and not options.lmm_lineage_per_variant)
     job_block = options.block_size if (options.print_filtered or lmm_block_lineage or not job_path) else max(options.block_size, 1 << 16)
     # the reader runs as far ahead as the job stream holds blocks in flight (fixed effects: 2 + lanes, include/seerhip.h sh_job_depth)
-    job_ahead = (2 + engs[0].get_lanes()) if (job_path and not options.lmm) else 2
+    job_ahead = (2 + engs[0].get_lanes()) if (job_path and not options.lmm and engs) else 2
     if options.load_packed:
         blocks = iter_packed_blocks_cached(p, options.load_packed, options.min_af, options.max_af, job_block,
                                            want_patterns=bool(options.output_patterns), want_samples=options.print_samples,
-                                           raw=job_path, device=(engs[0].device if job_path else None), ahead=job_ahead)
+                                           raw=job_path, device=(engs[0].device if (job_path and engs) else None), ahead=job_ahead)
     elif native and len(kmer_files) > 1:
         blocks = iter_packed_blocks_native_multi(p, kmer_files, options.min_af, options.max_af, job_block,
                                                  want_patterns=bool(options.output_patterns), want_samples=options.print_samples, raw=job_path)
@@ -454,6 +471,11 @@ def main(argv=None):
     import collections
     import time as _time
     cli_timing = _route.debug("cli")
+
+    def json_load(path_):
+        import json as _json_
+        with open(path_) as fh_:
+            return _json_.load(fh_)
 
     def new_tm():
         return {"engine": 0.0, "sink": 0.0, "write": 0.0, "blocks": 0, "t0": _time.perf_counter(), "reader": 0.0, "queue": 0.0, "format": 0.0,
@@ -839,6 +861,24 @@ def main(argv=None):
     from . import _abi as _abi_mod
     _lib = _abi_mod.load()
     ru_loop0 = _res.getrusage(_res.RUSAGE_SELF); cpu_stage0 = _abi_mod.host_cpu_seconds(); t_loop0 = _time.perf_counter()
+
+    def task_cpu():
+        """(SEERHIP_DEBUG=cli) user / system CPU seconds of every thread of the process by name: /proc/self/task/*/stat"""
+        out = {}
+        try:
+            tck = float(os.sysconf("SC_CLK_TCK"))
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    st = open("/proc/self/task/%s/stat" % tid).read()
+                except (IOError, OSError):
+                    continue
+                comm = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (comm, int(f[11]) / tck, int(f[12]) / tck)
+        except Exception:
+            pass
+        return out
+    task0 = task_cpu() if cli_timing else {}
     thread_cpu = {}                                        # CPU seconds of the Python threads of the block loop, by role (time.thread_time)
     # a packed cache through the job stream: the block loop runs inside the library, one call per device (SEERHIP_ROUTE job=py: the loop in
     # Python, as round 5 had it and as text input still has it)
@@ -846,7 +886,70 @@ def main(argv=None):
                          and (patterns is None or has_fd(patterns)))
     if packed_c_loop:
         check_packed_cache(p, options.load_packed)
-    if len(engs) > 1 and options.load_packed:
+    if proc_mode:
+        import pickle
+        import shutil
+        import subprocess
+        import tempfile
+        check_packed_cache(p, options.load_packed)
+        G = len(devs_)
+        state_dir = tempfile.mkdtemp(prefix="pyseer_amd_job_")
+        try:
+            arrays = {}
+            st_ = {"n": len(p), "lmm": bool(options.lmm), "devices": devs_, "continuous": bool(options.continuous), "filter_pvalue": options.filter_pvalue,
+                   "lrt_pvalue": options.lrt_pvalue, "no_dedup": bool(options.no_dedup), "min_af": options.min_af, "max_af": options.max_af,
+                   "print_filtered": bool(options.print_filtered), "lineage_labels": (list(lineage_dict) if options.lineage else None),
+                   "lineage_per_variant": bool(options.lmm_lineage_per_variant), "patterns": patterns is not None,
+                   "sample_names": ([str(x) for x in p.index] if options.print_samples else None), "job_block": int(job_block),
+                   "dma": _route.route("dma", "1") != "0", "path": os.path.abspath(options.load_packed)}
+            if options.lmm:
+                arrays.update(U=lmm.U, S=lmm.S, Y=lmm.Y, X=lmm.X); st_["h2"] = float(h2)
+            else:
+                arrays.update(y=np.asarray(p.values, dtype=float), W=covariate_block(len(p), m, cov))
+                st_["llf"] = float("nan") if options.continuous else float(null_fit.llf)
+                st_["firth_null"] = None if options.continuous else float(firth_null)
+            if options.lineage:
+                arrays.update(lin=np.asarray(lineage_clusters, dtype=float), lin_cov=(np.asarray(cov.values, dtype=float) if cov.shape[1] > 0 else np.zeros((0, 0))))
+            np.savez(os.path.join(state_dir, "arrays.npz"), **arrays)
+            with open(os.path.join(state_dir, "state.pkl"), "wb") as fh:
+                pickle.dump(st_, fh)
+            sys.stdout.flush()
+            env_c = dict(os.environ)
+            env_c["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env_c.get("PYTHONPATH", "")
+            t_children0 = _time.perf_counter()
+            kids = [subprocess.Popen([sys.executable, "-m", "pyseer_amd._packed_child", state_dir, str(i)], env=env_c,
+                                     stdout=(None if i == 0 else subprocess.DEVNULL), stderr=subprocess.PIPE) for i in range(G)]
+            # (like the reference's and the single-device run's, the output of a run that fails is partial: what part 0 had printed)
+            errs_c = [k_.communicate()[1].decode() for k_ in kids]
+            for i, k_ in enumerate(kids):
+                for line in errs_c[i].splitlines():
+                    if line.startswith("No observations of ") or line.startswith("pyseer_amd:"):
+                        sys.stderr.write(line + "\n")
+            bad = [i for i, k_ in enumerate(kids) if k_.returncode != 0]
+            if bad:
+                sys.stderr.write(errs_c[bad[0]][-4000:])
+                _die("pyseer_amd: the stream of device %d failed; the output is partial\n" % devs_[bad[0]])
+            results = [json_load(os.path.join(state_dir, "result_%d.json" % i)) for i in range(G)]
+            for i in range(1, G):                          # the parts, in the order of the input
+                with open(os.path.join(state_dir, "out_%d.tsv" % i), "rb") as fh:
+                    shutil.copyfileobj(fh, sys.stdout.buffer if hasattr(sys.stdout, "buffer") else sys.stdout, 1 << 22)
+            if patterns is not None:
+                patterns.flush()
+                for i in range(G):
+                    with open(os.path.join(state_dir, "pat_%d.txt" % i), "rb") as fh:
+                        shutil.copyfileobj(fh, patterns, 1 << 22)
+            prefilter, tested, printed = (sum(r_[k_] for r_ in results) for k_ in ("prefilter", "tested", "printed"))
+            tms = []
+            for i, r_ in enumerate(results):
+                tm_ = new_tm(); tm_.update(blocks=r_["blocks"], rows=r_["prefilter"] + r_["tested"], loop=r_["wall_s"], engine=r_["wall_s"], overlap=True, job=True)
+                tms.append(tm_)
+                thread_cpu["device %d process (block loop, user + sys)" % devs_[i]] = r_["user_s"] + r_["sys_s"]
+            child_budget = {"user_s": sum(r_["user_s"] for r_ in results), "sys_s": sum(r_["sys_s"] for r_ in results),
+                            "stages": {k_: sum(r_["library_stage_cpu_s"].get(k_, 0.0) for r_ in results) for k_ in results[0]["library_stage_cpu_s"]},
+                            "wall_s": max(r_["wall_s"] for r_ in results), "launch_to_join_s": _time.perf_counter() - t_children0}
+        finally:
+            shutil.rmtree(state_dir, ignore_errors=True)
+    elif len(engs) > 1 and options.load_packed:
         import shutil
         import tempfile
         import threading as _th
@@ -907,7 +1010,10 @@ def main(argv=None):
         prefilter, tested, printed = (sum(c[j] for c in counts) for j in range(3))
     elif packed_c_loop:
         t_th = _time.thread_time()
-        prefilter, tested, printed = run_stream_packed(engs[0], (0, 1), sys.stdout.buffer if hasattr(sys.stdout, "buffer") else sys.stdout, patterns, tms[0])
+        part01 = (0, 1)
+        if options.packed_part:
+            part01 = tuple(int(x) for x in options.packed_part.split("/"))
+        prefilter, tested, printed = run_stream_packed(engs[0], part01, sys.stdout.buffer if hasattr(sys.stdout, "buffer") else sys.stdout, patterns, tms[0])
         thread_cpu["stream 0 loop thread"] = _time.thread_time() - t_th
     elif job_path:
         t_th = _time.thread_time()
@@ -921,12 +1027,20 @@ def main(argv=None):
         # thread: getrusage) over the loop, the library's own per-stage thread CPU (csrc/host_pool.h), the loop threads' CPU (time.thread_time)
         ru1 = _res.getrusage(_res.RUSAGE_SELF); st1 = _abi_mod.host_cpu_seconds()
         rows_all = sum(tm_["rows"] for tm_ in tms)
-        budget = {"rows": int(rows_all), "wall_s": _time.perf_counter() - t_loop0, "streams": len(tms), "job_path": bool(job_path),
+        if proc_mode:                                      # the block loops ran in the devices' processes: their own rusage over their loops
+            ru1 = type("R", (), {"ru_utime": ru1.ru_utime + child_budget["user_s"], "ru_stime": ru1.ru_stime + child_budget["sys_s"]})()
+            st1 = {k_: st1.get(k_, 0.0) + child_budget["stages"].get(k_, 0.0) for k_ in set(st1) | set(child_budget["stages"])}
+        budget = {"rows": int(rows_all), "wall_s": (child_budget["wall_s"] if proc_mode else _time.perf_counter() - t_loop0), "streams": len(tms), "job_path": bool(job_path),
                   "host_cpus": int(_lib.sh_host_cpus()), "pool_workers": int(_lib.sh_host_pool_workers()),
                   "process_cpu_s": (ru1.ru_utime - ru_loop0.ru_utime) + (ru1.ru_stime - ru_loop0.ru_stime),
                   "process_user_s": ru1.ru_utime - ru_loop0.ru_utime, "process_sys_s": ru1.ru_stime - ru_loop0.ru_stime,
                   "library_stage_cpu_s": {k_: st1[k_] - cpu_stage0.get(k_, 0.0) for k_ in st1},
                   "loop_thread_cpu_s": thread_cpu}
+        by_name = {}
+        for tid, (comm, ut, stt) in task_cpu().items():
+            u0, s0 = task0.get(tid, (comm, 0.0, 0.0))[1:]
+            a = by_name.setdefault(comm, [0, 0.0, 0.0]); a[0] += 1; a[1] += ut - u0; a[2] += stt - s0
+        budget["threads_by_name"] = {k_: {"threads": v_[0], "user_s": round(v_[1], 3), "sys_s": round(v_[2], 3)} for k_, v_ in by_name.items() if v_[1] + v_[2] >= 0.01}
         import json as _json
         sys.stderr.write("[cli budget] " + _json.dumps(budget) + "\n")
     if cli_timing:

@@ -108,6 +108,7 @@ class HostPool {
     static void work(Job *j) { for (;;) { const int64_t i0 = j->next.fetch_add(j->chunk); if (i0 >= j->n) return; const int64_t i1 = std::min(j->n, i0 + j->chunk); for (int64_t i = i0; i < i1; ++i) (*j->fn)(i); } }
     Job *pick() { for (Job *x : jobs) if (x->active < x->want && x->next.load(std::memory_order_relaxed) < x->n) return x; return nullptr; }   // (mu held)
     void worker() {
+        pthread_setname_np(pthread_self(), "sh-pool");
         for (;;) {
             Job *j = nullptr;
             { std::unique_lock<std::mutex> lk(mu); cv_work.wait(lk, [&] { return quit || (j = pick()) != nullptr; }); if (quit) return; ++j->active; }

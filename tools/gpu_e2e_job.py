@@ -107,6 +107,46 @@ def run(name, extra, env_more):
     return e
 
 
+def run_procs(name, extra, env_more, nproc=8):
+    """The same job as `nproc` PROCESSES side by side, each over its own range of the cache (--packed-part i/n) on the one device: what one
+    process per GPU of an 8-GPU node costs the host (separate address spaces: no shared lock under page faults and hipHostRegister)."""
+    env = dict(env0); env.update(env_more)
+    model = (["--no-distances", "--covariates", d + "/cov.tsv", "--use-covariates"] + ["%dq" % j for j in range(2, 12)]) if FIXED else ["--lmm", "--load-lmm", d + "/lmm.npz"]
+    t0 = time.time()
+    procs = []
+    for i in range(nproc):
+        out = d + "/out_%s_%d.tsv" % (name, i)
+        procs.append((subprocess.Popen([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv"] + model +
+                                       ["--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup", "--packed-part", "%d/%d" % (i, nproc)] + EXTRA + extra,
+                                       env=env, stdout=open(out, "w"), stderr=subprocess.PIPE), out))
+    errs = [p_.communicate()[1].decode() for p_, _ in procs]
+    dt = time.time() - t0
+    h = hashlib.md5(); nbytes = 0
+    for i, (p_, out) in enumerate(procs):
+        with open(out, "rb") as f:
+            if i:
+                f.readline()                                  # (every process prints the header)
+            for c in iter(lambda: f.read(1 << 24), b""):
+                h.update(c); nbytes += len(c)
+    budgets = [json.loads([l for l in e_.splitlines() if l.startswith("[cli budget] ")][-1][len("[cli budget] "):]) for e_ in errs]
+    rows = sum(b["rows"] for b in budgets); cpu = sum(b["process_cpu_s"] for b in budgets); wall = max(b["wall_s"] for b in budgets)
+    stages = {}
+    for b in budgets:
+        for k, v in b["library_stage_cpu_s"].items():
+            stages[k] = stages.get(k, 0.0) + v
+    m = rows / 1e6
+    e = {"rc": max(p_.returncode for p_, _ in procs), "processes": nproc, "wall_s": dt, "output_bytes": nbytes, "md5": h.hexdigest(), "loop_rows_per_s": rows / wall,
+         "cpu_s_per_million_rows": dict({"process_total": cpu / m, "process_user": sum(b["process_user_s"] for b in budgets) / m,
+                                         "process_sys": sum(b["process_sys_s"] for b in budgets) / m}, **{"library_" + k: v / m for k, v in stages.items() if v}),
+         "cpus_needed_at_8x33M_rows_per_s": cpu / m * 8 * 33.0, "threads_by_name": [b.get("threads_by_name") for b in budgets][:2]}
+    res["runs"][name] = e
+    print("%s: rc %d, %.2f s wall; loops %.3g rows/s together; block loops %.3f CPU-s = %.4f CPU-s per million rows -> %.1f CPUs at 8 x 33 M rows/s (quota %s); output %d bytes" % (
+        name, e["rc"], dt, e["loop_rows_per_s"], cpu, cpu / m, e["cpus_needed_at_8x33M_rows_per_s"], quota, nbytes), flush=True)
+    if e["rc"]:
+        print(errs[0][-2000:])
+    return e
+
+
 WHICH = os.environ.get("E2E_RUNS", "r04sink_1ctx,job_1ctx,r04sink_8ctx,job_8ctx").split(",")      # + job_8ctx_spin: the runtime's default (spinning) waits
 for lrt, tag in [x.split(":") for x in os.environ.get("E2E_LRT", "1e-3:lrt1e-3,1:lrt1").split(",")]:
     L = ["--lrt-pvalue", lrt]
@@ -120,11 +160,16 @@ for lrt, tag in [x.split(":") for x in os.environ.get("E2E_LRT", "1e-3:lrt1e-3,1
             rt.append("wait=spin")
         if w_.endswith("_staged"):
             rt.append("dma=0")
+        if "_threads" in w_:                               # the devices' streams as threads of one process (round 5) instead of one process each
+            rt.append("procs=0")
         if "_py" in w_:                                    # round 5's loop: the job stream driven block by block from Python
             rt.append("job=py")
         if "_lanes1" in w_:
             rt.append("lanes=1")
         env_more = {"SEERHIP_ROUTE": ",".join(rt)} if rt else {}
+        if "8proc" in w_:
+            md5.add(run_procs(w_ + "_" + tag, L, env_more)["md5"])
+            continue
         md5.add(run(w_ + "_" + tag, extra, env_more)["md5"])
     res["identical_" + tag] = len(md5) == 1
     print("outputs identical (%s): %s" % (tag, res["identical_" + tag]), flush=True)
