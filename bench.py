@@ -38,7 +38,7 @@ GLM_KERNELS = {False: "k_glm_fast<Q,true> (prefilter, routing) + k_glm_bitdot + 
                      "k_firth_step2 (exact two-pass rounds) for the fits that leave the fast passes"}
 FP64_FLOP_PER_TEST = 5.0e7         # 2*k*N + 6k fp64 flop of the reference formulation, k=4999
 ALGO_BYTES_PER_TEST = 673          # ceil(N/8) in + 48 out
-PROFILE_DIRS = ("r05", "r04", "r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
+PROFILE_DIRS = ("r06", "r05", "r04", "r03", "r02", "r01")      # committed rocprofv3 summaries, newest first
 
 
 # ---------------------------------------------------------------------------------------------------------------
