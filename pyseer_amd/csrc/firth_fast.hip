@@ -531,7 +531,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     // log-likelihood, I = I(null) + the matrix-core sum of (w - w0) m2 (~1e-7 on log det), in the reference's columns (det I = det I_s prod s_j^2);
     // I11 = sum w k in fp64 (the complement's: I00 - I11').  A last step above 1e-7 keeps the exact evaluation, and so does a fit whose weights
     // have moved far from the null model's (rho > FF_RHO: a strong effect): the matrix-core sum's 1e-6 then shows in log det I at ~1e-6 rho.
-    if (last && fin && dmax <= 1e-7 && rho <= FF_RHO && !(FF_ABL & 8)) {
+    if (last && fin && dmax <= FF_FIN_TOL && rho <= FF_RHO && !(FF_ABL & 8)) {
         double lsd = 0.0;
 #pragma unroll
         for (int j = 0; j < Q; ++j) lsd += log(P.wstd[Q + j]);

@@ -16,6 +16,9 @@ typedef double ff_v2d __attribute__((ext_vector_type(2)));
 #ifndef FF_TAU
 #define FF_TAU 1e-7                /* an increase of the one-pass F beyond this leaves for the exact rounds, whose comparison is the reference's own.  = the evaluation noise of the one-pass F (the matrix-core part of log det: ~1e-6 rho, rho <= 0.05).  Round 6: 1e-5 -> 1e-7 at the same rate (profiles/r06/ab_ff_tau.txt); the reference itself never halves on a rise between F's rounding noise and 1e-5 (profiles/r06/firth_subtau_search.txt) */
 #endif
+#ifndef FF_FIN_TOL
+#define FF_FIN_TOL 1e-7            /* a fit whose LAST step (any coordinate) is at most this is finished in the pass that found it (F to second order, I11 as it is) */
+#endif
 #ifndef FF_ABL
 #define FF_ABL 0                   /* timing ablations (results meaningless): 1 = no MFMAs, 2 = no LDS-DMA / barriers, 4 = no sample arithmetic; 8 (results valid) = every fit finished by the exact kernel */
 #endif

@@ -24,12 +24,17 @@ typedef float ffw_v4f __attribute__((ext_vector_type(4)));
 #define FFW_ABL 0                  /* timing ablations of k_firth_fastw_fin (results meaningless): 1 = no carrier count, 2 = no contraction */
 #endif
 
+#ifndef FFW_RHO2
+#define FFW_RHO2 0.03
+#define FFW_NOISE 1.5e-7
+#define FFW_KB_REL 1e-7
+#endif
 template <int Q> struct FFW {
     typedef FFC<Q> C;
     static constexpr int T2H = (C::N2 + 15) / 16, T3H = (C::N3 + 15) / 16, NTA = T2H + T3H;   // 16-row tiles of the degree-2 / degree-3 tables
     static constexpr int NACC = 2 * T2H + T3H + 1, AWK = 2 * T2H + T3H;                        // (w - w0).m2, c.m3, c k.m2, (w - w0) k.(1, z)
     static constexpr int RS = (Q + 2 + 3) & ~3;            // floats per sample record: z_s[Q], s = 1 - 2 y (0 behind sample N), -2^12 w0; padded to 16 bytes
-    static constexpr int ROWS = NACC * 16 + 16;            // hand-over rows per fit: the accumulator tiles' rows, then -score[PC], I11
+    static constexpr int ROWS = NACC * 16 + 32;            // hand-over rows per fit: the accumulator tiles' rows, then -score[PC] and I11 (hi), then their lo parts
     static constexpr int REC_PIECES = (32 * RS * 4 + 1023) / 1024, NPIECE = NTA + REC_PIECES, STAGE = NPIECE * 1024;
     static constexpr int NPW = (NPIECE + 7) / 8;           // 1 KB LDS-DMA pieces per wavefront and stage (8 wavefronts; the last ones repeat the last piece)
     static constexpr int NRING = 3;
@@ -39,7 +44,7 @@ extern "C" int shk_firth_fastw_layout(int Q, int *t2h, int *t3h, int *rs, int *r
 {
     const int z1 = Q + 1, n2 = ff_tri(z1), n3 = ff_tet(z1);
     *t2h = (n2 + 15) / 16; *t3h = (n3 + 15) / 16; *rs = (Q + 2 + 3) & ~3;
-    *rows = (2 * *t2h + *t3h + 1) * 16 + 16;
+    *rows = (2 * *t2h + *t3h + 1) * 16 + 32;
     return 0;
 }
 
@@ -95,8 +100,12 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = ffw_v4f{0.0f, 0.0f, 0.0f, 0.0f};
     float nU[PC], Ik0 = 0.0f;                               // -score = sum (mu - y) x;  I11 = sum w k
+    // (round 6) summed in single precision within a group (8 samples of this lane) and in double precision across groups: 1 250 float additions
+    // per lane at a running sum of ~20 put 1e-7 on the step of a rare variant (V_11 ~ bse^2 = 0.04) -- nothing for a FIRST pass, whose point is
+    // 1e-5 from the fit anyway, but a second single-precision pass (firth_first32=2) must land within 1e-7 for the fp64 pass behind it to finish the fit
+    double nUd[PC], Ik0d = 0.0;
 #pragma unroll
-    for (int a = 0; a < PC; ++a) nU[a] = 0.0f;
+    for (int a = 0; a < PC; ++a) { nU[a] = 0.0f; nUd[a] = 0.0; }
 
     extern __shared__ __attribute__((aligned(16))) char ffw_lds[];
     char *const lds = ffw_lds;
@@ -210,6 +219,9 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
             const uint32_t pm = pair_mask(byte, pp);
             Pw[pp] = Bw[pp]; Pc[pp] = Bc[pp]; Pk[pp] = Bc[pp] & pm; Px[pp] = Bw[pp] & pm;
         }
+#pragma unroll
+        for (int a = 0; a < PC; ++a) { nUd[a] += (double)nU[a]; nU[a] = 0.0f; }
+        Ik0d += (double)Ik0; Ik0 = 0.0f;
         // this wavefront's share of the next stage has landed (the one after it may be in flight); the bare barrier: everyone's has, and
         // everyone is done reading this stage
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
@@ -227,17 +239,21 @@ void k_firth_fast32w(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, 
     }
     // ---- hand-over: a lane's registers are rows 4 kq .. + 3 of every 16-row tile of its variant; the four quarters' vector sums are added here
 #pragma unroll
-    for (int a = 0; a < PC; ++a) { nU[a] += __shfl_xor(nU[a], 16); nU[a] += __shfl_xor(nU[a], 32); }
-    Ik0 += __shfl_xor(Ik0, 16); Ik0 += __shfl_xor(Ik0, 32);
+    for (int a = 0; a < PC; ++a) { nUd[a] += __shfl_xor(nUd[a], 16); nUd[a] += __shfl_xor(nUd[a], 32); }
+    Ik0d += __shfl_xor(Ik0d, 16); Ik0d += __shfl_xor(Ik0d, 32);
     if (!live) return;
 #pragma unroll
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ws[(int64_t)(t * 16 + 4 * kq + r) * ws_cap + li] = acc[t][r];
-    if (kq == 0) {
+    if (kq == 0) {                                          // hi + lo floats (the workspace is a float array)
 #pragma unroll
-        for (int a = 0; a < PC; ++a) ws[(int64_t)(NACC * 16 + a) * ws_cap + li] = nU[a];
-        ws[(int64_t)(NACC * 16 + PC) * ws_cap + li] = Ik0;
+        for (int a = 0; a <= PC; ++a) {
+            const double x = a < PC ? nUd[a] : Ik0d;
+            const float hi = (float)x;
+            ws[(int64_t)(NACC * 16 + a) * ws_cap + li] = hi;
+            ws[(int64_t)(NACC * 16 + 16 + a) * ws_cap + li] = (float)(x - (double)hi);
+        }
     }
 }
 
@@ -321,8 +337,8 @@ __global__ __launch_bounds__(64) void k_firth_fastw_fin(const uint64_t *__restri
     const bool flip = 2 * carriers > N;
     double nUd[PC];
 #pragma unroll
-    for (int a = 0; a < PC; ++a) nUd[a] = (double)ws[(int64_t)(W::NACC * 16 + a) * ws_cap + li];
-    const double Ik0d = (double)ws[(int64_t)(W::NACC * 16 + PC) * ws_cap + li];
+    for (int a = 0; a < PC; ++a) nUd[a] = (double)ws[(int64_t)(W::NACC * 16 + a) * ws_cap + li] + (double)ws[(int64_t)(W::NACC * 16 + 16 + a) * ws_cap + li];
+    const double Ik0d = (double)ws[(int64_t)(W::NACC * 16 + PC) * ws_cap + li] + (double)ws[(int64_t)(W::NACC * 16 + 16 + PC) * ws_cap + li];
     // ---- I in the standardised basis (design order 0 = 1, 1 = k, 2.. = z), its factor, V ----------------------------------------------------
     const float unscale = (float)(1.0 / FF_SCALE);
     double I[NH];
@@ -394,11 +410,47 @@ __global__ __launch_bounds__(64) void k_firth_fastw_fin(const uint64_t *__restri
         for (int a = 0; a < PC; ++a) { const double dd = cand[a] - fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s]; sn = fma(dd, dd, sn); }
         sn = sqrt(sn);
     }
+    // A SECOND single-precision pass (iter == 0 on entry) leaves ~1e-7 of its own arithmetic in the point it forms, and the fit's remaining
+    // passes shrink that by the iteration's linear rate each -- 1e-3 .. 2e-2 for most fits, so that the ONE fp64 pass behind it ends within
+    // 1e-9 of the exact rounds' answer.  A fit that contracts slowly (quasi-separated: rate 0.1 .. 0.3) would keep 3e-8 of it: where this
+    // pass' step is more than FFW_RHO2 of the previous one the pass is discarded -- state untouched, the fp64 pass takes it over from the
+    // same candidate, as in round 5.
+    // The same for a fit whose kbeta is so small that what is left shows RELATIVE to it (the reference-made rows hold kbeta to 1e-6 relative
+    // with no absolute slack: kbeta = 7.5e-4 allows 7.5e-10): this pass leaves ~FFW_NOISE sqrt(V_11) on kbeta (every carrier's mu - y rounded to
+    // float, summed over the carriers, through V_11 ~ 1 / (carriers w)), the fp64 pass a fraction max(rate, 0.02) of that; where that exceeds
+    // FFW_KB_REL |kbeta| -- one fit in fifty -- the pass is discarded too.
+    if (iter == 0 && fin) {
+        double dn = 0.0;
+#pragma unroll
+        for (int a = 0; a < PC; ++a) dn = fma(d[a], d[a], dn);
+        const double rate = sqrt(dn) / fmax(sn, 1e-300);
+        const double v11 = fabs(Vm[sidx(1, 1)]);
+        const bool slow = !(rate <= FFW_RHO2);
+        const bool small = fmax(rate, 0.02) * FFW_NOISE * sqrt(v11) > FFW_KB_REL * fabs(cand[1] + d[1]);
+        if (slow || small) { list_push(true, next_fast, next_fast_count, s); return; }
+    }
     iter = iter < 0 ? 0 : iter + 1;
+    // The pass evaluated the model at cand ROUNDED to float (in the standardised basis: k_firth_fast32w's bs), and the step it found leads
+    // to the fit from THERE: the new candidate is that rounded point + d.  (cand + d carried the rounding, 6e-8 |beta|, into the next point --
+    // nothing after a first pass, 1e-7 too much after a second one.)  The same arithmetic as the pass' prologue, then its inverse.
+    double base[PC];
+    {
+        double b0 = cand[0];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { base[2 + j] = (double)(float)(cand[2 + j] * P.wstd[Q + j]) / P.wstd[Q + j]; b0 = fma(cand[2 + j], P.wstd[j], b0); }
+        double b1 = cand[1];
+        if (flip) { b0 += b1; b1 = -b1; }
+        const double r0 = (double)(float)b0, r1 = (double)(float)b1;
+        base[1] = flip ? -r1 : r1;
+        double o0 = flip ? r0 - base[1] : r0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) o0 = fma(-base[2 + j], P.wstd[j], o0);
+        base[0] = o0;
+    }
 #pragma unroll
     for (int a = 0; a < PC; ++a) {
         fw.st[(int64_t)(fw_beta<PC>() + a) * cap + s] = cand[a];
-        fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = fin ? cand[a] + d[a] : cand[a];
+        fw.st[(int64_t)(fw_cand<PC>() + a) * cap + s] = fin ? base[a] + d[a] : cand[a];
     }
     fw.iter[s] = iter; fw.halv[s] = 0;
     const bool last = iter > 0 && sn < 1e-4;

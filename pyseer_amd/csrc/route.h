@@ -20,7 +20,7 @@
 //   ll_first=0       [1]  score pass first, likelihood pass last
 //   newton=1         [0]  every variant through the all-fp64 kernel (the reference's trajectory)
 //   firth_last=0     [1]  Firth rounds: the last likelihood pass taken instead of carried over the last step
-//   firth_first32=0  [1]  one-pass Firth: the first pass in fp64 like the others
+//   firth_first32=n  [2]  one-pass Firth: how many of the first passes run in single precision (0: all fp64; 1: round 5; 2: then ONE fp64 pass finishes)
 //   afcompact=M      [1]  0: never compact AF / prefilter-rejected rows before the kernels, 2: always
 //   complement=0     [1]  LMM: rows with more than N/2 carriers stored as given
 //   reader_slab=B, reader_pad=B   reader: bytes per decoded slab / carried over between slabs

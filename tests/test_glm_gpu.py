@@ -742,7 +742,9 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     # two: the exact rounds;  one: the one-pass kernels, their single-precision first pass at two wavefronts per SIMD (firth_fast_w.hip: 16-row
     # tiles, 16 variants per wavefront, sums handed to a per-fit kernel);  one_w0: that pass at one wavefront per SIMD (firth_fast.hip, round 4)
     # one_f64: every pass of the one-pass kernel in fp64, the first included (route key firth_first32)
-    for mode, route in (("two", "firth_fast=0"), ("one", None), ("one_w0", "firth_w=0"), ("one_f64", "firth_first32=0")):
+    # one_r5: round 5's sequence -- ONE single-precision pass, then two fp64 passes (since round 6 the default is two single-precision passes at
+    # two wavefronts per SIMD and ONE fp64 pass, which finishes the fit: its last step is ~1e-8)
+    for mode, route in (("two", "firth_fast=0"), ("one", None), ("one_w0", "firth_w=0"), ("one_f64", "firth_first32=0"), ("one_r5", "firth_first32=1")):
         if route is None:
             monkeypatch.delenv("SEERHIP_ROUTE", raising=False)
         else:
@@ -752,9 +754,13 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
     a = out["two"]
     ok = np.isfinite(a["kbeta"])
     assert ok.sum() > V // 2
-    for mode in ("one", "one_w0", "one_f64"):
+    for mode in ("one", "one_w0", "one_f64", "one_r5"):
         b = out[mode]
-        assert np.array_equal(a["flags"], b["flags"]), (mode, np.where(a["flags"] != b["flags"])[0][:10])
+        # (bit 18, SH_FLAG_FIRTH_SENSITIVE, is informational: "the stop rule was met within 1e-8 of its limit" may fall either way between two
+        # arithmetic orders -- at most a couple of rows; every other bit is held exactly)
+        assert int(((a["flags"] ^ b["flags"]) >> 18 & 1).sum()) <= 2, mode
+        df_ = np.where((a["flags"] & ~np.uint32(1 << 18)) != (b["flags"] & ~np.uint32(1 << 18)))[0]
+        assert df_.size == 0, (mode, df_[:10], [hex(int(x)) for x in a["flags"][df_[:10]]], [hex(int(x)) for x in b["flags"][df_[:10]]], a["kbeta"][df_[:10]], b["kbeta"][df_[:10]])
         assert np.array_equal(ok, np.isfinite(b["kbeta"])), mode
         dev = {f: float(np.max(np.abs(b[f][ok] - a[f][ok]) / np.maximum(np.abs(a[f][ok]), 1e-300))) for f in ("pvalue", "bse")}
         # kbeta in units of the test's own tolerance (1e-6 relative or 2e-8 absolute): |d| / (1e-6 |kbeta| + 2e-8)
@@ -768,7 +774,10 @@ def test_one_pass_firth_equals_the_two_pass_rounds(N, q, V, monkeypatch):
         close(b["betas"][ok], a["betas"][ok], rtol=1e-6, atol=2e-8, what="betas")
         # measured on the C4 workload (profiles/r04/firth_fast_check_q10.json, 259 560 fits): kbeta 4.9e-9 absolute, bse 2.3e-8, p 1.0e-8;
         # the ceilings here leave a factor ~10 on this test's harsher rows (real effects, rare and majority carriers)
-        assert dev["kbeta_tol_units"] <= 0.25 and dev["bse"] <= 3e-7 and dev["pvalue"] <= 1.5e-7, (mode, dev)
+        # round 6 (two single-precision passes, then ONE fp64 pass): a rare variant (55 .. 70 carriers: V_11 ~ 0.08) keeps up to 1e-8 of the second
+        # single-precision pass' arithmetic (each carrier's mu - y rounded to float), shrunk once by the iteration's rate instead of twice:
+        # 0.33 of the tolerance on this test's rows, 0.41 on the worst of 259 560 C4 fits (tools/gpu_firth_n32_diag.py; round 5's sequence: 0.31)
+        assert dev["kbeta_tol_units"] <= (0.5 if mode == "one" else 0.25) and dev["bse"] <= 3e-7 and dev["pvalue"] <= 1.5e-7, (mode, dev)
 
 
 def test_contexts_on_one_device_run_concurrently_and_agree_bit_for_bit():
