@@ -342,7 +342,7 @@ def glm_roofline(cfg, q, Vs, kern_s, klaunch, rb):
 def glm_metric(cfg, N):
     force = cfg == "C4"
     return ("k-mer tests/sec at N=%d samples (fixed effects: %s), whole job" % (N, "Firth" if force else "logistic"),
-            "f64 (eta, likelihood, score, solves) + f16 hi/lo MFMA with fp32 accumulation (information matrix, third-moment tensor of the penalty); f32 for the first of the ~3 passes (its step is 1e-5 from the fit at best); f64 throughout for the fits the exact kernels take" if force
+            "f64 (eta, likelihood, score, solves) + f16 hi/lo MFMA with fp32 accumulation (information matrix, third-moment tensor of the penalty); f32 for the first two of the three passes (round 6: sums in f64 across groups; the second is discarded where a fit contracts slowly or its kbeta is small against what it leaves); f64 throughout for the fits the exact kernels take" if force
             else "f64 (eta, score, likelihood, the last Newton step, solves); the final information matrix = the null model's matrix and the carrier sums in exact f64 / int8 limbs + the DIFFERENCES w - w0 summed in f32 (f16 hi/lo MFMA products, fp32 accumulation; the variant's row per 64-sample word in f32, across words in f64); f32 / f16-MFMA Hessians in the Newton steering passes")
 
 
