@@ -25,6 +25,7 @@ def main():
     from .engine import Engine, Job
     lib = _abi.load()
     lib.sh_set_wait_mode(0 if _route.route("wait") == "spin" else 1)
+    lib.sh_set_host_streams(len(st["devices"]))                # this process is one of that many: its share of the CPU budget and of the pinning budget
     dev = st["devices"][i]
     e = Engine(st["n"], device=dev)
     if st["lmm"]:
