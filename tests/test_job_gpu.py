@@ -382,3 +382,35 @@ def test_the_librarys_own_block_loop_over_a_packed_cache(lmm, tmp_path):
         job.run_packed(path, (0, 1), 1000, out_fd=os.open(os.devnull, os.O_WRONLY))
     assert "truncated packed cache" in str(ei.value)
     job.close(); e.close()
+
+
+def test_the_block_loop_on_edge_caches(tmp_path):
+    """sh_job_run_packed on the edges: a cache without a single block, one stored block shared out to three parts (two of them own nothing),
+    and more parts than rows -- counters zero where nothing is owned, the parts still concatenate to the whole."""
+    from pyseer_amd.engine import Job
+    from pyseer_amd.input import PackedCacheWriter
+    N = 300
+    e = _setup(True, N, pret=1.0, lrtt=1.0)
+    names = ["s%d" % i for i in range(N)]
+
+    def run(path, part):
+        job = Job(e, True, True)
+        fo = str(tmp_path / "o.tsv")
+        with open(fo, "wb") as a:
+            c = job.run_packed(path, part, 1000, out_fd=a.fileno())
+        job.close()
+        return open(fo, "rb").read(), c
+    empty = str(tmp_path / "empty.seerpack")
+    PackedCacheWriter(empty, names).close()
+    assert run(empty, (0, 1)) == (b"", (0, 0, 0, 0)) and run(empty, (2, 3)) == (b"", (0, 0, 0, 0))
+    one = str(tmp_path / "one.seerpack")
+    w = PackedCacheWriter(one, names)
+    bits, counts, blob, off = _rows(N, 5, 901)
+    w.write_block(blob, off, counts, bits); w.close()
+    whole = run(one, (0, 1))
+    assert whole[1][3] == 1 and whole[1][0] + whole[1][1] == 5 and whole[0].count(b"\n") == 5
+    for n in (3, 8):
+        parts = [run(one, (i, n)) for i in range(n)]
+        assert b"".join(p[0] for p in parts) == whole[0]
+        assert sum(p[1][3] for p in parts) == 1 and sum(1 for p in parts if p[1][3] == 0) == n - 1
+    e.close()
