@@ -849,6 +849,10 @@ def main():
                     "C4": fixed_effects_line("C4", dev, local, cpu=cpu, parity=not args.no_parity),
                     "C4_literal": fixed_effects_line("C4", dev, local, cpu=False, parity=not args.no_parity, env={"SEERHIP_ROUTE": "firth_literal=1"}),
                     "C2": fixed_effects_line("C2", dev, local, steps=3, cpu=cpu, parity=not args.no_parity),
+                    # a caller that holds ONE batch at a time (no lanes to fill): what a large call buys -- the `synchronous` entry of these two is
+                    # one sh_glm_batch_dev of 2^20 rows per step on one stream, beside the same rows through the lanes
+                    "C2N5000_calls_of_2e20_rows": fixed_effects_line("C2N5000", dev, local, steps=3, Vs=1 << 20, cpu=False, parity=not args.no_parity),
+                    "C4_calls_of_2e20_rows": fixed_effects_line("C4", dev, local, steps=3, Vs=1 << 20, cpu=False, parity=not args.no_parity),
                     "C3_five_limbs": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=5),
                     "C3_all_refined_56bit": lmm_variant_line(U, S, y, C, h2, dev, local, bits[:nb3], 3, limbs=0, tol=1e-300),
                     "C3_host_pointers_pcie_inclusive": lmm_host_pointer_line(U, S, y, C, h2, dev, local, bits[0], 4),
