@@ -442,7 +442,8 @@ def main(argv=None):
     # (--lineage, round 6: fit_lineage_effect runs inside the stream, for printed rows -- sh_job_set_lineage.  The LMM's lineage is that of each
     # block's LAST variant (pyseer/lmm.py:209-213, the stale `k`), so its blocks must end where the reference's do: no coalescing)
     lmm_block_lineage = bool(options.lineage and options.lmm and not options.lmm_lineage_per_variant)
-    job_block = options.block_size if (options.print_filtered or lmm_block_lineage or not job_path) else max(options.block_size, 1 << 16)
+    # (2^18 rows: a call of 2^16 runs the LMM 7 % slower, the logistic path 27 %, Firth 15 % -- profiles/r06/rows_per_call.txt; round 5 had 2^16)
+    job_block = options.block_size if (options.print_filtered or lmm_block_lineage or not job_path) else max(options.block_size, 1 << 18)
     # the reader runs as far ahead as the job stream holds blocks in flight (fixed effects: 2 + lanes, include/seerhip.h sh_job_depth)
     job_ahead = (2 + engs[0].get_lanes()) if (job_path and not options.lmm and engs) else 2
     if options.load_packed:

@@ -36,6 +36,8 @@
 //   reader=serial|zlib [par] container decoder of the native reader;  reader_threads=T  its parser workers
 //   wait=spin        [sleep], job=0 / py [1], dma=0 [1], procs=0 [1]   command line (pyseer_amd/__main__.py, input.py): host threads spin on the device; the
 //                    Python block loop instead of the job stream; rows through pinned slabs instead of DMA from the registered cache mapping
+//   dma_window=B     [1 GB] bytes of the packed-cache mapping registered for DMA at a time by the library's block loop (job_run.inc; small values:
+//                    many windows in a small cache)
 //   reader_chunk=B   [4 MB] most compressed bytes per region of the parallel gzip decoder (regions are sized for ~12 MB of text; small values:
 //                    many regions in a small file);  reader_workers=W  its decoding threads [2/3 of the reader's threads, at most 32]
 #pragma once
@@ -47,7 +49,7 @@ static inline const char *const *sh_route_keys()
 {
     static const char *const keys[] = {"chord", "chord_n32", "chord_enter", "bitdot", "first_bordered", "pk", "warm", "fin_rounds", "ll_first", "newton",
                                        "firth_last", "firth_first32", "afcompact", "complement", "reader_slab", "reader_pad", "reader_chunk", "reader_workers", "reader_depth", "reader_helpers", "reader_target",
-                                       "firth_literal", "firth_strict", "firth_fast", "firth_w", "lmm_limbs", "lmm_tol", "qf", "lanes", "reader", "reader_threads", "wait", "job", "dma", "procs", nullptr};
+                                       "firth_literal", "firth_strict", "firth_fast", "firth_w", "lmm_limbs", "lmm_tol", "qf", "lanes", "reader", "reader_threads", "wait", "job", "dma", "procs", "dma_window", nullptr};
     return keys;
 }
 // the route string in force for the calling thread: the environment's, or the one a parent context was set up under (lanes_api.inc)

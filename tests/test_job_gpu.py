@@ -374,6 +374,17 @@ def test_the_librarys_own_block_loop_over_a_packed_cache(lmm, tmp_path):
         assert b"".join(x[0] for x in parts) == want[0] and b"".join(x[1] for x in parts) == want[1]
         assert tuple(sum(x[2][a] for x in parts) for a in range(3)) == want[2] and sum(x[3] for x in parts) == want[3]
     assert len(want[0]) > 1000 and len(want[1]) == 25 * want[2][1]
+    # several DMA windows in this small cache (route key dma_window: bytes registered at a time): merged groups whose stored blocks lie in two
+    # windows are copied range by range from both, a block that starts on the page a window ends on belongs to none and its group is staged
+    for window in (4096, 30000, 100000):
+        os.environ["SEERHIP_ROUTE"] = "dma_window=%d" % window
+        try:
+            for block_rows in (1, 1000, 4000):
+                assert by_library(block_rows) == by_python(block_rows), (window, block_rows)
+            parts = [by_library(4000, (i, 2)) for i in range(2)]
+        finally:
+            del os.environ["SEERHIP_ROUTE"]
+        assert b"".join(x[0] for x in parts) == want[0] and b"".join(x[1] for x in parts) == want[1]
     # a truncated cache: refused, with the iterator's message
     raw = open(path, "rb").read()
     open(path, "wb").write(raw[:len(raw) - 5000])

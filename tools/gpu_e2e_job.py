@@ -13,7 +13,8 @@ import bench
 from pyseer_amd.input import PackedCacheWriter
 from pyseer_amd.packing import row_bytes_for
 
-N = 5000; V = int(os.environ.get("V", 10_000_000)); BLK = int(os.environ.get("BLOCK", 262144))
+N = 5000; V = int(os.environ.get("V", 10_000_000)); BLK = int(os.environ.get("BLOCK", 262144))       # BLOCK=0: the command line's own default
+STORED = int(os.environ.get("STORED", 1 << 18))        # rows per stored block of the cache (round 5's --save-packed default wrote 2^16)
 FIXED = os.environ.get("E2E_MODEL", "lmm") == "fixed"        # the fixed-effects job (logistic, 10 covariates: bench.py's C2N5000 workload) instead of --lmm
 d = os.environ.get("E2E_DIR", "/tmp/e2e_job"); os.makedirs(d, exist_ok=True)
 GPUS8 = os.environ.get("E2E_GPUS", "0,0,0,0,0,0,0,0")
@@ -42,8 +43,8 @@ rb = row_bytes_for(N)
 w = PackedCacheWriter(d + "/kmers.seerpack", names)
 rng = np.random.default_rng(0)
 alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
-for s in range(0, V, 1 << 18):
-    nv = min(1 << 18, V - s)
+for s in range(0, V, STORED):
+    nv = min(STORED, V - s)
     bits = bench.synth_bits(nv, N, rb, 7000 + s, dev).cpu().numpy()
     counts = np.unpackbits(bits, axis=1).sum(axis=1).astype(np.int32)
     nm = alphabet[rng.integers(0, 4, 31 * nv)].tobytes()
@@ -60,7 +61,7 @@ try:
 except Exception:
     pass
 env0 = dict(os.environ); env0["PYTHONPATH"] = ROOT; env0["SEERHIP_DEBUG"] = "cli"
-res = {"n_samples": N, "k_mers": V, "block_size": BLK, "cache_GB": os.path.getsize(d + "/kmers.seerpack") / 1e9, "cpu_quota": quota, "nproc": os.cpu_count(), "runs": {}}
+res = {"n_samples": N, "k_mers": V, "block_size": BLK, "stored_block_rows": STORED, "cache_GB": os.path.getsize(d + "/kmers.seerpack") / 1e9, "cpu_quota": quota, "nproc": os.cpu_count(), "runs": {}}
 
 
 def digest(p):
@@ -77,7 +78,7 @@ def run(name, extra, env_more):
     t0 = time.time(); ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     model = (["--no-distances", "--covariates", d + "/cov.tsv", "--use-covariates"] + ["%dq" % j for j in range(2, 12)]) if FIXED else ["--lmm", "--load-lmm", d + "/lmm.npz"]
     r = subprocess.run([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv"] + model +
-                       ["--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup"] + EXTRA + extra,
+                       ["--load-packed", d + "/kmers.seerpack"] + (["--block_size", str(BLK)] if BLK else []) + ["--no-dedup"] + EXTRA + extra,
                        env=env, stdout=open(out, "w"), stderr=subprocess.PIPE)
     dt = time.time() - t0; ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     err = r.stderr.decode()
@@ -117,7 +118,7 @@ def run_procs(name, extra, env_more, nproc=8):
     for i in range(nproc):
         out = d + "/out_%s_%d.tsv" % (name, i)
         procs.append((subprocess.Popen([sys.executable, "-m", "pyseer_amd", "--kmers", d + "/kmers.txt", "--uncompressed", "--phenotypes", d + "/pheno.tsv"] + model +
-                                       ["--load-packed", d + "/kmers.seerpack", "--block_size", str(BLK), "--no-dedup", "--packed-part", "%d/%d" % (i, nproc)] + EXTRA + extra,
+                                       ["--load-packed", d + "/kmers.seerpack"] + (["--block_size", str(BLK)] if BLK else []) + ["--no-dedup", "--packed-part", "%d/%d" % (i, nproc)] + EXTRA + extra,
                                        env=env, stdout=open(out, "w"), stderr=subprocess.PIPE), out))
     errs = [p_.communicate()[1].decode() for p_, _ in procs]
     dt = time.time() - t0
