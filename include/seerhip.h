@@ -301,8 +301,8 @@ int     sh_job_set_samples(sh_job *job, const char *names, const int64_t *name_o
 /* The whole block loop of one stream of a packed cache (pyseer_amd/input.py PackedCacheWriter: the `--save-packed` / `--load-packed` file) in
  * one call -- the loop over load_var_block / fit / print of pyseer/__main__.py:541-593, 777-827 for part `part_i` of `part_n` contiguous ranges
  * of the cache's rows (the reference's `--cpu N`; one part per device).  Stored blocks are merged to at least block_rows rows (never split)
- * exactly as the single stream would cut them; rows go to the device by DMA from registered windows of the file's mapping (use_dma != 0) or
- * through pinned slabs; the text of the printed rows is written to out_fd, the pattern text (sh_job_set_patterns) to pat_fd, in input order.
+ * exactly as the single stream would cut them; rows go to the device by DMA from registered windows of the file's mapping (use_dma != 0; a
+ * block merged from several stored blocks range by range, each to its place) or through pinned slabs; the text of the printed rows is written to out_fd, the pattern text (sh_job_set_patterns) to pat_fd, in input order.
  * counters[0..3] += pre-filtered, tested, printed variants and blocks.  *stop != 0 (may be NULL) ends the stream at the next block.  The
  * calling thread holds no interpreter lock: streams of several contexts run side by side on threads of one process. */
 int     sh_job_run_packed(sh_job *job, const char *path, int part_i, int part_n, int64_t block_rows, int use_dma, int out_fd, int pat_fd,
