@@ -116,6 +116,25 @@ struct alignas(128) Part {                          // (a cache line pair of its
 static constexpr int kMaxParts = 32;
 struct Parts { Part a[kMaxParts]; };
 static Parts &my_parts() { static thread_local Parts p; return p; }
+static Part &my_gather() { static thread_local Part g; return g; }     // the calling thread's gathered text (format_core with own_text)
+
+// The block loop of the library (csrc/job_run.inc) hands a block's gathered text to a writer thread instead of copying it: the calling thread's
+// gather buffer is detached (text must be that buffer; NULL otherwise -- e.g. the one-part case, whose text is the part itself) and a
+// buffer the writer is done with is attached in its place (its pages are already faulted in).
+extern "C" char *format_gather_detach(const char *text, size_t *cap)
+{
+    Part &g = my_gather();
+    if (!text || g.p != text) return nullptr;
+    char *p = g.p; *cap = g.cap;
+    g.p = nullptr; g.n = 0; g.cap = 0;
+    return p;
+}
+extern "C" void format_gather_attach(char *p, size_t cap)
+{
+    Part &g = my_gather();
+    free(g.p);
+    g.p = p; g.n = 0; g.cap = cap;
+}
 
 // how many sinks are inside the formatter right now (tests/test_sink_cpu.py: two sinks format concurrently)
 static std::atomic<int> g_inside{0}, g_inside_max{0};
@@ -198,7 +217,7 @@ static int64_t format_core(const char *names, const int64_t *name_off, const int
     for (int i = 0; i < nth; ++i) start[(size_t)i + 1] = start[(size_t)i] + (int64_t)parts[(size_t)i].n;
     const int64_t total = start[(size_t)nth];
     if (own_text) {                                                        // gather into a buffer of the calling thread's own
-        static thread_local Part gather;
+        Part &gather = my_gather();
         gather.n = 0; gather.room((size_t)total + 16);
         out = gather.p; cap = total; *own_text = gather.p;
     }

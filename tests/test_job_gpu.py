@@ -395,6 +395,51 @@ def test_the_librarys_own_block_loop_over_a_packed_cache(lmm, tmp_path):
     job.close(); e.close()
 
 
+@pytest.mark.parametrize("lmm", [True, False])
+def test_the_block_loop_writes_large_texts_through_its_writer_thread(lmm, tmp_path):
+    """Every row printed (the reference's default thresholds; here --print-filtered too): a block's text is several MB, formatted in parts and
+    gathered, and sh_job_run_packed hands the gather buffer itself to its writer thread (csrc/job_run.inc OutWriter: detached, a finished one
+    attached in its place) -- seven blocks, so buffers are recycled, between small ones that travel as copies.  Same bytes, same order as the
+    blocks collected one by one from Python; pattern text too."""
+    from pyseer_amd.engine import Job
+    from pyseer_amd.input import PackedCacheWriter
+    N = 300
+    e = _setup(lmm, N, pret=1.0, lrtt=1.0)
+    names = ["s%d" % i for i in range(N)]
+    sizes = [30000, 50, 30000, 30000, 7, 30000, 30000, 30000, 30000, 900]
+    blocks = [_rows(N, v, 1700 + i) for i, v in enumerate(sizes)]
+    path = str(tmp_path / "big.seerpack")
+    w = PackedCacheWriter(path, names)
+    for bits, counts, blob, off in blocks:
+        w.write_block(blob, off, counts, bits)
+    w.close()
+    job = Job(e, lmm, True, patterns=True)
+    text, pat, cnt = [], [], [0, 0, 0]
+    for bits, counts, blob, off in blocks:
+        job.submit(bits, counts, blob, off)
+        t, c, _ = job.collect(); text.append(bytes(t)); pat.append(bytes(job.patterns()))
+        for a in range(3):
+            cnt[a] += c[a]
+    job.close()
+    want = b"".join(text), b"".join(pat)
+    assert max(len(t) for t in text) > (1 << 21) and cnt[2] == sum(sizes)          # every row printed; the large blocks' texts are over 2 MB
+    job = Job(e, lmm, True, patterns=True)
+    fo, fp = str(tmp_path / "o.tsv"), str(tmp_path / "p.txt")
+    with open(fo, "wb") as a, open(fp, "wb") as b:
+        c = job.run_packed(path, (0, 1), 1, out_fd=a.fileno(), pat_fd=b.fileno())
+    job.close()
+    assert (open(fo, "rb").read(), open(fp, "rb").read()) == want and tuple(c[:3]) == tuple(cnt) and c[3] == len(sizes)
+    # a descriptor that cannot be written to: the stream ends with an error, not with a short file
+    job = Job(e, lmm, True)
+    rd = os.open(fo, os.O_RDONLY)
+    from pyseer_amd import _abi
+    with pytest.raises(_abi.SeerHipError) as ei:
+        job.run_packed(path, (0, 1), 1, out_fd=rd)
+    os.close(rd)
+    assert "writing the output failed" in str(ei.value)
+    job.close(); e.close()
+
+
 def test_the_block_loop_on_edge_caches(tmp_path):
     """sh_job_run_packed on the edges: a cache without a single block, one stored block shared out to three parts (two of them own nothing),
     and more parts than rows -- counters zero where nothing is owned, the parts still concatenate to the whole."""
