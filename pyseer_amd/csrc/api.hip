@@ -60,7 +60,17 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SH_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-template <typename T> static hipError_t dmalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)); }
+// (SEERHIP_DEBUG=poison: every allocation filled with 0xFF bytes -- NaN as a float or a double, -1 as an index -- so that a kernel that reads what
+// nobody wrote fails a test at once instead of when the allocator happens to hand out a dirty page: tools/gpu_poison.sh)
+template <typename T> static hipError_t dmalloc(T **p, size_t n)
+{
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T));
+    if (e == hipSuccess && n && sh_debug("poison")) {               // (complete before anybody's stream can write the buffer)
+        const hipError_t m = hipMemset(*p, 0xFF, n * sizeof(T));
+        return m != hipSuccess ? m : hipStreamSynchronize(nullptr);
+    }
+    return e;
+}
 
 struct sh_lanes;
 // what sh_glm_setup was called with: the lanes of the context (lanes_api.inc) are set up from it

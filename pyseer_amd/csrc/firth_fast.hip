@@ -174,7 +174,13 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     constexpr int NPIECE = (NTA * 2 + 2 + 3) & ~3, STAGE = NPIECE * 1024;
     // (the single-precision pass takes the tables' hi halves only: one product per tile, 2^-11 on sums that need 1e-5)
     constexpr int NFETCH = F32 ? NTA + 2 : NTA * 2 + 2, NPW = (NFETCH + 3) / 4;     // 1 KB pieces, NPW per wavefront (the last ones padding)
-    constexpr int NRING = 3;
+    // Ring of FOUR stages, copies issued THREE iterations ahead (round 6; was three / two).  Iteration g reads stage g and -- its last pair's
+    // read-ahead: the next group's first record and first fragment -- stage g + 1, so stage g + 1 must have landed for EVERY wavefront when g
+    // starts: the end of iteration g - 1 waits for this wavefront's share of everything but the copies issued last (stage g + 2) and then takes
+    // the barrier.  With copies only two ahead that wait covered stage g, and stage g + 1 was read on the strength of having been in flight for a
+    // whole iteration: 5 400 cycles at Q = 10 in fp64, but ~1 500 in the single-precision pass at Q <= 3 -- less than a loaded memory system's
+    // latency: 5 of 60 repeated calls differed (tools/gpu_firth_determinism.py, profiles/r06/firth_determinism.txt).
+    constexpr int NRING = 4;
     char *const lds = (char *)xw_lds;
     const char *const tab_g = (const char *)P.ff_tab;
     const char *const rec_g = F32 ? (const char *)P.ff_rec32 : (const char *)P.ff_rec;
@@ -303,8 +309,8 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     // A group = 8 samples per lane = four pairs; the MFMAs of the PREVIOUS group's operands are issued AMONG the pairs' arithmetic (the matrix
     // core works beside the vector ALU only if the instruction stream alternates: sched_group_barrier), table tiles pp, pp + 4, pp + 8 ...
     // behind pair pp (an even share of the MFMAs: a degree-2 tile carries six, a degree-3 tile three), their A fragments read from LDS ahead of
-    // the pair.  The tables of iteration g + 2 are in flight while g computes (ring of NRING buffers): the end of an iteration waits for its
-    // wavefront's share of g + 1 only.
+    // the pair.  The tables of iterations g + 2 and g + 3 are in flight while g computes (ring of NRING buffers): the end of an iteration waits for its
+    // wavefront's share of g + 1 and g + 2 only.
     constexpr int PER = (NTA + 3) / 4;
     RT ra[RS], rb[RS];
     uint64_t w64 = 0, wnext = T[v];
@@ -328,7 +334,8 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
     };
     dma(0);
     dma(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    dma(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");         // (stages 0 and 1 have landed; stage 2 may be in flight)
     __syncthreads();
     fetch_rec(lds, 0, ra);
     ff_v4u ah[PER], al[PER];                                                    // the slot's A fragments: [0] read a sample ahead of the rest
@@ -339,14 +346,14 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
             wnext = T[(int64_t)min((g >> 2) + 1, P.NB64 - 1) * Vpad + v];
         }
         const uint32_t byte = ((uint32_t)(w64 >> (16 * (g & 3) + 8 * h)) & 0xffu) ^ flipm;
-        if (!(FF_ABL & 2)) dma(min(g + 2, NG));
+        if (!(FF_ABL & 2)) dma(min(g + 3, NG));
 #if FF_STAGGER
         // the four wavefronts leave the barrier together and would hit the LDS with their reads at the same moments of every pair: a quarter of
         // a pair's time apart they find it free
         if (wave == 1) __builtin_amdgcn_s_sleep(FF_STAGGER); else if (wave == 2) __builtin_amdgcn_s_sleep(2 * FF_STAGGER); else if (wave == 3) __builtin_amdgcn_s_sleep(3 * FF_STAGGER);
 #endif
         const char *const buf = lds + (g % NRING) * STAGE;
-        const char *const bufn = lds + ((g + 1) % NRING) * STAGE;               // (landed: the end of the previous iteration waited for it)
+        const char *const bufn = lds + ((g + 1) % NRING) * STAGE;               // (landed: the end of the previous iteration waited for everything but stage g + 2)
         // A pair of samples = one slot.  LDS reads are issued a whole sample ahead of their use and the fences keep them there (left alone the
         // compiler clusters them in front of their first use: 22 exposed LDS latencies per group, a third of the kernel's time):
         //   [record of the odd sample, fragments 1..]  |  even sample + the MFMAs of fragment 0  |  [record of the next even sample, the next
@@ -403,7 +410,7 @@ void k_firth_fast(const uint64_t *__restrict__ T, int64_t Vpad, GlmParams P, Fir
 #pragma unroll
             for (int e = 0; e < 4; ++e) { Pw[q2][e] = Bw[q2][e]; Pc[q2][e] = Bc[q2][e]; Pk[q2][e] = Bk[q2][e]; Px[q2][e] = Bx[q2][e]; }
         if (!F32 && (g & 3) == 3) { int e2; prod = frexp(prod, &e2); pexp += e2; }
-        // this wavefront's share of the NEXT iteration's tables has landed (the one after it may still be in flight), then the bare barrier:
+        // this wavefront's share of the next TWO iterations' tables has landed (the copies issued last, stage g + 3, may still be in flight), then the bare barrier:
         // everyone's has, and everyone is done reading this iteration's buffer.  (__syncthreads() would add a vmcnt(0) and wait for both)
         if (!(FF_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
     };
@@ -568,7 +575,7 @@ static hipError_t launch_firth_fast(hipStream_t st, int64_t n, const uint64_t *T
                                     uint32_t *flags)
 {
     if (n <= 0) return hipSuccess;
-    constexpr size_t lds = 3 * (size_t)((FFC<Q>::NTA * 2 + 2 + 3) & ~3) * 1024;
+    constexpr size_t lds = 4 * (size_t)((FFC<Q>::NTA * 2 + 2 + 3) & ~3) * 1024;      // NRING stages
     hipLaunchKernelGGL((k_firth_fast<Q, F32>), dim3((unsigned)((n + 127) / 128)), dim3(256), lds, st, T, Vpad, P, fw, in_list, in_count, next_fast, next_fast_count,
                        exact_list, exact_count, V, out, flags);
     return hipGetLastError();
