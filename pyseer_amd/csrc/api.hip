@@ -60,6 +60,22 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(SH_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+// SEERHIP_DEBUG=backtrace: a native backtrace on stderr when the process aborts (SIGABRT: an assertion of a runtime underneath, glibc's heap
+// checks, std::terminate) or faults -- Python's faulthandler shows the interpreter's frames only.
+#include <execinfo.h>
+#include <signal.h>
+static void sh_abort_backtrace(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "[seerhip] fatal signal; native backtrace of the signalled thread:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+namespace { struct ShBacktraceInit { ShBacktraceInit() { if (sh_debug("backtrace")) { signal(SIGABRT, sh_abort_backtrace); signal(SIGSEGV, sh_abort_backtrace); signal(SIGBUS, sh_abort_backtrace); } } } sh_backtrace_init; }
+
 // (SEERHIP_DEBUG=poison: every allocation filled with 0xFF bytes -- NaN as a float or a double, -1 as an index -- so that a kernel that reads what
 // nobody wrote fails a test at once instead of when the allocator happens to hand out a dirty page: tools/gpu_poison.sh)
 template <typename T> static hipError_t dmalloc(T **p, size_t n)

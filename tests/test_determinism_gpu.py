@@ -19,23 +19,27 @@ if ROOT not in sys.path:
 
 
 class _Busy(object):
-    """another stream of the device saturated with matrix products while the calls under test run"""
+    """a second context of the library on the same device, testing batches of its own on a thread of its own while the calls under test run
+    (the library's own concurrency, as tests/test_glm_gpu.py::test_contexts_on_one_device_run_concurrently_and_agree_bit_for_bit uses it;
+    tools/gpu_firth_determinism.py loads the device with matrix products of another framework instead)"""
     def __enter__(self):
-        import torch
+        import bench
+        from pyseer_amd.engine import Engine, pack_variants
         self.stop = False
+        N, q = 1000, 10
+        y, W, nl, nf = bench.synth_glm_inputs(N, q)
+        rng = np.random.default_rng(1)
+        bits = pack_variants((rng.random((16384, N)) < rng.uniform(0.05, 0.95, 16384)[:, None]).astype(np.uint8))
+        self.e = Engine(N); self.e.set_af_filter(0.01, 0.99); self.e.glm_setup(y, W, False, nl, nf)
 
         def run():
-            a = torch.randn(4096, 4096, device="cuda"); s = torch.cuda.Stream()
-            with torch.cuda.stream(s):
-                while not self.stop:
-                    for _ in range(8):
-                        a = (a @ a).clamp(-1, 1)
-                    s.synchronize()
+            while not self.stop:
+                self.e.glm_batch(bits)
         self.th = threading.Thread(target=run); self.th.start()
         return self
 
     def __exit__(self, *exc):
-        self.stop = True; self.th.join()
+        self.stop = True; self.th.join(); self.e.close()
 
 
 def _same(a, b):

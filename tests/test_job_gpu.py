@@ -97,6 +97,9 @@ def test_job_stream_equals_the_block_sink(lmm, pret, lrtt, print_filtered):
         assert all(c[2] == s for (_, c), s in zip(got, sizes))
 
 
+_KEPT = []
+
+
 def test_job_stream_reads_registered_rows_by_dma():
     """rows_are_dma: the device reads the rows where they lie (sh_host_register on the caller's memory, as the CLI does with the windows of the
     packed-cache mapping); same text as the staged copy."""
@@ -107,6 +110,7 @@ def test_job_stream_reads_registered_rows_by_dma():
     e = _setup(True, N)
     bits, counts, blob, off = _rows(N, 5000, 7)
     big = np.zeros((3 << 20,), dtype=np.uint8)                       # a page-aligned window well above the 1 MB the CLI bothers with
+    _KEPT.append(big)                                                # (never freed: its address range is not handed out again in this session)
     view = big[:bits.size].reshape(bits.shape); view[:] = bits
     assert lib.sh_host_register(view.ctypes.data, view.nbytes, 0) == 0, lib.sh_last_error()
     job = Job(e, True)
