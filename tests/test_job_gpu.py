@@ -380,10 +380,11 @@ def test_the_librarys_own_block_loop_over_a_packed_cache(lmm, tmp_path):
     assert len(want[0]) > 1000 and len(want[1]) == 25 * want[2][1]
     # several DMA windows in this small cache (route key dma_window: bytes registered at a time): merged groups whose stored blocks lie in two
     # windows are copied range by range from both, a block that starts on the page a window ends on belongs to none and its group is staged
-    for window in (4096, 30000, 100000):
+    # (one window size: every call registers and lets go a dozen small ranges of the same re-mapped file -- enough of that for one session)
+    for window in (30000,):
         os.environ["SEERHIP_ROUTE"] = "dma_window=%d" % window
         try:
-            for block_rows in (1, 1000, 4000):
+            for block_rows in (1000, 4000):
                 assert by_library(block_rows) == by_python(block_rows), (window, block_rows)
             parts = [by_library(4000, (i, 2)) for i in range(2)]
         finally:
