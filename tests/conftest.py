@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# glibc writes its fatal messages (heap consistency checks, fortify, stack protector) to the controlling terminal when there is one, and
+# only otherwise to stderr: a session that aborts must say why in its log ("open at the end of round 6")
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
