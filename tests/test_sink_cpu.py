@@ -204,3 +204,49 @@ def test_format_records_equals_format_rows():
     fl = np.full(nv, -1, np.int32); fl[idx] = lin
     assert got_lin == RowFormatter(labels).format(blob, off, idx.astype(np.int64), full, ff, fb, fv, fl)
     assert got_lin != got and got_lin.count(b"\tNA\t") >= int((lin < 0).sum())
+
+
+def test_the_gather_buffer_can_be_handed_over_and_replaced():
+    """csrc/writer.cpp format_gather_detach / format_gather_attach: the block loop's writer thread (csrc/job_run.inc OutWriter) takes the formatter's
+    gathered text as the buffer itself and gives a finished buffer back.  Detaching anything but the calling thread's gather buffer is refused;
+    after a detach the next call gathers into a fresh buffer, after an attach into the one given -- the same text every time."""
+    import ctypes as C
+    from pyseer_amd import _abi
+    from pyseer_amd.sink import names_blob
+    lib = _abi.load()
+    lib.format_gather_detach.restype = C.c_void_p; lib.format_gather_detach.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.format_gather_attach.restype = None; lib.format_gather_attach.argtypes = [C.c_void_p, C.c_size_t]
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(9)
+    nv, n_samples = 30000, 500
+    blob, off = names_blob(["K%d" % i for i in range(nv)])
+    counts = rng.integers(0, n_samples + 1, nv).astype(np.int32)
+    idx = np.arange(nv, dtype=np.int32)
+    cols = rng.normal(size=(5, nv))
+    flags = np.zeros(nv, np.uint32)
+    cp = (_abi.c_dp * 5)(*[cols[a].ctypes.data_as(_abi.c_dp) for a in range(5)])
+
+    def fmt():
+        text = C.c_void_p()
+        n = lib.sh_format_records(blob, off.ctypes.data_as(C.POINTER(C.c_int64)), counts.ctypes.data_as(C.POINTER(C.c_int32)), n_samples,
+                                  idx.ctypes.data_as(C.POINTER(C.c_int32)), nv, cp, 5, None, 0, 0, None, None, None, 0,
+                                  flags.ctypes.data_as(_abi.c_u32p), C.byref(text))
+        return text.value, n
+    if lib.sh_host_cpus() < 2:
+        import pytest
+        pytest.skip("one CPU: the text is the one part itself, nothing is gathered")
+    t0, n0 = fmt()
+    want = C.string_at(t0, n0)
+    assert n0 > (1 << 20)
+    cap = C.c_size_t(0)
+    assert lib.format_gather_detach(t0 + 1, C.byref(cap)) is None            # not the gather buffer
+    p = lib.format_gather_detach(t0, C.byref(cap))
+    assert p == t0 and cap.value >= n0
+    assert lib.format_gather_detach(t0, C.byref(cap)) is None                # already gone
+    t1, n1 = fmt()                                                          # a fresh buffer; the detached one is still ours
+    assert C.string_at(t1, n1) == want and C.string_at(p, n0) == want
+    if lib.sh_host_cpus() > 1:
+        assert t1 != p
+    lib.format_gather_attach(p, cap)                                        # (frees the fresh buffer, gathers into the old one from now on)
+    t2, n2 = fmt()
+    assert t2 == p and C.string_at(t2, n2) == want
